@@ -1,0 +1,5 @@
+"""omok-ai_amd — MI355X-native batched self-play engine for the `mcts` + `alpha-zero` hot path
+of AcrylicShrimp/omok-ai.  The compute lives in csrc/ (HIP kernels behind the C ABI declared in
+include/omok_mi355x.h); this package is the thin Python host mirror of the reference's crate API.
+"""
+from . import weights  # noqa: F401

@@ -1,0 +1,68 @@
+"""Oracle net vs the independent torch fixtures; RNG contract known answers."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+import omok_ai_amd  # noqa: F401
+from omok_ai_amd import weights
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("n", [9, 15])
+def test_net_matches_torch_fixture(n):
+    g = np.load(os.path.join(GOLD, f"net_n{n}.npz"))
+    tensors = weights.init_random(n, seed=int(g["seed"]))
+    assert weights.checksum(tensors) == pytest.approx(float(g["weight_checksum"]), rel=1e-12)
+    net = O.Net(n, tensors)
+    p, v = net.forward(g["inputs"], threads=4)
+    assert np.abs(p - g["p"]).max() < 1e-4  # fp32 restatement vs float64 torch (fp32 rounding only)
+    assert np.abs(v - g["v"]).max() < 1e-4
+    assert np.allclose(p.sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_weight_tensor_sizes():
+    for n, total in ((9, 5643250), (15, 15154306)):
+        shapes = weights.tensor_shapes(n)
+        assert len(shapes) == 31 == O.lib().orc_net_num_tensors()
+        assert sum(int(np.prod(s)) for s in shapes) == total
+        net = O.Net(n)
+        for i, s in enumerate(shapes):
+            assert O.lib().orc_net_tensor_size(net.h, i) == int(np.prod(s))
+
+
+def test_philox_known_answers():
+    """Philox4x32-10 KATs from the Random123 distribution (kat_vectors)."""
+    out = (C.c_uint32 * 4)()
+    O.lib().orc_philox(0, 0, 0, 0, 0, out)
+    assert list(out) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    O.lib().orc_philox(0xffffffffffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, out)
+    assert list(out) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    O.lib().orc_philox((0x299f31d0 << 32) | 0xa4093822, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, out)
+    assert list(out) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_det_log_exp_accuracy():
+    L = O.lib()
+    for x in [1e-300, 1e-10, 0.03, 0.5, 0.9999, 1.0, 1.5, 2.0, 10.0, 12345.678, 1e300]:
+        assert L.orc_det_log(x) == pytest.approx(math.log(x), rel=1e-14, abs=1e-15)
+    for x in [-700.0, -50.0, -1.0, -1e-9, 0.0, 1e-9, 0.5, 1.0, 3.3, 50.0, 700.0]:
+        assert L.orc_det_exp(x) == pytest.approx(math.exp(x), rel=1e-14)
+    assert L.orc_det_exp(-800.0) == 0.0
+    for x in np.linspace(0.0, 1.0, 33, dtype=np.float32):
+        assert abs(L.orc_det_expf(float(x)) - np.exp(np.float32(x))) <= 2e-7 * np.exp(x)
+
+
+def test_gamma_distribution():
+    """Dirichlet noise source: Gamma(alpha) draws have mean alpha (and variance alpha)."""
+    L = O.lib()
+    for alpha in (0.03, 0.5, 1.0, 2.5):
+        xs = np.array([L.orc_gamma(alpha, 123, c % 200, c // 200, 7) for c in range(20000)], dtype=np.float64)
+        assert np.all(xs >= 0)
+        assert xs.mean() == pytest.approx(alpha, rel=0.08)
+        assert xs.var() == pytest.approx(alpha, rel=0.2)
+    assert L.orc_gamma(0.03, 1, 2, 3, 4) == L.orc_gamma(0.03, 1, 2, 3, 4)

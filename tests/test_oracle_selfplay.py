@@ -1,0 +1,112 @@
+"""Oracle tree search / self-play: regression fixture + structural invariants of Appendix A."""
+import hashlib
+import os
+
+import numpy as np
+
+import omok_ai_amd  # noqa: F401
+from omok_ai_amd import weights
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _fingerprint(sp, games):
+    h = hashlib.sha256()
+    for g in range(games):
+        for side in (0, 1):
+            ints, floats = sp.tree_dump(g, side)
+            h.update(ints.tobytes())
+            h.update(floats.tobytes())
+            h.update(np.array(sp.tree_root(g, side)[:1], dtype=np.uint32).tobytes())
+    return h.hexdigest()
+
+
+def check_tree_invariants(ints, floats, root_n, hw):
+    n_nodes = ints.shape[0]
+    parent, action, status, turn, legal, nch, n = (ints[:, i] for i in range(7))
+    order = ints[:, 7] & 0xffff
+    assert parent[0] == -1
+    assert np.all(parent[1:] < np.arange(1, n_nodes))  # creation order
+    assert np.all(parent[1:] >= 0)
+    kids = np.bincount(parent[1:], minlength=n_nodes) if n_nodes > 1 else np.zeros(n_nodes, dtype=int)
+    assert np.array_equal(kids, nch)
+    for i in range(1, n_nodes):
+        assert legal[i] == legal[parent[i]] - 1
+        assert turn[i] == 1 - turn[parent[i]]
+        assert status[parent[i]] == 0  # terminal nodes are never expanded
+    # insertion ranks of siblings are a permutation of 0..nch-1
+    for pnode in np.unique(parent[1:]):
+        r = np.sort(order[1:][parent[1:] == pnode])
+        assert np.array_equal(r, np.arange(len(r)))
+    # visit counts: n(node) >= sum of children n (pending/terminal self-visits make it larger)
+    csum = np.zeros(n_nodes, dtype=np.int64)
+    np.add.at(csum, parent[1:], n[1:])
+    assert root_n >= csum[0] or root_n == csum[0]
+    eff = floats[:, 1:]
+    assert np.all(eff >= 0)
+
+
+def test_selfplay_fixture_and_invariants():
+    g = np.load(os.path.join(GOLD, "selfplay_n9.npz"))
+    n, games, count, k = int(g["n"]), int(g["games"]), int(g["count"]), int(g["k"])
+    tensors = weights.init_random(n, seed=0)
+    net = O.Net(n, tensors)
+    root_p, _ = net.forward(O.Environment(n).encode_nn_input(0)[None])
+    sp = O.SelfPlay(n, games, cap_nodes=2048, cap_tables=1024, seed=int(g["seed"]))
+    sp.reset(root_p[0])
+    ply = 0
+    while sp.alive_count > 0:
+        for rnd in range((count + k - 1) // k):
+            inp = sp.round_generate(rnd, k, 0.25, 0.03)
+            if len(inp):
+                p, v = net.forward(inp, threads=4)
+                sp.round_scatter(p, v)
+        side = sp.ply & 1
+        for gi in range(games):
+            if sp.game_alive(gi):
+                ints, floats = sp.tree_dump(gi, side)
+                check_tree_invariants(ints, floats, sp.tree_root(gi, side)[0], n * n)
+        a = sp.sample(1.0, int(g["threshold"]))
+        assert np.array_equal(a, g["actions"][ply]), f"ply {ply}"
+        p, _ = net.forward(sp.mirror_generate(), threads=4)
+        sp.advance(p)
+        assert _fingerprint(sp, games) == str(g["fingerprints"][ply]), f"ply {ply}"
+        ply += 1
+    assert sp.error == 0
+    assert [sp.game_status(i) for i in range(games)] == list(g["status"])
+    assert [sp.game_plies(i) for i in range(games)] == list(g["plies"])
+    # replay tuples: board before the move, pi sums to 1, z only on the winning ply
+    for gi in range(games):
+        boards, turns, pi, z = sp.replay(gi)
+        assert len(boards) == sp.game_plies(gi)
+        assert np.allclose(pi.sum(axis=1), 1.0, atol=1e-5)
+        assert np.all(turns == np.arange(len(turns)) % 2)
+        assert np.all((boards != 0).sum(axis=1) == np.arange(len(boards)))
+        assert np.all(z[:-1] == 0) and z[-1] == (1.0 if sp.game_status(gi) >= 2 else 0.0)
+
+
+def test_first_round_semantics():
+    """A6/A4: with root n=0 every sim of the first rounds expands a distinct root child; pending
+    children get no statistics until scatter; sims/move rounds up to a multiple of K."""
+    n, k = 9, 8
+    hw = n * n
+    sp = O.SelfPlay(n, 1, cap_nodes=512, cap_tables=256, seed=3)
+    sp.reset(np.full(hw, 1.0 / hw, dtype=np.float32))
+    inp = sp.round_generate(0, k, 0.25, 0.03)
+    assert len(inp) == k
+    ints, floats = sp.tree_dump(0, 0)
+    assert ints.shape[0] == 1 + k and np.all(ints[1:, 0] == 0) and np.all(ints[1:, 6] == 0)
+    assert np.all((ints[1:, 7] >> 16) == 0)  # pending: placeholder policy
+    assert np.allclose(floats[1:, 1:].max(axis=1), 1.0 / (hw - 1))
+    assert abs(floats[0, 1:].sum() - 1.0) < 1e-5  # noised root policy renormalised
+    v = np.linspace(-0.5, 0.5, k).astype(np.float32)
+    sp.round_scatter(np.full((k, hw), 1.0 / hw, dtype=np.float32), v)
+    ints, floats = sp.tree_dump(0, 0)
+    assert np.all(ints[1:, 6] == 1) and np.all((ints[1:, 7] >> 16) == 1)
+    assert np.array_equal(floats[1:, 0], -v)  # child.w = -value (pme.rs:229)
+    rn, rw, _, _ = sp.tree_root(0, 0)
+    assert rn == k
+    # masked + renormalised policy: occupied cell is 0 (pme.rs:235-249)
+    for i in range(1, 1 + k):
+        assert floats[i, 1 + ints[i, 1]] == 0.0 and abs(floats[i, 1:].sum() - 1.0) < 1e-5
