@@ -1,0 +1,168 @@
+/*
+ * omok_mi355x.h — C ABI of the MI355X-native self-play engine (libomok_mi355x.so).
+ *
+ * Drop-in boundary for the `environment` + `mcts` + `alpha-zero` self-play path of
+ * AcrylicShrimp/omok-ai.  The reference has no FFI; the path sits behind Rust crate `pub` APIs.
+ * Each entry point below names the reference interface it replaces (file:line in the reference
+ * tree).  Plain pointers and sizes only; every buffer is caller-owned host memory unless the
+ * name ends in `_dev`.  All device state is owned by the opaque handle.
+ *
+ * Conventions
+ *   - return value: 0 = OK, < 0 = error (OMOK_ERR_*); omok_last_error() gives the text.
+ *     Nothing throws or aborts across this boundary (the reference returns Result<_, Status>
+ *     / Option and its callers unwrap()).
+ *   - enums are the reference's declaration order (environment/src/lib.rs:5-9,22-25,46-51):
+ *       Stone {Empty=0, Black=1, White=2}; Turn {Black=0, White=1};
+ *       GameStatus {InProgress=0, Draw=1, BlackWin=2, WhiteWin=3}; Option::None -> -1.
+ *   - a handle is single-owner (one host thread per GPU); calls block until the work they
+ *     describe is complete (mirrors Session::run) unless documented otherwise.
+ *   - RNG: the reference is unseeded (thread_rng).  This library defines the stream
+ *     (Philox4x32-10, see DESIGN.md "RNG contract"); `seed` and `game_offset` select it.
+ */
+#ifndef OMOK_MI355X_H
+#define OMOK_MI355X_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMOK_OK 0
+#define OMOK_ERR_INVALID (-1)     /* bad argument */
+#define OMOK_ERR_HIP (-2)         /* HIP runtime failure (no GPU, OOM, launch error) */
+#define OMOK_ERR_STATE (-3)       /* call order violated / net not loaded */
+#define OMOK_ERR_OVERFLOW (-4)    /* a tree arena (max_nodes / max_tables) overflowed */
+#define OMOK_ERR_ILLEGAL (-5)     /* illegal game operation (Option::None in the reference) */
+
+#define OMOK_MODE_PLAYER 0   /* EnvTurnMode::Player   (alpha-zero/src/encoder.rs:4-8) */
+#define OMOK_MODE_OPPONENT 1 /* EnvTurnMode::Opponent */
+
+#define OMOK_NET_F16X3 0 /* split-fp16 MFMA (hi+lo operands, 3 MFMAs per product, fp32 accumulate) */
+#define OMOK_NET_F32 1   /* plain fp32 VALU kernels (debug / A-B reference on the GPU) */
+
+typedef struct omok_engine omok_engine;
+
+typedef struct {
+    int32_t board_size;  /* N: 9 (reference, environment/src/lib.rs:70) or 15 */
+    int32_t games;       /* G concurrent games = episode_count (src/config.rs:90); two trees each */
+    int32_t max_nodes;   /* per-tree node arena (<= 65535) */
+    int32_t max_tables;  /* per-tree child-table arena (<= 65535) */
+    int32_t max_batch_k; /* largest evaluate_batch_size that will be used (<= 64) */
+    int32_t device;      /* HIP device ordinal */
+    int32_t net_mode;    /* OMOK_NET_* */
+    int32_t reserved;
+    uint64_t seed;       /* RNG key */
+    int64_t game_offset; /* global id of game 0 (multi-GPU sharding: rank * games) */
+} omok_config;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int omok_create(const omok_config* cfg, omok_engine** out);
+void omok_destroy(omok_engine* e);
+const char* omok_last_error(const omok_engine* e); /* e may be NULL: error of the last failed create */
+
+/* ---- policy/value net: AgentModel (alpha-zero/src/agent_model.rs:105-134) over Network
+ *      (alpha-zero/src/network.rs:51-262).  31 tensors in the reference's variable order
+ *      (network.rs:78-79,113-122,149-150,162-163,201-202,240-241), conv kernels HWIO, fc [in,out].
+ *      This is also the positional order of ModelIO::load (alpha-zero/src/model_io.rs:92-120). */
+int omok_net_num_tensors(void);
+int64_t omok_net_tensor_size(const omok_engine* e, int index);
+int omok_net_load(omok_engine* e, int index, const float* data, int64_t count);
+int omok_net_commit(omok_engine* e); /* pack into MFMA operand layouts; required before any eval */
+/* AgentModel::evaluate_pv (agent_model.rs:116-134): in [B][N][N][3] f32 (encoder.rs layout),
+ * p [B][N*N] softmax probabilities, v [B] tanh.  evaluate_p (:105-114) = same with v NULL. */
+int omok_evaluate_pv(omok_engine* e, const float* in, int32_t batch, float* p, float* v);
+
+/* ---- environment crate on device (environment/src/lib.rs:62-166), batched.
+ *      Plays `len` moves per row from Environment::new(); status_out[b][i] is the
+ *      Option<GameStatus> of move i (-1 = None: occupied cell, the board is left unchanged).
+ *      boards_out [B][N*N] Stone bytes, turns_out [B], legal_out [B] (legal_move_count). */
+int omok_env_play(omok_engine* e, const int32_t* moves, int32_t batch, int32_t len,
+                  int32_t* status_out, uint8_t* boards_out, uint8_t* turns_out, uint16_t* legal_out);
+/* encode_nn_input (alpha-zero/src/encoder.rs:10-46) for `batch` environments given as
+ * Stone-byte boards + side to move; out [batch][N][N][3] f32. */
+int omok_encode_nn_input(omok_engine* e, const uint8_t* boards, const uint8_t* turns, int32_t batch,
+                         int32_t mode, float* out);
+
+/* ---- self-play: G games x two agents (src/trainer.rs:81-205) ---------------------------- */
+/* Agent::new for both agents of every game (alpha-zero/src/agent.rs:16-35): root policy = raw
+ * evaluate_p of the empty board.  Also clears the replay buffer. */
+int omok_selfplay_reset(omok_engine* e);
+/* ParallelMCTSExecutor::execute (alpha-zero/src/parallel_mcts_executor.rs:26-35) on the
+ * side-to-move agents of all live games: rounds of `batch_size` simulations per tree, one net
+ * forward per round, ordered scatter; simulations round up to a multiple of batch_size. */
+int omok_execute(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha);
+/* Agent::sample_action for every live game (agent.rs:83-137) with the trainer's mode rule
+ * (trainer.rs:138-146): Boltzmann(temperature) while the game's ply < threshold, else Best.
+ * Records the transition (env before the move, pi) like trainer.rs:150-173.
+ * actions [G]: chosen cell, -1 for finished games.  May be NULL. */
+int omok_sample_actions(omok_engine* e, float temperature, int32_t threshold, int32_t* actions);
+/* Agent::play_action on the mover's tree, then ensure_action_exists + play_action on the
+ * opponent's tree (agent.rs:144-232, trainer.rs:156-167), finished games retire
+ * (trainer.rs:175-201).  Uses the actions chosen by the last omok_sample_actions. */
+int omok_advance(omok_engine* e);
+/* whole self-play phase of one trainer iteration (trainer.rs:95-205): repeats
+ * execute/sample/advance until every game is finished or max_plies (>0) plies were played.
+ * stats (may be NULL, 16 doubles): see OMOK_STAT_* */
+int omok_selfplay_run(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha,
+                      float temperature, int32_t threshold, int32_t max_plies, double* stats);
+
+/* step-wise form of execute() for parity tests: generate -> (eval | inject) -> scatter */
+int omok_round_generate(omok_engine* e, int32_t round, int32_t batch_size, float epsilon, float alpha,
+                        int32_t* n_requests);
+int omok_round_inputs(omok_engine* e, float* inputs /* [n_requests][N][N][3] */);
+int omok_round_eval(omok_engine* e);
+int omok_round_outputs(omok_engine* e, float* p, float* v);
+int omok_round_inject(omok_engine* e, const float* p, const float* v);
+int omok_round_scatter(omok_engine* e);
+/* step-wise form of the opponent-tree mirror eval inside omok_advance */
+int omok_mirror_generate(omok_engine* e, int32_t* n_requests);
+int omok_mirror_inputs(omok_engine* e, float* inputs);
+int omok_mirror_eval(omok_engine* e);
+int omok_mirror_outputs(omok_engine* e, float* p);
+int omok_mirror_inject(omok_engine* e, const float* p);
+int omok_mirror_apply(omok_engine* e);
+
+/* ---- inspection ------------------------------------------------------------------------ */
+int omok_alive_count(omok_engine* e);                  /* >= 0, or error */
+int omok_current_ply(omok_engine* e);
+int omok_game_info(omok_engine* e, uint8_t* alive, uint8_t* status, int32_t* plies); /* each [G], may be NULL */
+/* canonical dump of one tree (MCTS::root / Node fields, mcts/src/node.rs:10-21):
+ * ints [n][8] = parent, action, status, turn, legal_move_count, children, n, order|has_policy<<16
+ * floats [n][1+N*N] = w, policy row.  returns the node count (or -count if cap is too small). */
+int omok_tree_dump(omok_engine* e, int32_t game, int32_t side, int32_t* ints, float* floats, int32_t cap_nodes);
+int omok_tree_root(omok_engine* e, int32_t game, int32_t side, uint32_t* root_n, float* root_w,
+                   int32_t* n_nodes, int32_t* n_tables);
+/* Transition{env, policy, z} records of one game (trainer.rs:20-24,169-173; z as recorded at play
+ * time, before the back-fill of trainer.rs:207-214).  returns the ply count. */
+int omok_replay_game(omok_engine* e, int32_t game, uint8_t* boards, uint8_t* turns, float* pi, float* z,
+                     int32_t cap_plies);
+/* replay tuples of all games packed on the device for an RCCL gather: record = board u8[N*N],
+ * turn u8, pad to 4, pi f32[N*N], z f32.  Writes at most cap_records to dst_dev (a device
+ * pointer the caller owns, e.g. a torch tensor) and returns the record count. */
+int64_t omok_replay_pack_dev(omok_engine* e, void* dst_dev, int64_t cap_records);
+int32_t omok_replay_record_bytes(const omok_engine* e);
+
+#define OMOK_STAT_SIMS 0        /* simulations run (incl. terminal hits / no-action sims) */
+#define OMOK_STAT_EVALS 1       /* net evaluations (search requests + mirror evals + root) */
+#define OMOK_STAT_PLY_GAMES 2   /* sum over plies of live games */
+#define OMOK_STAT_FINISHED 3    /* games finished */
+#define OMOK_STAT_MS_TREE 4     /* HIP-event ms in tree kernels (round+scan+scatter) */
+#define OMOK_STAT_MS_TRUNK 5    /* ... net trunk kernel */
+#define OMOK_STAT_MS_FC0 6      /* ... fc0 GEMM kernel */
+#define OMOK_STAT_MS_TAIL 7     /* ... fc1/heads kernel */
+#define OMOK_STAT_MS_PLY 8      /* ... sample/mirror/advance kernels */
+#define OMOK_STAT_FC0_LAUNCHES 9
+#define OMOK_STAT_FC0_ROWS 10   /* sum of batch rows over fc0 launches */
+#define OMOK_STAT_TREE_BYTES 11 /* kernel-counted algorithmic bytes of the round kernels */
+#define OMOK_STAT_ROUND_LAUNCHES 12
+#define OMOK_STAT_MS_ROUND 13   /* HIP-event ms in the round (select/expand/backup) kernel only */
+#define OMOK_STAT_COUNT 16
+int omok_get_stats(omok_engine* e, double* stats /* [OMOK_STAT_COUNT] */);
+int omok_reset_stats(omok_engine* e);
+/* enable per-kernel HIP-event timing (adds a stream sync per launch; off by default) */
+int omok_set_profiling(omok_engine* e, int32_t enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -3,3 +3,5 @@ of AcrylicShrimp/omok-ai.  The compute lives in csrc/ (HIP kernels behind the C 
 include/omok_mi355x.h); this package is the thin Python host mirror of the reference's crate API.
 """
 from . import weights  # noqa: F401
+from . import binding  # noqa: F401
+from .api import Engine, Environment, SelfPlay  # noqa: F401

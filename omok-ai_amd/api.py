@@ -1,0 +1,268 @@
+"""Host-side mirror of the reference's crate API for the self-play path, over the C ABI.
+
+Names follow the reference so parity tests read like its own code:
+  Environment                      environment/src/lib.rs:62-166
+  encode_nn_input                  alpha-zero/src/encoder.rs:10-46
+  AgentModel.evaluate_p/_pv        alpha-zero/src/agent_model.rs:105-134
+  SelfPlay.execute                 ParallelMCTSExecutor::execute, alpha-zero/src/parallel_mcts_executor.rs:26-35
+  SelfPlay.sample_actions/advance  Agent::{sample_action, play_action, ensure_action_exists}, agent.rs:83-232
+  SelfPlay.run                     Trainer::train self-play phase, src/trainer.rs:95-205
+All compute happens in the HIP library; nothing here has a CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import binding as B
+from . import weights as W
+
+EMPTY, BLACK, WHITE = 0, 1, 2
+TURN_BLACK, TURN_WHITE = 0, 1
+IN_PROGRESS, DRAW, BLACK_WIN, WHITE_WIN = 0, 1, 2, 3
+
+
+class Engine:
+    """Opaque engine handle (omok_create / omok_destroy)."""
+
+    def __init__(self, board_size=15, games=1, max_nodes=2048, max_tables=1024, max_batch_k=16, device=0,
+                 net_mode=B.NET_F16X3, seed=0, game_offset=0):
+        self.n, self.hw, self.games = board_size, board_size * board_size, games
+        self.max_nodes = max_nodes
+        self.max_batch_k = max_batch_k
+        cfg = B.Config(board_size, games, max_nodes, max_tables, max_batch_k, device, net_mode, 0, seed, game_offset)
+        h = C.c_void_p()
+        rc = B.lib().omok_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise B.OmokError(rc, B.lib().omok_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            B.lib().omok_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise B.OmokError(rc, B.lib().omok_last_error(self.h).decode())
+        return rc
+
+    # ---- net --------------------------------------------------------------------------------
+    def load_weights(self, tensors):
+        """31 tensors in the reference's variable order (network.rs / model_io.rs positional order)."""
+        assert len(tensors) == B.lib().omok_net_num_tensors()
+        for i, t in enumerate(tensors):
+            t = np.ascontiguousarray(t, dtype=np.float32).ravel()
+            self._chk(B.lib().omok_net_load(self.h, i, B.fptr(t), t.size))
+        self._chk(B.lib().omok_net_commit(self.h))
+
+    def load_random_weights(self, seed=0):
+        self.load_weights(W.init_random(self.n, seed))
+
+    def evaluate_pv(self, inputs):
+        x = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 3 * self.hw)
+        b = x.shape[0]
+        p = np.zeros((b, self.hw), dtype=np.float32)
+        v = np.zeros(b, dtype=np.float32)
+        self._chk(B.lib().omok_evaluate_pv(self.h, B.fptr(x), b, B.fptr(p), B.fptr(v)))
+        return p.reshape(b, self.n, self.n), v.reshape(b, 1)
+
+    def evaluate_p(self, inputs):
+        return self.evaluate_pv(inputs)[0]
+
+    # ---- environment ------------------------------------------------------------------------
+    def env_play(self, moves):
+        """moves [B][L] int32 -> (status [B][L], boards [B][HW], turns [B], legal [B])."""
+        moves = np.ascontiguousarray(moves, dtype=np.int32)
+        if moves.ndim == 1:
+            moves = moves[None]
+        b, l = moves.shape
+        status = np.zeros((b, max(l, 1)), dtype=np.int32)
+        boards = np.zeros((b, self.hw), dtype=np.uint8)
+        turns = np.zeros(b, dtype=np.uint8)
+        legal = np.zeros(b, dtype=np.uint16)
+        self._chk(B.lib().omok_env_play(self.h, B.iptr(moves), b, l, B.iptr(status), B.u8ptr(boards), B.u8ptr(turns),
+                                        legal.ctypes.data_as(C.POINTER(C.c_uint16))))
+        return status[:, :l], boards, turns, legal
+
+    def encode_nn_input(self, boards, turns, mode=B.MODE_PLAYER):
+        boards = np.ascontiguousarray(boards, dtype=np.uint8).reshape(-1, self.hw)
+        turns = np.ascontiguousarray(turns, dtype=np.uint8).reshape(-1)
+        out = np.zeros((boards.shape[0], 3 * self.hw), dtype=np.float32)
+        self._chk(B.lib().omok_encode_nn_input(self.h, B.u8ptr(boards), B.u8ptr(turns), boards.shape[0], mode, B.fptr(out)))
+        return out.reshape(-1, self.n, self.n, 3)
+
+    # ---- stats ------------------------------------------------------------------------------
+    def set_profiling(self, on=True):
+        self._chk(B.lib().omok_set_profiling(self.h, 1 if on else 0))
+
+    def stats(self):
+        s = (C.c_double * 16)()
+        self._chk(B.lib().omok_get_stats(self.h, s))
+        return dict(zip(B.STAT_NAMES, list(s)))
+
+    def reset_stats(self):
+        self._chk(B.lib().omok_reset_stats(self.h))
+
+
+class Environment:
+    """environment::Environment backed by the device rules kernel (replays its move list)."""
+
+    def __init__(self, engine):
+        self.eng = engine
+        self.moves = []
+        self._sync()
+
+    def _sync(self):
+        m = np.array([self.moves], dtype=np.int32).reshape(1, len(self.moves))
+        st, boards, turns, legal = self.eng.env_play(m)
+        self.board, self.turn, self.legal_move_count = boards[0], int(turns[0]), int(legal[0])
+        return st[0]
+
+    def place_stone(self, index):
+        self.moves.append(int(index))
+        st = self._sync()
+        s = int(st[-1])
+        if s < 0:
+            self.moves.pop()
+            return None
+        return s
+
+    def encode_board(self, turn):
+        """Environment::encode_board(turn): the first 2*HW floats of the NN input with that perspective."""
+        t = np.array([turn], dtype=np.uint8)
+        return self.eng.encode_nn_input(self.board[None], t, B.MODE_PLAYER).reshape(-1)[: 2 * self.eng.hw].copy()
+
+
+class SelfPlay:
+    """G games x (black agent, white agent): the reference's self-play phase on one GPU."""
+
+    def __init__(self, engine):
+        self.eng = engine
+        self.h = engine.h
+        self.n, self.hw, self.games = engine.n, engine.hw, engine.games
+        self._chk = engine._chk
+
+    def reset(self):
+        self._chk(B.lib().omok_selfplay_reset(self.h))
+
+    @property
+    def ply(self):
+        return self._chk(B.lib().omok_current_ply(self.h))
+
+    @property
+    def alive_count(self):
+        return self._chk(B.lib().omok_alive_count(self.h))
+
+    def game_info(self):
+        alive = np.zeros(self.games, dtype=np.uint8)
+        status = np.zeros(self.games, dtype=np.uint8)
+        plies = np.zeros(self.games, dtype=np.int32)
+        self._chk(B.lib().omok_game_info(self.h, B.u8ptr(alive), B.u8ptr(status), B.iptr(plies)))
+        return alive, status, plies
+
+    def execute(self, count, batch_size, epsilon=0.25, alpha=0.03):
+        self._chk(B.lib().omok_execute(self.h, count, batch_size, epsilon, alpha))
+
+    def sample_actions(self, temperature=1.0, threshold=30):
+        a = np.zeros(self.games, dtype=np.int32)
+        self._chk(B.lib().omok_sample_actions(self.h, temperature, threshold, B.iptr(a)))
+        return a
+
+    def advance(self):
+        self._chk(B.lib().omok_advance(self.h))
+
+    def run(self, count, batch_size, epsilon=0.25, alpha=0.03, temperature=1.0, threshold=30, max_plies=0):
+        s = (C.c_double * 16)()
+        self._chk(B.lib().omok_selfplay_run(self.h, count, batch_size, epsilon, alpha, temperature, threshold, max_plies, s))
+        return dict(zip(B.STAT_NAMES, list(s)))
+
+    # ---- step-wise (parity tests) -----------------------------------------------------------
+    def round_generate(self, rnd, batch_size, epsilon=0.25, alpha=0.03):
+        n = C.c_int32()
+        self._chk(B.lib().omok_round_generate(self.h, rnd, batch_size, epsilon, alpha, C.byref(n)))
+        self._nreq = n.value
+        return n.value
+
+    def round_inputs(self):
+        out = np.zeros((self._nreq, 3 * self.hw), dtype=np.float32)
+        if self._nreq:
+            self._chk(B.lib().omok_round_inputs(self.h, B.fptr(out)))
+        return out
+
+    def round_eval(self):
+        self._chk(B.lib().omok_round_eval(self.h))
+        p = np.zeros((self._nreq, self.hw), dtype=np.float32)
+        v = np.zeros(self._nreq, dtype=np.float32)
+        if self._nreq:
+            self._chk(B.lib().omok_round_outputs(self.h, B.fptr(p), B.fptr(v)))
+        return p, v
+
+    def round_inject(self, p, v):
+        p = np.ascontiguousarray(p, dtype=np.float32)
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        if self._nreq:
+            self._chk(B.lib().omok_round_inject(self.h, B.fptr(p), B.fptr(v)))
+
+    def round_scatter(self):
+        self._chk(B.lib().omok_round_scatter(self.h))
+
+    def mirror_generate(self):
+        n = C.c_int32()
+        self._chk(B.lib().omok_mirror_generate(self.h, C.byref(n)))
+        self._nmir = n.value
+        return n.value
+
+    def mirror_inputs(self):
+        out = np.zeros((self._nmir, 3 * self.hw), dtype=np.float32)
+        if self._nmir:
+            self._chk(B.lib().omok_mirror_inputs(self.h, B.fptr(out)))
+        return out
+
+    def mirror_eval(self):
+        self._chk(B.lib().omok_mirror_eval(self.h))
+        p = np.zeros((self._nmir, self.hw), dtype=np.float32)
+        if self._nmir:
+            self._chk(B.lib().omok_mirror_outputs(self.h, B.fptr(p)))
+        return p
+
+    def mirror_inject(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float32)
+        if self._nmir:
+            self._chk(B.lib().omok_mirror_inject(self.h, B.fptr(p)))
+
+    def mirror_apply(self):
+        self._chk(B.lib().omok_mirror_apply(self.h))
+
+    # ---- inspection -------------------------------------------------------------------------
+    def tree_dump(self, game, side):
+        cap = self.eng.max_nodes
+        ints = np.zeros((cap, 8), dtype=np.int32)
+        floats = np.zeros((cap, 1 + self.hw), dtype=np.float32)
+        n = self._chk(B.lib().omok_tree_dump(self.h, game, side, B.iptr(ints), B.fptr(floats), cap))
+        return ints[:n].copy(), floats[:n].copy()
+
+    def tree_root(self, game, side):
+        rn, rw, nn, nt = C.c_uint32(), C.c_float(), C.c_int32(), C.c_int32()
+        self._chk(B.lib().omok_tree_root(self.h, game, side, C.byref(rn), C.byref(rw), C.byref(nn), C.byref(nt)))
+        return rn.value, rw.value, nn.value, nt.value
+
+    def replay(self, game):
+        cap = self.hw
+        boards = np.zeros((cap, self.hw), dtype=np.uint8)
+        turns = np.zeros(cap, dtype=np.uint8)
+        pi = np.zeros((cap, self.hw), dtype=np.float32)
+        z = np.zeros(cap, dtype=np.float32)
+        n = self._chk(B.lib().omok_replay_game(self.h, game, B.u8ptr(boards), B.u8ptr(turns), B.fptr(pi), B.fptr(z), cap))
+        return boards[:n], turns[:n], pi[:n], z[:n]
+
+    def replay_record_bytes(self):
+        return self._chk(B.lib().omok_replay_record_bytes(self.h))
+
+    def replay_pack_into(self, dev_ptr, cap_records):
+        n = B.lib().omok_replay_pack_dev(self.h, C.c_void_p(dev_ptr), cap_records)
+        if n < 0:
+            raise B.OmokError(int(n), B.lib().omok_last_error(self.h).decode())
+        return int(n)

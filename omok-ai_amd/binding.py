@@ -1,0 +1,115 @@
+"""ctypes binding of libomok_mi355x.so (include/omok_mi355x.h).  No fallbacks: if the HIP library
+is missing or no GPU is present every entry point raises."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libomok_mi355x.so")
+
+OK = 0
+NET_F16X3, NET_F32 = 0, 1
+MODE_PLAYER, MODE_OPPONENT = 0, 1
+STAT_NAMES = ["sims", "evals", "ply_games", "finished", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply",
+              "fc0_launches", "fc0_rows", "tree_bytes", "round_launches", "ms_round", "_14", "_15"]
+
+# every symbol include/omok_mi355x.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "omok_create", "omok_destroy", "omok_last_error", "omok_net_num_tensors", "omok_net_tensor_size", "omok_net_load",
+    "omok_net_commit", "omok_evaluate_pv", "omok_env_play", "omok_encode_nn_input", "omok_selfplay_reset", "omok_execute",
+    "omok_sample_actions", "omok_advance", "omok_selfplay_run", "omok_round_generate", "omok_round_inputs",
+    "omok_round_eval", "omok_round_outputs", "omok_round_inject", "omok_round_scatter", "omok_mirror_generate",
+    "omok_mirror_inputs", "omok_mirror_eval", "omok_mirror_outputs", "omok_mirror_inject", "omok_mirror_apply",
+    "omok_alive_count", "omok_current_ply", "omok_game_info", "omok_tree_dump", "omok_tree_root", "omok_replay_game",
+    "omok_replay_pack_dev", "omok_replay_record_bytes", "omok_get_stats", "omok_reset_stats", "omok_set_profiling",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("board_size", C.c_int32), ("games", C.c_int32), ("max_nodes", C.c_int32), ("max_tables", C.c_int32),
+                ("max_batch_k", C.c_int32), ("device", C.c_int32), ("net_mode", C.c_int32), ("reserved", C.c_int32),
+                ("seed", C.c_uint64), ("game_offset", C.c_int64)]
+
+
+class OmokError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"omok error {code}: {msg}")
+        self.code = code
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OmokError(-2, f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                            "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    u8p = C.POINTER(C.c_uint8)
+    H = C.c_void_p
+    L.omok_create.argtypes = [C.POINTER(Config), C.POINTER(H)]
+    L.omok_destroy.argtypes = [H]
+    L.omok_destroy.restype = None
+    L.omok_last_error.argtypes = [H]
+    L.omok_last_error.restype = C.c_char_p
+    L.omok_net_tensor_size.argtypes = [H, C.c_int]
+    L.omok_net_tensor_size.restype = C.c_int64
+    L.omok_net_load.argtypes = [H, C.c_int, fp, C.c_int64]
+    L.omok_net_commit.argtypes = [H]
+    L.omok_evaluate_pv.argtypes = [H, fp, C.c_int32, fp, fp]
+    L.omok_env_play.argtypes = [H, ip, C.c_int32, C.c_int32, ip, u8p, u8p, C.POINTER(C.c_uint16)]
+    L.omok_encode_nn_input.argtypes = [H, u8p, u8p, C.c_int32, C.c_int32, fp]
+    L.omok_selfplay_reset.argtypes = [H]
+    L.omok_execute.argtypes = [H, C.c_int32, C.c_int32, C.c_float, C.c_float]
+    L.omok_sample_actions.argtypes = [H, C.c_float, C.c_int32, ip]
+    L.omok_advance.argtypes = [H]
+    L.omok_selfplay_run.argtypes = [H, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,
+                                    C.POINTER(C.c_double)]
+    L.omok_round_generate.argtypes = [H, C.c_int32, C.c_int32, C.c_float, C.c_float, ip]
+    L.omok_round_inputs.argtypes = [H, fp]
+    L.omok_round_eval.argtypes = [H]
+    L.omok_round_outputs.argtypes = [H, fp, fp]
+    L.omok_round_inject.argtypes = [H, fp, fp]
+    L.omok_round_scatter.argtypes = [H]
+    L.omok_mirror_generate.argtypes = [H, ip]
+    L.omok_mirror_inputs.argtypes = [H, fp]
+    L.omok_mirror_eval.argtypes = [H]
+    L.omok_mirror_outputs.argtypes = [H, fp]
+    L.omok_mirror_inject.argtypes = [H, fp]
+    L.omok_mirror_apply.argtypes = [H]
+    L.omok_alive_count.argtypes = [H]
+    L.omok_current_ply.argtypes = [H]
+    L.omok_game_info.argtypes = [H, u8p, u8p, ip]
+    L.omok_tree_dump.argtypes = [H, C.c_int32, C.c_int32, ip, fp, C.c_int32]
+    L.omok_tree_root.argtypes = [H, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), fp, ip, ip]
+    L.omok_replay_game.argtypes = [H, C.c_int32, u8p, u8p, fp, fp, C.c_int32]
+    L.omok_replay_pack_dev.argtypes = [H, C.c_void_p, C.c_int64]
+    L.omok_replay_pack_dev.restype = C.c_int64
+    L.omok_replay_record_bytes.argtypes = [H]
+    L.omok_get_stats.argtypes = [H, C.POINTER(C.c_double)]
+    L.omok_reset_stats.argtypes = [H]
+    L.omok_set_profiling.argtypes = [H, C.c_int32]
+    _lib = L
+    return L
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def u8ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))

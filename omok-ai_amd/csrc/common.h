@@ -1,0 +1,119 @@
+// common.h — data layout in HBM and launch interface shared by the HIP translation units.
+//
+// One tree = one arena, owned by exactly one wavefront at a time.  Layout:
+//   tree id t = side * G + game            (side 0 = black agent, 1 = white agent, trainer.rs:83-84)
+//   hdr    [T][cap_nodes]           16 B   NodeHdr  (Node fields of mcts/src/node.rs:10-21)
+//   board  [T][cap_nodes][2*NW]     u64    black words, white words (bit a = cell a)
+//   policy [T][cap_nodes][ROWP]     f32    BoardState.policy (alpha-zero/src/mcts_node.rs:10)
+//   child tables [T][cap_tables][ROWP]: cn u32, cw f32, cidx u16, corder u8; owner [T][cap_tables]
+//     a node's (n, w) live in its PARENT's table at index = action (coalesced PUCT scan);
+//     child.p is parent.policy[action] (the reference keeps them equal at all times).
+//   ROWP = HW rounded up to 64 (one wave iteration per 64 cells); pad cells: corder = 0xFF.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace omok {
+
+constexpr uint16_t NONE16 = 0xFFFFu;
+constexpr uint8_t NONE8 = 0xFFu;
+constexpr int KMAX = 64;
+constexpr float F32_EPS = 1.1920928955078125e-7f;
+
+enum { ST_IN_PROGRESS = 0, ST_DRAW = 1, ST_BLACK_WIN = 2, ST_WHITE_WIN = 3 };
+enum { RNG_EXPAND = 1, RNG_NOISE = 2, RNG_SAMPLE = 3 };
+
+template <int N>
+struct Geo {
+    static constexpr int HW = N * N;
+    static constexpr int ROWP = (HW + 63) / 64 * 64;
+    static constexpr int NW = (HW + 63) / 64;
+    static constexpr int IT = ROWP / 64;
+};
+
+struct __attribute__((aligned(16))) NodeHdr {
+    uint16_t parent;
+    uint16_t table;
+    uint16_t legal;
+    uint16_t nch;
+    uint8_t action;
+    uint8_t status;
+    uint8_t turn;
+    uint8_t has_policy;
+    uint32_t pad;
+};
+static_assert(sizeof(NodeHdr) == 16, "NodeHdr must be 16 bytes");
+
+struct __attribute__((aligned(16))) TreeState {
+    uint32_t n_nodes;
+    uint32_t n_tables;
+    uint32_t root_n;
+    float root_w;
+    uint32_t error;
+    uint32_t n_req;
+    uint32_t req_base;
+    uint32_t pad;
+};
+
+struct GameState {
+    uint8_t alive;
+    uint8_t status;
+    uint8_t pad0, pad1;
+    int32_t plies;
+    int32_t last_action;
+    int32_t mirror_idx;
+};
+
+struct Store {
+    NodeHdr* hdr;
+    uint64_t* board;
+    float* policy;
+    uint32_t* tcn;
+    float* tcw;
+    uint16_t* tcidx;
+    uint8_t* tcorder;
+    uint16_t* towner;
+    TreeState* ts;
+    uint16_t* req_node; // [T][KMAX]
+    GameState* gs;      // [G]
+    // dense request list of the current NN batch
+    uint32_t* req_ref;  // (t << 16) | node
+    uint32_t* req_aux;  // 0xFFFFFFFF none, else action | mode << 16 : stone to add before encoding
+    int32_t* d_count;   // [0] = live batch size
+    // replay
+    uint64_t* rp_board; // [G][HW][2*NW]
+    uint8_t* rp_turn;   // [G][HW]
+    float* rp_pi;       // [G][HW][ROWP]
+    float* rp_z;        // [G][HW]
+    unsigned long long* d_bytes; // kernel-counted algorithmic bytes
+    int cap_nodes, cap_tables, games;
+};
+
+struct RoundArgs {
+    int side, round, K, ply;
+    float epsilon, alpha;
+    uint64_t seed;
+    int64_t game_offset;
+};
+
+// ---- tree_kernels.hip launchers (all asynchronous on `st`) ---------------------------------
+void launch_reset(int n, const Store& S, const float* root_policy_dev /*ROWP*/, hipStream_t st);
+void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st);
+void launch_scan(int n, const Store& S, int side, hipStream_t st);
+void launch_scatter(int n, const Store& S, int side, const float* p_dev, const float* v_dev, hipStream_t st);
+void launch_sample(int n, const Store& S, int side, int ply, float temperature, int threshold, uint64_t seed,
+                   int64_t game_offset, int32_t* actions_dev, hipStream_t st);
+void launch_mirror_scan(int n, const Store& S, int side, hipStream_t st);
+void launch_advance(int n, const Store& S, int side, const float* p_dev, hipStream_t st);
+void launch_encode_requests(int n, const Store& S, float* out_dev /*[B][3HW]*/, int max_b, hipStream_t st);
+void launch_env_play(int n, const int32_t* moves_dev, int batch, int len, int32_t* status_dev, uint8_t* boards_dev,
+                     uint8_t* turns_dev, uint16_t* legal_dev, hipStream_t st);
+void launch_encode_boards(int n, const uint8_t* boards_dev, const uint8_t* turns_dev, int batch, int mode,
+                          float* out_dev, hipStream_t st);
+void launch_replay_pack(int n, const Store& S, uint8_t* dst_dev, long long cap_records, long long* d_total,
+                        hipStream_t st);
+size_t advance_lds_bytes(int cap_nodes, int cap_tables);
+
+// ---- net_kernels.hip --------------------------------------------------------------------------
+struct NetBuffers; // defined in net.h
+} // namespace omok

@@ -1,0 +1,839 @@
+// engine.cpp — host side of libomok_mi355x.so: the opaque handle, HBM allocation, kernel
+// orchestration and the C ABI of include/omok_mi355x.h.
+//
+// Mirrors the reference's host control flow:
+//   omok_execute       <- ParallelMCTSExecutor::execute (alpha-zero/src/parallel_mcts_executor.rs:26-270)
+//   omok_selfplay_run  <- Trainer::train self-play phase (src/trainer.rs:95-205)
+// but enqueues a whole execute() (all rounds) on one HIP stream without host round trips: the
+// live batch size stays on the device (Store::d_count) and the net kernels bound themselves by it.
+#include "../../include/omok_mi355x.h"
+#include "common.h"
+#include "net.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace omok;
+
+// ---------------------------------------------------------------------------------------------
+hipEvent_t Prof::get() {
+    if (n_pool > 0) return pool[--n_pool];
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+void Prof::begin(int cat, hipStream_t st) {
+    if (!enabled) return;
+    if (n_items == cap_items) {
+        if (cap_items >= 8192) resolve();
+        else {
+            cap_items = cap_items ? cap_items * 2 : 1024;
+            items = (Item*)realloc(items, sizeof(Item) * cap_items);
+        }
+    }
+    Item it{cat, get(), get()};
+    hipEventRecord(it.a, st);
+    items[n_items++] = it;
+}
+void Prof::end(hipStream_t st) {
+    if (!enabled || n_items == 0) return;
+    hipEventRecord(items[n_items - 1].b, st);
+}
+void Prof::resolve() {
+    if (n_items == 0) return;
+    hipEventSynchronize(items[n_items - 1].b);
+    if (cap_pool < n_pool + 2 * n_items) {
+        cap_pool = n_pool + 2 * n_items + 64;
+        pool = (hipEvent_t*)realloc(pool, sizeof(hipEvent_t) * cap_pool);
+    }
+    for (int i = 0; i < n_items; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, items[i].a, items[i].b) == hipSuccess) {
+            ms[items[i].cat] += t;
+            launches[items[i].cat] += 1;
+        }
+        pool[n_pool++] = items[i].a;
+        pool[n_pool++] = items[i].b;
+    }
+    n_items = 0;
+}
+void Prof::destroy() {
+    resolve();
+    for (int i = 0; i < n_pool; ++i) hipEventDestroy(pool[i]);
+    free(pool);
+    free(items);
+    pool = nullptr; items = nullptr; n_pool = cap_pool = n_items = cap_items = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct omok_engine {
+    omok_config cfg{};
+    int n = 0, hw = 0, rowp = 0, nw = 0, T = 0;
+    Store S{};
+    Net net{};
+    Prof prof{};
+    hipStream_t st = nullptr;
+    std::vector<void*> allocs;
+    std::string err;
+    int ply = 0;
+    bool reset_done = false;
+    bool sampled = false;
+    int round_reqs = -1;   // step-wise API state
+    int mirror_reqs = -1;
+    float* d_root_policy = nullptr;
+    int32_t* d_actions = nullptr;
+    uint32_t* d_error = nullptr; // [0] error bits, [1] alive count
+    unsigned long long* d_evals = nullptr;
+    long long* d_pack_total = nullptr;
+    // host-side stats
+    double sims = 0, evals = 0, ply_games = 0, finished = 0;
+    size_t bytes = 0;
+};
+
+static std::string g_create_error;
+
+static int fail(omok_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                        \
+    do {                                                                                       \
+        hipError_t _r = (call);                                                                \
+        if (_r != hipSuccess) return fail(e, OMOK_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_r)); \
+    } while (0)
+
+template <typename Tp>
+static int dalloc(omok_engine* e, Tp** p, size_t count) {
+    void* q = nullptr;
+    const size_t bytes = count * sizeof(Tp);
+    hipError_t r = hipMalloc(&q, bytes ? bytes : 16);
+    if (r != hipSuccess) return fail(e, OMOK_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(r));
+    e->allocs.push_back(q);
+    e->bytes += bytes;
+    *p = (Tp*)q;
+    return 0;
+}
+
+// tiny helper kernels --------------------------------------------------------------------------
+__global__ void k_count_alive(Store S, uint32_t* d_error, unsigned long long* d_evals) {
+    __shared__ uint32_t s_cnt, s_err;
+    if (threadIdx.x == 0) { s_cnt = 0; s_err = 0; }
+    __syncthreads();
+    uint32_t c = 0, er = 0;
+    for (int g = threadIdx.x; g < S.games; g += blockDim.x) {
+        c += S.gs[g].alive ? 1u : 0u;
+        er |= S.ts[g].error | S.ts[S.games + g].error;
+    }
+    atomicAdd(&s_cnt, c);
+    atomicOr(&s_err, er);
+    __syncthreads();
+    if (threadIdx.x == 0) { d_error[0] = s_err; d_error[1] = s_cnt; }
+}
+__global__ void k_add_evals(const int32_t* d_count, unsigned long long* d_evals) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) d_evals[0] += (unsigned long long)d_count[0];
+}
+__global__ void k_copy_root_policy(const float* p, float* dst, int hw, int rowp) {
+    const int a = threadIdx.x;
+    if (a < rowp) dst[a] = a < hw ? p[a] : 0.0f;
+}
+__global__ void k_pack_rows(const float* src, float* dst, int hw, int rowp, int rows) { // [rows][ROWP] -> [rows][HW]
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)rows * hw) dst[i] = src[(i / hw) * rowp + (i % hw)];
+}
+__global__ void k_unpack_rows(const float* src, float* dst, int hw, int rowp, int rows) { // [rows][HW] -> [rows][ROWP]
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)rows * rowp) dst[i] = (int)(i % rowp) < hw ? src[(i / rowp) * hw + (i % rowp)] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" const char* omok_last_error(const omok_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+extern "C" void omok_destroy(omok_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->cfg.device);
+    if (e->st) hipStreamSynchronize(e->st);
+    e->prof.destroy();
+    net_free(e->net);
+    for (void* p : e->allocs) hipFree(p);
+    if (e->st) hipStreamDestroy(e->st);
+    delete e;
+}
+
+extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
+    if (!cfg || !out) return fail(nullptr, OMOK_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->board_size != 9 && cfg->board_size != 15)
+        return fail(nullptr, OMOK_ERR_INVALID, "board_size must be 9 or 15 (got %d)", cfg->board_size);
+    if (cfg->games < 1 || cfg->games > 32767) return fail(nullptr, OMOK_ERR_INVALID, "games must be in [1, 32767]");
+    if (cfg->max_nodes < 2 || cfg->max_nodes > 16384 || cfg->max_tables < 1 || cfg->max_tables > 16384)
+        return fail(nullptr, OMOK_ERR_INVALID, "max_nodes / max_tables must be in [2, 16384]");
+    if (cfg->max_batch_k < 1 || cfg->max_batch_k > KMAX) return fail(nullptr, OMOK_ERR_INVALID, "max_batch_k must be in [1, 64]");
+    if (cfg->net_mode != OMOK_NET_F16X3 && cfg->net_mode != OMOK_NET_F32) return fail(nullptr, OMOK_ERR_INVALID, "bad net_mode");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, OMOK_ERR_HIP, "no HIP device available: this library has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, OMOK_ERR_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
+    omok_engine* e = new omok_engine();
+    e->cfg = *cfg;
+    e->n = cfg->board_size;
+    e->hw = e->n * e->n;
+    e->rowp = (e->hw + 63) / 64 * 64;
+    e->nw = (e->hw + 63) / 64;
+    e->T = 2 * cfg->games;
+    hipError_t r = hipSetDevice(cfg->device);
+    if (r == hipSuccess) r = hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking);
+    if (r != hipSuccess) {
+        g_create_error = std::string("HIP init failed: ") + hipGetErrorString(r);
+        delete e;
+        return OMOK_ERR_HIP;
+    }
+    Store& S = e->S;
+    S.cap_nodes = cfg->max_nodes;
+    S.cap_tables = cfg->max_tables;
+    S.games = cfg->games;
+    const size_t T = (size_t)e->T, cn = (size_t)cfg->max_nodes, ct = (size_t)cfg->max_tables, rp = (size_t)e->rowp;
+    const size_t G = (size_t)cfg->games, HW = (size_t)e->hw;
+    const size_t max_b = G * (size_t)cfg->max_batch_k;
+    int rc = 0;
+    rc |= dalloc(e, &S.hdr, T * cn);
+    rc |= dalloc(e, &S.board, T * cn * 2 * e->nw);
+    rc |= dalloc(e, &S.policy, T * cn * rp);
+    rc |= dalloc(e, &S.tcn, T * ct * rp);
+    rc |= dalloc(e, &S.tcw, T * ct * rp);
+    rc |= dalloc(e, &S.tcidx, T * ct * rp);
+    rc |= dalloc(e, &S.tcorder, T * ct * rp);
+    rc |= dalloc(e, &S.towner, T * ct);
+    rc |= dalloc(e, &S.ts, T);
+    rc |= dalloc(e, &S.req_node, T * KMAX);
+    rc |= dalloc(e, &S.gs, G);
+    rc |= dalloc(e, &S.req_ref, max_b);
+    rc |= dalloc(e, &S.req_aux, max_b);
+    rc |= dalloc(e, &S.d_count, 4);
+    rc |= dalloc(e, &S.rp_board, G * HW * 2 * e->nw);
+    rc |= dalloc(e, &S.rp_turn, G * HW);
+    rc |= dalloc(e, &S.rp_pi, G * HW * rp);
+    rc |= dalloc(e, &S.rp_z, G * HW);
+    rc |= dalloc(e, &S.d_bytes, 2);
+    rc |= dalloc(e, &e->d_root_policy, rp);
+    rc |= dalloc(e, &e->d_actions, G);
+    rc |= dalloc(e, &e->d_error, 4);
+    rc |= dalloc(e, &e->d_evals, 2);
+    rc |= dalloc(e, &e->d_pack_total, 2);
+    if (rc) {
+        g_create_error = e->err;
+        omok_destroy(e);
+        return OMOK_ERR_HIP;
+    }
+    hipMemsetAsync(S.d_count, 0, 16, e->st);
+    hipMemsetAsync(S.d_bytes, 0, 16, e->st);
+    hipMemsetAsync(e->d_error, 0, 16, e->st);
+    hipMemsetAsync(e->d_evals, 0, 16, e->st);
+    hipMemsetAsync(S.gs, 0, sizeof(GameState) * G, e->st);
+    hipMemsetAsync(S.ts, 0, sizeof(TreeState) * T, e->st);
+    e->net.n = e->n;
+    e->net.hw = e->hw;
+    e->net.rowp = e->rowp;
+    e->net.mode = cfg->net_mode;
+    e->net.max_b = (int)max_b;
+    for (int i = 0; i < NET_TENSORS; ++i) e->net.wsize[i] = net_tensor_size(e->n, i);
+    if (net_alloc(e->net) == 0) {
+        g_create_error = "net buffer allocation failed (hipMalloc)";
+        omok_destroy(e);
+        return OMOK_ERR_HIP;
+    }
+    if (hipStreamSynchronize(e->st) != hipSuccess) {
+        g_create_error = "stream sync failed after init";
+        omok_destroy(e);
+        return OMOK_ERR_HIP;
+    }
+    *out = e;
+    return OMOK_OK;
+}
+
+// ---- net ---------------------------------------------------------------------------------------
+extern "C" int omok_net_num_tensors(void) { return NET_TENSORS; }
+extern "C" int64_t omok_net_tensor_size(const omok_engine* e, int index) { return e ? net_tensor_size(e->n, index) : -1; }
+
+extern "C" int omok_net_load(omok_engine* e, int index, const float* data, int64_t count) {
+    if (!e || !data) return OMOK_ERR_INVALID;
+    if (index < 0 || index >= NET_TENSORS) return fail(e, OMOK_ERR_INVALID, "tensor index %d out of range", index);
+    if (count != e->net.wsize[index]) return fail(e, OMOK_ERR_INVALID, "tensor %d: expected %lld values, got %lld", index, (long long)e->net.wsize[index], (long long)count);
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, hipMemcpyAsync(e->net.w[index], data, sizeof(float) * (size_t)count, hipMemcpyHostToDevice, e->st));
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    e->net.loaded[index] = true;
+    e->net.committed = false;
+    return OMOK_OK;
+}
+
+extern "C" int omok_net_commit(omok_engine* e) {
+    if (!e) return OMOK_ERR_INVALID;
+    for (int i = 0; i < NET_TENSORS; ++i)
+        if (!e->net.loaded[i]) return fail(e, OMOK_ERR_STATE, "tensor %d was never loaded", i);
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (net_commit(e->net, e->st) != 0) return fail(e, OMOK_ERR_HIP, "weight packing failed");
+    HIPCHK(e, hipStreamSynchronize(e->st));
+    e->net.committed = true;
+    return OMOK_OK;
+}
+
+static int need_net(omok_engine* e) {
+    if (!e->net.committed) return fail(e, OMOK_ERR_STATE, "net not loaded/committed (omok_net_load x31 + omok_net_commit)");
+    return 0;
+}
+
+static int check_async(omok_engine* e, const char* what) {
+    hipError_t r = hipGetLastError();
+    if (r != hipSuccess) return fail(e, OMOK_ERR_HIP, "%s: launch failed: %s", what, hipGetErrorString(r));
+    return 0;
+}
+
+static int sync_and_check(omok_engine* e, const char* what) {
+    hipError_t r = hipStreamSynchronize(e->st);
+    if (r != hipSuccess) return fail(e, OMOK_ERR_HIP, "%s: %s", what, hipGetErrorString(r));
+    return check_async(e, what);
+}
+
+extern "C" int omok_evaluate_pv(omok_engine* e, const float* in, int32_t batch, float* p, float* v) {
+    if (!e || !in || !p || batch < 0) return OMOK_ERR_INVALID;
+    if (need_net(e)) return OMOK_ERR_STATE;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    const size_t in_row = 3 * (size_t)e->hw;
+    float* d_pack = e->net.in_f32; // reused as the packed output staging after the forward
+    for (int32_t done = 0; done < batch; done += e->net.max_b) {
+        const int b = std::min<int32_t>(e->net.max_b, batch - done);
+        HIPCHK(e, hipMemcpyAsync(e->net.in_f32, in + (size_t)done * in_row, sizeof(float) * in_row * b, hipMemcpyHostToDevice, e->st));
+        HIPCHK(e, hipMemcpyAsync(e->S.d_count, &b, sizeof(int32_t), hipMemcpyHostToDevice, e->st));
+        net_forward_inputs(e->net, e->S, b, e->st, &e->prof);
+        const size_t tot = (size_t)b * e->hw;
+        k_pack_rows<<<(unsigned)((tot + 255) / 256), 256, 0, e->st>>>(e->net.p, d_pack, e->hw, e->rowp, b);
+        HIPCHK(e, hipMemcpyAsync(p + (size_t)done * e->hw, d_pack, sizeof(float) * tot, hipMemcpyDeviceToHost, e->st));
+        if (v) HIPCHK(e, hipMemcpyAsync(v + done, e->net.v, sizeof(float) * b, hipMemcpyDeviceToHost, e->st));
+        if (sync_and_check(e, "evaluate_pv")) return OMOK_ERR_HIP;
+        e->evals += b;
+    }
+    return OMOK_OK;
+}
+
+// ---- environment -------------------------------------------------------------------------------
+extern "C" int omok_env_play(omok_engine* e, const int32_t* moves, int32_t batch, int32_t len, int32_t* status_out,
+                             uint8_t* boards_out, uint8_t* turns_out, uint16_t* legal_out) {
+    if (!e || batch < 1 || len < 0 || (len > 0 && !moves)) return OMOK_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    int32_t *d_moves = nullptr, *d_status = nullptr;
+    uint8_t *d_boards = nullptr, *d_turns = nullptr;
+    uint16_t* d_legal = nullptr;
+    const size_t ml = (size_t)batch * (size_t)(len > 0 ? len : 1);
+    HIPCHK(e, hipMalloc((void**)&d_moves, ml * 4));
+    HIPCHK(e, hipMalloc((void**)&d_status, ml * 4));
+    HIPCHK(e, hipMalloc((void**)&d_boards, (size_t)batch * e->hw));
+    HIPCHK(e, hipMalloc((void**)&d_turns, (size_t)batch));
+    HIPCHK(e, hipMalloc((void**)&d_legal, (size_t)batch * 2));
+    if (len > 0) hipMemcpyAsync(d_moves, moves, ml * 4, hipMemcpyHostToDevice, e->st);
+    launch_env_play(e->n, d_moves, batch, len, d_status, d_boards, d_turns, d_legal, e->st);
+    if (status_out && len > 0) hipMemcpyAsync(status_out, d_status, ml * 4, hipMemcpyDeviceToHost, e->st);
+    if (boards_out) hipMemcpyAsync(boards_out, d_boards, (size_t)batch * e->hw, hipMemcpyDeviceToHost, e->st);
+    if (turns_out) hipMemcpyAsync(turns_out, d_turns, (size_t)batch, hipMemcpyDeviceToHost, e->st);
+    if (legal_out) hipMemcpyAsync(legal_out, d_legal, (size_t)batch * 2, hipMemcpyDeviceToHost, e->st);
+    const int rc = sync_and_check(e, "env_play");
+    hipFree(d_moves); hipFree(d_status); hipFree(d_boards); hipFree(d_turns); hipFree(d_legal);
+    return rc ? OMOK_ERR_HIP : OMOK_OK;
+}
+
+extern "C" int omok_encode_nn_input(omok_engine* e, const uint8_t* boards, const uint8_t* turns, int32_t batch,
+                                    int32_t mode, float* out) {
+    if (!e || !boards || !turns || !out || batch < 1 || (mode != 0 && mode != 1)) return OMOK_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    uint8_t *d_boards = nullptr, *d_turns = nullptr;
+    float* d_out = nullptr;
+    HIPCHK(e, hipMalloc((void**)&d_boards, (size_t)batch * e->hw));
+    HIPCHK(e, hipMalloc((void**)&d_turns, (size_t)batch));
+    HIPCHK(e, hipMalloc((void**)&d_out, (size_t)batch * 3 * e->hw * 4));
+    hipMemcpyAsync(d_boards, boards, (size_t)batch * e->hw, hipMemcpyHostToDevice, e->st);
+    hipMemcpyAsync(d_turns, turns, (size_t)batch, hipMemcpyHostToDevice, e->st);
+    launch_encode_boards(e->n, d_boards, d_turns, batch, mode, d_out, e->st);
+    hipMemcpyAsync(out, d_out, (size_t)batch * 3 * e->hw * 4, hipMemcpyDeviceToHost, e->st);
+    const int rc = sync_and_check(e, "encode_nn_input");
+    hipFree(d_boards); hipFree(d_turns); hipFree(d_out);
+    return rc ? OMOK_ERR_HIP : OMOK_OK;
+}
+
+// ---- self-play ---------------------------------------------------------------------------------
+static int read_status(omok_engine* e, uint32_t* err_bits, uint32_t* alive) {
+    k_count_alive<<<1, 1024, 0, e->st>>>(e->S, e->d_error, e->d_evals);
+    uint32_t h[2] = {0, 0};
+    HIPCHK(e, hipMemcpyAsync(h, e->d_error, 8, hipMemcpyDeviceToHost, e->st));
+    if (sync_and_check(e, "status readback")) return OMOK_ERR_HIP;
+    if (err_bits) *err_bits = h[0];
+    if (alive) *alive = h[1];
+    return 0;
+}
+
+static int tree_error(omok_engine* e, uint32_t bits) {
+    if (bits & 1u) return fail(e, OMOK_ERR_OVERFLOW, "a tree arena overflowed (max_nodes=%d, max_tables=%d): raise them", e->cfg.max_nodes, e->cfg.max_tables);
+    if (bits & 4u) return fail(e, OMOK_ERR_ILLEGAL, "sample_action on a tree with no visited children (run execute first)");
+    if (bits) return fail(e, OMOK_ERR_ILLEGAL, "illegal tree operation (error bits 0x%x)", bits);
+    return 0;
+}
+
+extern "C" int omok_selfplay_reset(omok_engine* e) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (need_net(e)) return OMOK_ERR_STATE;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    // Agent::new: evaluate_p on the empty board in Player mode (agent.rs:19-20); the result is the
+    // same for every tree of a fixed net, so it is computed once.
+    std::vector<float> in(3 * (size_t)e->hw, 0.0f);
+    for (int i = 2 * e->hw; i < 3 * e->hw; ++i) in[i] = 1.0f; // Black to move (encoder.rs:34-37)
+    const int one = 1;
+    HIPCHK(e, hipMemcpyAsync(e->net.in_f32, in.data(), sizeof(float) * in.size(), hipMemcpyHostToDevice, e->st));
+    HIPCHK(e, hipMemcpyAsync(e->S.d_count, &one, sizeof(int32_t), hipMemcpyHostToDevice, e->st));
+    net_forward_inputs(e->net, e->S, 1, e->st, &e->prof);
+    k_copy_root_policy<<<1, 256, 0, e->st>>>(e->net.p, e->d_root_policy, e->hw, e->rowp);
+    launch_reset(e->n, e->S, e->d_root_policy, e->st);
+    if (sync_and_check(e, "selfplay_reset")) return OMOK_ERR_HIP;
+    e->evals += 1;
+    e->ply = 0;
+    e->reset_done = true;
+    e->sampled = false;
+    e->round_reqs = e->mirror_reqs = -1;
+    return OMOK_OK;
+}
+
+static int need_reset(omok_engine* e) {
+    if (!e->reset_done) return fail(e, OMOK_ERR_STATE, "omok_selfplay_reset has not been called");
+    return 0;
+}
+
+static void enqueue_round(omok_engine* e, int round, int K, float eps, float alpha, bool eval_and_scatter) {
+    const int side = e->ply & 1;
+    RoundArgs a{side, round, K, e->ply, eps, alpha, e->cfg.seed, e->cfg.game_offset};
+    e->prof.begin(PC_ROUND, e->st);
+    launch_round(e->n, e->S, a, e->st);
+    e->prof.end(e->st);
+    e->prof.begin(PC_TREE_OTHER, e->st);
+    launch_scan(e->n, e->S, side, e->st);
+    k_add_evals<<<1, 64, 0, e->st>>>(e->S.d_count, e->d_evals);
+    e->prof.end(e->st);
+    if (eval_and_scatter) {
+        net_forward_requests(e->net, e->S, e->cfg.games * K, e->st, &e->prof);
+        e->prof.begin(PC_TREE_OTHER, e->st);
+        launch_scatter(e->n, e->S, side, e->net.p, e->net.v, e->st);
+        e->prof.end(e->st);
+    }
+}
+
+static int enqueue_execute(omok_engine* e, int count, int K, float eps, float alpha) {
+    int processed = 0, round = 0;
+    while (processed < count) { // pme.rs:39-42,207
+        enqueue_round(e, round, K, eps, alpha, true);
+        processed += K;
+        round += 1;
+    }
+    return round;
+}
+
+static int check_exec_args(omok_engine* e, int count, int K, float eps, float alpha) {
+    if (count < 1) return fail(e, OMOK_ERR_INVALID, "count must be >= 1");
+    if (K < 1 || K > e->cfg.max_batch_k) return fail(e, OMOK_ERR_INVALID, "batch_size %d outside [1, max_batch_k=%d]", K, e->cfg.max_batch_k);
+    if (!(alpha > 0.0f)) return fail(e, OMOK_ERR_INVALID, "alpha must be > 0");
+    if (!(eps >= 0.0f && eps <= 1.0f)) return fail(e, OMOK_ERR_INVALID, "epsilon must be in [0,1]");
+    return 0;
+}
+
+extern "C" int omok_execute(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (need_net(e) || need_reset(e)) return OMOK_ERR_STATE;
+    if (check_exec_args(e, count, batch_size, epsilon, alpha)) return OMOK_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    uint32_t bits = 0, alive = 0;
+    if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
+    const int rounds = enqueue_execute(e, count, batch_size, epsilon, alpha);
+    e->sims += (double)rounds * batch_size * alive;
+    if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
+    return tree_error(e, bits);
+}
+
+static void enqueue_sample(omok_engine* e, float temperature, int threshold) {
+    e->prof.begin(PC_PLY, e->st);
+    launch_sample(e->n, e->S, e->ply & 1, e->ply, temperature, threshold, e->cfg.seed, e->cfg.game_offset, e->d_actions, e->st);
+    e->prof.end(e->st);
+}
+
+extern "C" int omok_sample_actions(omok_engine* e, float temperature, int32_t threshold, int32_t* actions) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (need_reset(e)) return OMOK_ERR_STATE;
+    if (!(temperature > 0.0f)) return fail(e, OMOK_ERR_INVALID, "temperature must be > 0");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    enqueue_sample(e, temperature, threshold);
+    if (actions) HIPCHK(e, hipMemcpyAsync(actions, e->d_actions, sizeof(int32_t) * e->cfg.games, hipMemcpyDeviceToHost, e->st));
+    uint32_t bits = 0;
+    if (read_status(e, &bits, nullptr)) return OMOK_ERR_HIP;
+    e->sampled = true;
+    return tree_error(e, bits);
+}
+
+static void enqueue_mirror_and_advance(omok_engine* e) {
+    const int side = e->ply & 1;
+    e->prof.begin(PC_PLY, e->st);
+    launch_mirror_scan(e->n, e->S, side, e->st);
+    k_add_evals<<<1, 64, 0, e->st>>>(e->S.d_count, e->d_evals);
+    e->prof.end(e->st);
+    net_forward_requests(e->net, e->S, e->cfg.games, e->st, &e->prof);
+    e->prof.begin(PC_PLY, e->st);
+    launch_advance(e->n, e->S, side, e->net.p, e->st);
+    e->prof.end(e->st);
+}
+
+extern "C" int omok_advance(omok_engine* e) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (need_net(e) || need_reset(e)) return OMOK_ERR_STATE;
+    if (!e->sampled) return fail(e, OMOK_ERR_STATE, "omok_sample_actions must precede omok_advance");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    uint32_t bits = 0, before = 0, after = 0;
+    if (read_status(e, &bits, &before)) return OMOK_ERR_HIP;
+    enqueue_mirror_and_advance(e);
+    if (read_status(e, &bits, &after)) return OMOK_ERR_HIP;
+    e->ply_games += before;
+    e->finished += (double)before - (double)after;
+    e->ply += 1;
+    e->sampled = false;
+    return tree_error(e, bits);
+}
+
+extern "C" int omok_selfplay_run(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha,
+                                 float temperature, int32_t threshold, int32_t max_plies, double* stats) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (need_net(e) || need_reset(e)) return OMOK_ERR_STATE;
+    if (check_exec_args(e, count, batch_size, epsilon, alpha)) return OMOK_ERR_INVALID;
+    if (!(temperature > 0.0f)) return fail(e, OMOK_ERR_INVALID, "temperature must be > 0");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    uint32_t bits = 0, alive = 0;
+    if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
+    int plies = 0;
+    while (alive > 0 && (max_plies <= 0 || plies < max_plies)) { // trainer.rs:95
+        const int rounds = enqueue_execute(e, count, batch_size, epsilon, alpha);
+        enqueue_sample(e, temperature, threshold);
+        enqueue_mirror_and_advance(e);
+        e->sims += (double)rounds * batch_size * alive;
+        e->ply_games += alive;
+        e->ply += 1;
+        plies += 1;
+        uint32_t after = 0;
+        if (read_status(e, &bits, &after)) return OMOK_ERR_HIP;
+        e->finished += (double)alive - (double)after;
+        alive = after;
+        if (tree_error(e, bits)) return bits & 1u ? OMOK_ERR_OVERFLOW : OMOK_ERR_ILLEGAL;
+    }
+    e->sampled = false;
+    if (stats) return omok_get_stats(e, stats);
+    return OMOK_OK;
+}
+
+// ---- step-wise API (parity tests) --------------------------------------------------------------
+extern "C" int omok_round_generate(omok_engine* e, int32_t round, int32_t batch_size, float epsilon, float alpha, int32_t* n_requests) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (need_reset(e)) return OMOK_ERR_STATE;
+    if (check_exec_args(e, 1, batch_size, epsilon, alpha)) return OMOK_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    enqueue_round(e, round, batch_size, epsilon, alpha, false);
+    int32_t cnt = 0;
+    HIPCHK(e, hipMemcpyAsync(&cnt, e->S.d_count, sizeof(int32_t), hipMemcpyDeviceToHost, e->st));
+    uint32_t bits = 0, alive = 0;
+    if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
+    e->sims += (double)batch_size * alive;
+    e->round_reqs = cnt;
+    if (n_requests) *n_requests = cnt;
+    return tree_error(e, bits);
+}
+
+static int requests_to_inputs(omok_engine* e, int cnt, float* inputs) {
+    if (cnt <= 0) return OMOK_OK;
+    launch_encode_requests(e->n, e->S, e->net.in_f32, cnt, e->st);
+    HIPCHK(e, hipMemcpyAsync(inputs, e->net.in_f32, sizeof(float) * 3 * (size_t)e->hw * cnt, hipMemcpyDeviceToHost, e->st));
+    return sync_and_check(e, "request inputs") ? OMOK_ERR_HIP : OMOK_OK;
+}
+
+static int outputs_to_host(omok_engine* e, int cnt, float* p, float* v) {
+    if (cnt <= 0) return OMOK_OK;
+    float* d_pack = e->net.in_f32;
+    const size_t tot = (size_t)cnt * e->hw;
+    k_pack_rows<<<(unsigned)((tot + 255) / 256), 256, 0, e->st>>>(e->net.p, d_pack, e->hw, e->rowp, cnt);
+    HIPCHK(e, hipMemcpyAsync(p, d_pack, sizeof(float) * tot, hipMemcpyDeviceToHost, e->st));
+    if (v) HIPCHK(e, hipMemcpyAsync(v, e->net.v, sizeof(float) * cnt, hipMemcpyDeviceToHost, e->st));
+    return sync_and_check(e, "outputs") ? OMOK_ERR_HIP : OMOK_OK;
+}
+
+static int inject_outputs(omok_engine* e, int cnt, const float* p, const float* v) {
+    if (cnt <= 0) return OMOK_OK;
+    float* d_pack = e->net.in_f32;
+    HIPCHK(e, hipMemcpyAsync(d_pack, p, sizeof(float) * (size_t)cnt * e->hw, hipMemcpyHostToDevice, e->st));
+    const size_t tot = (size_t)cnt * e->rowp;
+    k_unpack_rows<<<(unsigned)((tot + 255) / 256), 256, 0, e->st>>>(d_pack, e->net.p, e->hw, e->rowp, cnt);
+    if (v) HIPCHK(e, hipMemcpyAsync(e->net.v, v, sizeof(float) * cnt, hipMemcpyHostToDevice, e->st));
+    return sync_and_check(e, "inject") ? OMOK_ERR_HIP : OMOK_OK;
+}
+
+extern "C" int omok_round_inputs(omok_engine* e, float* inputs) {
+    if (!e || !inputs) return OMOK_ERR_INVALID;
+    if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
+    return requests_to_inputs(e, e->round_reqs, inputs);
+}
+extern "C" int omok_round_eval(omok_engine* e) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (need_net(e)) return OMOK_ERR_STATE;
+    if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
+    if (e->round_reqs == 0) return OMOK_OK;
+    net_forward_requests(e->net, e->S, e->round_reqs, e->st, &e->prof);
+    return sync_and_check(e, "round_eval") ? OMOK_ERR_HIP : OMOK_OK;
+}
+extern "C" int omok_round_outputs(omok_engine* e, float* p, float* v) {
+    if (!e || !p) return OMOK_ERR_INVALID;
+    if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
+    return outputs_to_host(e, e->round_reqs, p, v);
+}
+extern "C" int omok_round_inject(omok_engine* e, const float* p, const float* v) {
+    if (!e || !p || !v) return OMOK_ERR_INVALID;
+    if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
+    return inject_outputs(e, e->round_reqs, p, v);
+}
+extern "C" int omok_round_scatter(omok_engine* e) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
+    if (e->round_reqs > 0) launch_scatter(e->n, e->S, e->ply & 1, e->net.p, e->net.v, e->st);
+    e->round_reqs = -1;
+    return sync_and_check(e, "round_scatter") ? OMOK_ERR_HIP : OMOK_OK;
+}
+
+extern "C" int omok_mirror_generate(omok_engine* e, int32_t* n_requests) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (need_reset(e)) return OMOK_ERR_STATE;
+    if (!e->sampled) return fail(e, OMOK_ERR_STATE, "omok_sample_actions must precede the mirror step");
+    launch_mirror_scan(e->n, e->S, e->ply & 1, e->st);
+    k_add_evals<<<1, 64, 0, e->st>>>(e->S.d_count, e->d_evals);
+    int32_t cnt = 0;
+    HIPCHK(e, hipMemcpyAsync(&cnt, e->S.d_count, sizeof(int32_t), hipMemcpyDeviceToHost, e->st));
+    if (sync_and_check(e, "mirror_generate")) return OMOK_ERR_HIP;
+    e->mirror_reqs = cnt;
+    if (n_requests) *n_requests = cnt;
+    return OMOK_OK;
+}
+extern "C" int omok_mirror_inputs(omok_engine* e, float* inputs) {
+    if (!e || !inputs) return OMOK_ERR_INVALID;
+    if (e->mirror_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated mirror batch");
+    return requests_to_inputs(e, e->mirror_reqs, inputs);
+}
+extern "C" int omok_mirror_eval(omok_engine* e) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (need_net(e)) return OMOK_ERR_STATE;
+    if (e->mirror_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated mirror batch");
+    if (e->mirror_reqs > 0) net_forward_requests(e->net, e->S, e->mirror_reqs, e->st, &e->prof);
+    return sync_and_check(e, "mirror_eval") ? OMOK_ERR_HIP : OMOK_OK;
+}
+extern "C" int omok_mirror_outputs(omok_engine* e, float* p) {
+    if (!e || !p) return OMOK_ERR_INVALID;
+    if (e->mirror_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated mirror batch");
+    return outputs_to_host(e, e->mirror_reqs, p, nullptr);
+}
+extern "C" int omok_mirror_inject(omok_engine* e, const float* p) {
+    if (!e || !p) return OMOK_ERR_INVALID;
+    if (e->mirror_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated mirror batch");
+    return inject_outputs(e, e->mirror_reqs, p, nullptr);
+}
+extern "C" int omok_mirror_apply(omok_engine* e) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (e->mirror_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated mirror batch");
+    uint32_t bits = 0, before = 0, after = 0;
+    if (read_status(e, &bits, &before)) return OMOK_ERR_HIP;
+    launch_advance(e->n, e->S, e->ply & 1, e->net.p, e->st);
+    if (read_status(e, &bits, &after)) return OMOK_ERR_HIP;
+    e->ply_games += before;
+    e->finished += (double)before - (double)after;
+    e->ply += 1;
+    e->sampled = false;
+    e->mirror_reqs = -1;
+    return tree_error(e, bits);
+}
+
+// ---- inspection ----------------------------------------------------------------------------------
+extern "C" int omok_alive_count(omok_engine* e) {
+    if (!e) return OMOK_ERR_INVALID;
+    uint32_t bits = 0, alive = 0;
+    if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
+    return (int)alive;
+}
+extern "C" int omok_current_ply(omok_engine* e) { return e ? e->ply : OMOK_ERR_INVALID; }
+
+extern "C" int omok_game_info(omok_engine* e, uint8_t* alive, uint8_t* status, int32_t* plies) {
+    if (!e) return OMOK_ERR_INVALID;
+    std::vector<GameState> gs((size_t)e->cfg.games);
+    HIPCHK(e, hipMemcpyAsync(gs.data(), e->S.gs, sizeof(GameState) * gs.size(), hipMemcpyDeviceToHost, e->st));
+    if (sync_and_check(e, "game_info")) return OMOK_ERR_HIP;
+    for (size_t g = 0; g < gs.size(); ++g) {
+        if (alive) alive[g] = gs[g].alive;
+        if (status) status[g] = gs[g].status;
+        if (plies) plies[g] = gs[g].plies;
+    }
+    return OMOK_OK;
+}
+
+extern "C" int omok_tree_root(omok_engine* e, int32_t game, int32_t side, uint32_t* root_n, float* root_w, int32_t* n_nodes, int32_t* n_tables) {
+    if (!e || game < 0 || game >= e->cfg.games || (side != 0 && side != 1)) return OMOK_ERR_INVALID;
+    TreeState ts;
+    HIPCHK(e, hipMemcpyAsync(&ts, e->S.ts + (size_t)side * e->cfg.games + game, sizeof(ts), hipMemcpyDeviceToHost, e->st));
+    if (sync_and_check(e, "tree_root")) return OMOK_ERR_HIP;
+    if (root_n) *root_n = ts.root_n;
+    if (root_w) *root_w = ts.root_w;
+    if (n_nodes) *n_nodes = (int32_t)ts.n_nodes;
+    if (n_tables) *n_tables = (int32_t)ts.n_tables;
+    return OMOK_OK;
+}
+
+extern "C" int omok_tree_dump(omok_engine* e, int32_t game, int32_t side, int32_t* ints, float* floats, int32_t cap_nodes) {
+    if (!e || !ints || !floats || game < 0 || game >= e->cfg.games || (side != 0 && side != 1)) return OMOK_ERR_INVALID;
+    const size_t t = (size_t)side * e->cfg.games + game;
+    TreeState ts;
+    HIPCHK(e, hipMemcpyAsync(&ts, e->S.ts + t, sizeof(ts), hipMemcpyDeviceToHost, e->st));
+    if (sync_and_check(e, "tree_dump")) return OMOK_ERR_HIP;
+    const int nn = (int)ts.n_nodes, nt = (int)ts.n_tables;
+    if (nn > cap_nodes) return -nn;
+    const size_t rp = (size_t)e->rowp, nw2 = 2 * (size_t)e->nw;
+    std::vector<NodeHdr> hdr((size_t)nn);
+    std::vector<uint64_t> board((size_t)nn * nw2);
+    std::vector<float> pol((size_t)nn * rp), cw((size_t)nt * rp);
+    std::vector<uint32_t> cn((size_t)nt * rp);
+    std::vector<uint8_t> co((size_t)nt * rp);
+    const size_t tn = t * (size_t)e->cfg.max_nodes, tt = t * (size_t)e->cfg.max_tables;
+    hipMemcpyAsync(hdr.data(), e->S.hdr + tn, sizeof(NodeHdr) * nn, hipMemcpyDeviceToHost, e->st);
+    hipMemcpyAsync(board.data(), e->S.board + tn * nw2, 8 * nw2 * nn, hipMemcpyDeviceToHost, e->st);
+    hipMemcpyAsync(pol.data(), e->S.policy + tn * rp, 4 * rp * nn, hipMemcpyDeviceToHost, e->st);
+    if (nt) {
+        hipMemcpyAsync(cn.data(), e->S.tcn + tt * rp, 4 * rp * nt, hipMemcpyDeviceToHost, e->st);
+        hipMemcpyAsync(cw.data(), e->S.tcw + tt * rp, 4 * rp * nt, hipMemcpyDeviceToHost, e->st);
+        hipMemcpyAsync(co.data(), e->S.tcorder + tt * rp, rp * nt, hipMemcpyDeviceToHost, e->st);
+    }
+    if (sync_and_check(e, "tree_dump")) return OMOK_ERR_HIP;
+    const int hw = e->hw;
+    for (int i = 0; i < nn; ++i) {
+        const NodeHdr& h = hdr[i];
+        int32_t* o = ints + (size_t)i * 8;
+        float* f = floats + (size_t)i * (1 + hw);
+        uint32_t n = ts.root_n;
+        float w = ts.root_w;
+        int order = -1;
+        if (i != 0) {
+            const size_t slot = (size_t)hdr[h.parent].table * rp + h.action;
+            n = cn[slot]; w = cw[slot]; order = co[slot];
+        }
+        o[0] = h.parent == NONE16 ? -1 : h.parent;
+        o[1] = h.action == NONE8 ? -1 : h.action;
+        o[2] = h.status; o[3] = h.turn; o[4] = h.legal; o[5] = h.nch; o[6] = (int32_t)n;
+        o[7] = (order & 0xffff) | ((int32_t)h.has_policy << 16);
+        f[0] = w;
+        for (int a = 0; a < hw; ++a) {
+            float v;
+            if (h.has_policy) v = pol[(size_t)i * rp + a];
+            else {
+                const bool occ = ((board[(size_t)i * nw2 + a / 64] | board[(size_t)i * nw2 + e->nw + a / 64]) >> (a % 64)) & 1ULL;
+                v = (occ || h.legal == 0) ? 0.0f : 1.0f / (float)h.legal;
+            }
+            f[1 + a] = v;
+        }
+    }
+    return nn;
+}
+
+extern "C" int omok_replay_game(omok_engine* e, int32_t game, uint8_t* boards, uint8_t* turns, float* pi, float* z, int32_t cap_plies) {
+    if (!e || game < 0 || game >= e->cfg.games) return OMOK_ERR_INVALID;
+    GameState gs;
+    HIPCHK(e, hipMemcpyAsync(&gs, e->S.gs + game, sizeof(gs), hipMemcpyDeviceToHost, e->st));
+    if (sync_and_check(e, "replay_game")) return OMOK_ERR_HIP;
+    const int plies = gs.plies < e->hw ? gs.plies : e->hw;
+    const int n = plies < cap_plies ? plies : cap_plies;
+    if (n <= 0) return plies;
+    const size_t rp = (size_t)e->rowp, nw2 = 2 * (size_t)e->nw, hw = (size_t)e->hw;
+    std::vector<uint64_t> b((size_t)n * nw2);
+    std::vector<float> ppi((size_t)n * rp);
+    const size_t rec = (size_t)game * hw;
+    hipMemcpyAsync(b.data(), e->S.rp_board + rec * nw2, 8 * nw2 * n, hipMemcpyDeviceToHost, e->st);
+    hipMemcpyAsync(ppi.data(), e->S.rp_pi + rec * rp, 4 * rp * n, hipMemcpyDeviceToHost, e->st);
+    if (turns) hipMemcpyAsync(turns, e->S.rp_turn + rec, (size_t)n, hipMemcpyDeviceToHost, e->st);
+    if (z) hipMemcpyAsync(z, e->S.rp_z + rec, 4 * (size_t)n, hipMemcpyDeviceToHost, e->st);
+    if (sync_and_check(e, "replay_game")) return OMOK_ERR_HIP;
+    for (int p = 0; p < n; ++p)
+        for (size_t a = 0; a < hw; ++a) {
+            if (boards) {
+                const bool bl = (b[(size_t)p * nw2 + a / 64] >> (a % 64)) & 1ULL, wh = (b[(size_t)p * nw2 + e->nw + a / 64] >> (a % 64)) & 1ULL;
+                boards[(size_t)p * hw + a] = bl ? 1 : (wh ? 2 : 0);
+            }
+            if (pi) pi[(size_t)p * hw + a] = ppi[(size_t)p * rp + a];
+        }
+    return plies;
+}
+
+extern "C" int32_t omok_replay_record_bytes(const omok_engine* e) {
+    if (!e) return OMOK_ERR_INVALID;
+    return (e->hw + 1 + 3) / 4 * 4 + 4 * e->hw + 4;
+}
+
+extern "C" int64_t omok_replay_pack_dev(omok_engine* e, void* dst_dev, int64_t cap_records) {
+    if (!e || !dst_dev || cap_records < 0) return OMOK_ERR_INVALID;
+    hipMemsetAsync(e->d_pack_total, 0, 16, e->st);
+    launch_replay_pack(e->n, e->S, (uint8_t*)dst_dev, cap_records, e->d_pack_total, e->st);
+    long long total = 0;
+    if (hipMemcpyAsync(&total, e->d_pack_total, 8, hipMemcpyDeviceToHost, e->st) != hipSuccess) return OMOK_ERR_HIP;
+    if (sync_and_check(e, "replay_pack")) return OMOK_ERR_HIP;
+    return total;
+}
+
+extern "C" int omok_get_stats(omok_engine* e, double* stats) {
+    if (!e || !stats) return OMOK_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (sync_and_check(e, "get_stats")) return OMOK_ERR_HIP;
+    e->prof.resolve();
+    unsigned long long ev = 0, by = 0;
+    HIPCHK(e, hipMemcpy(&ev, e->d_evals, 8, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&by, e->S.d_bytes, 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < OMOK_STAT_COUNT; ++i) stats[i] = 0.0;
+    stats[OMOK_STAT_SIMS] = e->sims;
+    stats[OMOK_STAT_EVALS] = e->evals + (double)ev;
+    stats[OMOK_STAT_PLY_GAMES] = e->ply_games;
+    stats[OMOK_STAT_FINISHED] = e->finished;
+    stats[OMOK_STAT_MS_TREE] = e->prof.ms[PC_ROUND] + e->prof.ms[PC_TREE_OTHER];
+    stats[OMOK_STAT_MS_TRUNK] = e->prof.ms[PC_TRUNK];
+    stats[OMOK_STAT_MS_FC0] = e->prof.ms[PC_FC0];
+    stats[OMOK_STAT_MS_TAIL] = e->prof.ms[PC_TAIL];
+    stats[OMOK_STAT_MS_PLY] = e->prof.ms[PC_PLY];
+    stats[OMOK_STAT_FC0_LAUNCHES] = (double)e->prof.launches[PC_FC0];
+    stats[OMOK_STAT_FC0_ROWS] = e->evals + (double)ev;
+    stats[OMOK_STAT_TREE_BYTES] = (double)by;
+    stats[OMOK_STAT_ROUND_LAUNCHES] = (double)e->prof.launches[PC_ROUND];
+    stats[OMOK_STAT_MS_ROUND] = e->prof.ms[PC_ROUND];
+    return OMOK_OK;
+}
+
+extern "C" int omok_reset_stats(omok_engine* e) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (sync_and_check(e, "reset_stats")) return OMOK_ERR_HIP;
+    e->prof.resolve();
+    for (int i = 0; i < PC_COUNT; ++i) { e->prof.ms[i] = 0; e->prof.launches[i] = 0; }
+    e->sims = e->evals = e->ply_games = e->finished = 0;
+    hipMemset(e->d_evals, 0, 16);
+    hipMemset(e->S.d_bytes, 0, 16);
+    return OMOK_OK;
+}
+
+extern "C" int omok_set_profiling(omok_engine* e, int32_t enabled) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (!enabled) e->prof.resolve();
+    e->prof.enabled = enabled != 0;
+    return OMOK_OK;
+}

@@ -1,0 +1,90 @@
+// net.h — policy/value net state shared by engine.cpp and net_kernels.hip
+#pragma once
+#include "common.h"
+#include "../../include/omok_mi355x.h"
+
+namespace omok {
+
+constexpr int NET_TENSORS = 31;
+constexpr int NC = 128; // RESIDUAL_CHANNELS (alpha-zero/src/network.rs:24)
+constexpr int NM = 32;  // RESIDUAL_MIDDLE_CHANNELS (:25)
+constexpr int NF = 512; // FC_0_SIZE / FC_1_SIZE (:29-30)
+
+struct Net {
+    int n = 0, hw = 0, rowp = 0, mode = 0;
+    int max_b = 0;
+    bool committed = false;
+    bool loaded[NET_TENSORS] = {};
+    int64_t wsize[NET_TENSORS] = {};
+    float* w[NET_TENSORS] = {}; // raw fp32 tensors in reference order (device)
+    // outputs: p [max_b][ROWP] softmax probabilities (pad cells 0), v [max_b]
+    float* p = nullptr;
+    float* v = nullptr;
+    float* in_f32 = nullptr; // [max_b][3*HW] encoder.rs layout (evaluate_pv / step-wise API / f32 path)
+    // ---- OMOK_NET_F32 scratch (chunked) ----
+    int chunk = 0;
+    float *sx = nullptr, *sh = nullptr, *sd = nullptr, *sg = nullptr, *s0 = nullptr, *s1 = nullptr;
+    // ---- OMOK_NET_F16X3: packed split-fp16 operands (see net_kernels.hip) ----
+    void* wt_trunk = nullptr; // packed trunk weights (A-operand fragments, hi|lo)
+    float* wt_first = nullptr; // conv_in weights/bias + all biases + depthwise taps, fp32
+    void* wt_fc0 = nullptr;   // [kstep][ntile][hi|lo][lane][8] f16
+    void* wt_fc1 = nullptr;
+    void* wt_heads = nullptr;
+    void* a_fc0 = nullptr;    // [max_b][KSTEPS][hi 16 | lo 16] f16 : trunk output = fc0 A operand
+    void* h0 = nullptr;       // [max_b][512] hi|lo f16 : fc0 output = fc1 A operand
+    size_t bytes = 0;         // device bytes held
+};
+
+// sizes
+inline int64_t net_tensor_size(int n, int idx) {
+    const int64_t hw = (int64_t)n * n;
+    if (idx == 0) return 3 * NC;
+    if (idx == 1) return NC;
+    if (idx >= 2 && idx < 23) {
+        const int64_t q[7] = {NC * NM, NM, 9 * NM, NM * NM, NM, NM * NC, NC};
+        return q[(idx - 2) % 7];
+    }
+    switch (idx) {
+        case 23: return NC * hw * NF;
+        case 24: return NF;
+        case 25: return (int64_t)NF * NF;
+        case 26: return NF;
+        case 27: return NF;
+        case 28: return 1;
+        case 29: return NF * hw;
+        case 30: return hw;
+    }
+    return -1;
+}
+
+// net_kernels.hip
+// Forward of the `count` samples described by S.req_ref/req_aux (count read from S.d_count on the
+// device; grids are sized for max_count).  Results in net.p / net.v.
+void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, struct Prof* prof);
+// Forward of explicit f32 inputs already in net.in_f32 ([count][3HW]); count is a host value
+// and must also be stored in S.d_count[0] by the caller.
+void net_forward_inputs(Net& net, const Store& S, int count, hipStream_t st, struct Prof* prof);
+// Packs the raw tensors into the MFMA operand layouts (host-side repack + upload).
+int net_commit(Net& net, hipStream_t st);
+size_t net_alloc(Net& net); // allocates buffers for net.max_b; returns bytes, 0 on failure
+void net_free(Net& net);
+
+// ---- tiny profiler: HIP-event pairs per category, resolved lazily ----
+enum { PC_ROUND = 0, PC_TREE_OTHER, PC_TRUNK, PC_FC0, PC_TAIL, PC_PLY, PC_COUNT };
+struct Prof {
+    bool enabled = false;
+    struct Item { int cat; hipEvent_t a, b; };
+    Item* items = nullptr;
+    int n_items = 0, cap_items = 0;
+    hipEvent_t* pool = nullptr;
+    int n_pool = 0, cap_pool = 0;
+    double ms[PC_COUNT] = {};
+    long long launches[PC_COUNT] = {};
+    hipEvent_t get();
+    void begin(int cat, hipStream_t st);
+    void end(hipStream_t st);
+    void resolve(); // synchronises on the recorded events and accumulates ms
+    void destroy();
+};
+
+} // namespace omok

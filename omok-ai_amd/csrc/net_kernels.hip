@@ -1,0 +1,738 @@
+// net_kernels.hip — forward of the policy/value net (alpha-zero/src/network.rs:51-262, builders
+// network-utils/src/lib.rs:95-170,172-262,285-330,386-461) for gfx950.
+//
+// OMOK_NET_F16X3 (default): every contraction runs on v_mfma_f32_32x32x16_f16 with SPLIT fp16
+// operands: x = hi + lo (hi = f16(x), lo = f16(x - hi)), product = hi*hi + lo*hi + hi*lo in an
+// fp32 accumulator (3 MFMAs).  Plain fp16/bf16 inputs miss the 1e-3 parity bar on this net
+// (random-init logits have std ~9; tools/precision_study.py), split fp16 lands at ~1e-5.
+//
+// Everything is computed TRANSPOSED: D[out-feature, column] = W^T[out, in] * X[in, column] with the
+// column (pixel in the trunk, sample in the fc layers) on the MFMA lane.  A 32x32 accumulator
+// tile then IS the next layer's B operand (no LDS round trip): registers 8s..8s+7 of lane-half h
+// are the 8 k-values of k-step s, in the permuted order
+//     kperm(T, s, h, j) = 32*T + 16*s + 8*(j>>2) + 4*h + (j&3)
+// and every weight matrix is packed on the host in exactly that k order (pack_A below).
+//
+//   k_trunk   one workgroup = one sample, one wave = one 32-pixel tile: conv_in (VALU, K=3) ->
+//             3 x { 1x1 128->32, depthwise 3x3 through an LDS halo grid, 1x1 32->32, 1x1 32->128 +
+//             residual } with all weights LDS-resident -> fc0 operand rows (hi|lo f16) in HBM
+//   k_gemm_t  D^T[M x samples] = Wp[M x K] * Act^T, 8 waves, LDS double buffer: fc0, fc1, heads
+//   k_softmax policy softmax + value tanh
+//
+// OMOK_NET_F32: naive fp32 VALU kernels (k-ascending sums), debug / A-B reference on the GPU.
+#include "net.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace omok {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int kperm(int T, int s, int h, int j) { return 32 * T + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+__device__ inline float lrelu(float x) { return fmaxf(x, 0.2f * x); } // LeakyRelu alpha 0.2 (TF default)
+
+__device__ inline void split8(const float* v, half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)v[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(v[j] - (float)h);
+    }
+}
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define MFMA3(ah, al, bh, bl, c)   \
+    do {                           \
+        (c) = MFMA16((ah), (bh), (c)); \
+        (c) = MFMA16((al), (bh), (c)); \
+        (c) = MFMA16((ah), (bl), (c)); \
+    } while (0)
+
+// ===============================================================================================
+// OMOK_NET_F32 kernels
+// ===============================================================================================
+template <int ACT> // 0 none, 1 lrelu, 2 lrelu(x + res), 3 tanh
+__global__ void k32_linear(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+                           const float* res, float* out, int rows_per_sample, int cin, int cout,
+                           const int32_t* __restrict__ d_count, int base, int chunk) {
+    int cnt = d_count[0] - base;
+    if (cnt > chunk) cnt = chunk;
+    const size_t total = (size_t)(cnt > 0 ? cnt : 0) * rows_per_sample * cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / cout;
+        const int o = (int)(i % cout);
+        const float* x = in + row * cin;
+        float acc = 0.0f;
+        for (int k = 0; k < cin; ++k) acc += x[k] * w[(size_t)k * cout + o];
+        acc += b[o];
+        if (ACT == 2) acc += res[row * cout + o];
+        if (ACT == 1 || ACT == 2) acc = acc > 0.0f ? acc : 0.2f * acc;
+        if (ACT == 3) acc = tanhf(acc);
+        out[row * cout + o] = acc;
+    }
+}
+
+__global__ void k32_depthwise(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out, int n,
+                              const int32_t* __restrict__ d_count, int base, int chunk) {
+    int cnt = d_count[0] - base;
+    if (cnt > chunk) cnt = chunk;
+    const int hw = n * n;
+    const size_t total = (size_t)(cnt > 0 ? cnt : 0) * hw * NM;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % NM);
+        const size_t pix = i / NM;
+        const int px = (int)(pix % hw);
+        const size_t s = pix / hw;
+        const int y = px / n, x = px % n;
+        float acc = 0.0f;
+        for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) {
+                const int yy = y + dy - 1, xx = x + dx - 1;
+                if (yy < 0 || yy >= n || xx < 0 || xx >= n) continue;
+                acc += in[(s * hw + (size_t)(yy * n + xx)) * NM + c] * w[(dy * 3 + dx) * NM + c];
+            }
+        out[i] = acc;
+    }
+}
+
+__global__ void k32_softmax(const float* __restrict__ logits, float* __restrict__ p, int hw, int rowp,
+                            const int32_t* __restrict__ d_count, int base, int chunk) {
+    int cnt = d_count[0] - base;
+    if (cnt > chunk) cnt = chunk;
+    const int s = blockIdx.x;
+    if (s >= cnt) return;
+    const int lane = threadIdx.x;
+    const float* l = logits + (size_t)s * hw;
+    float mx = -INFINITY;
+    for (int a = lane; a < hw; a += 64) mx = fmaxf(mx, l[a]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.0f;
+    for (int a = lane; a < hw; a += 64) sum += expf(l[a] - mx);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    float* po = p + (size_t)(base + s) * rowp;
+    for (int a = lane; a < rowp; a += 64) po[a] = a < hw ? expf(l[a] - mx) / sum : 0.0f;
+}
+
+static void forward_f32(Net& net, const Store& S, int max_count, hipStream_t st, Prof* prof) {
+    const int hw = net.hw, n = net.n;
+    const int grid = 2048, blk = 256;
+    for (int base = 0; base < max_count; base += net.chunk) {
+        const int ch = net.chunk;
+        const float* in = net.in_f32 + (size_t)base * 3 * hw;
+        if (prof) prof->begin(PC_TRUNK, st);
+        k32_linear<1><<<grid, blk, 0, st>>>(in, net.w[0], net.w[1], nullptr, net.sx, hw, 3, NC, S.d_count, base, ch);
+        for (int b = 0; b < 3; ++b) {
+            float* const* t = net.w + 2 + 7 * b;
+            k32_linear<1><<<grid, blk, 0, st>>>(net.sx, t[0], t[1], nullptr, net.sh, hw, NC, NM, S.d_count, base, ch);
+            k32_depthwise<<<grid, blk, 0, st>>>(net.sh, t[2], net.sd, n, S.d_count, base, ch);
+            k32_linear<1><<<grid, blk, 0, st>>>(net.sd, t[3], t[4], nullptr, net.sg, hw, NM, NM, S.d_count, base, ch);
+            k32_linear<2><<<grid, blk, 0, st>>>(net.sg, t[5], t[6], net.sx, net.sx, hw, NM, NC, S.d_count, base, ch);
+        }
+        if (prof) { prof->end(st); prof->begin(PC_FC0, st); }
+        k32_linear<1><<<grid, blk, 0, st>>>(net.sx, net.w[23], net.w[24], nullptr, net.s0, 1, NC * hw, NF, S.d_count, base, ch);
+        if (prof) { prof->end(st); prof->begin(PC_TAIL, st); }
+        k32_linear<1><<<grid, blk, 0, st>>>(net.s0, net.w[25], net.w[26], nullptr, net.s1, 1, NF, NF, S.d_count, base, ch);
+        k32_linear<3><<<grid, blk, 0, st>>>(net.s1, net.w[27], net.w[28], nullptr, net.v + base, 1, NF, 1, S.d_count, base, ch);
+        k32_linear<0><<<grid, blk, 0, st>>>(net.s1, net.w[29], net.w[30], nullptr, net.sh, 1, NF, hw, S.d_count, base, ch);
+        k32_softmax<<<ch, 64, 0, st>>>(net.sh, net.p, hw, net.rowp, S.d_count, base, ch);
+        if (prof) prof->end(st);
+    }
+}
+
+// ===============================================================================================
+// OMOK_NET_F16X3: trunk
+// ===============================================================================================
+// Packed trunk weights (f16, 1 KiB fragments of [lane 64][8]): per block 36 fragments:
+//   L0 hi[8 ks] | L0 lo[8] | L1 hi[2] | L1 lo[2] | L2 hi[4 m][2 ks] | L2 lo[4][2]
+// fp32 side table (floats): per block { dw[9][32], b0[32], b1[32], b2[128] } then conv_w[3][128], conv_b[128]
+constexpr int TR_FRAGS_PER_BLOCK = 36;
+constexpr int TR_WBYTES = 3 * TR_FRAGS_PER_BLOCK * 1024;
+constexpr int TR_SIDE_PER_BLOCK = 9 * NM + NM + NM + NC; // 480 floats
+constexpr int TR_SIDE_FLOATS = 3 * TR_SIDE_PER_BLOCK + 3 * NC + NC; // 1952
+constexpr int GRID_STRIDE = 36; // floats per halo-grid row (32 + 4 pad: conflict-free b128 reads)
+
+template <int N>
+struct TrunkGeo {
+    static constexpr int HW = N * N;
+    static constexpr int TILES = (HW + 31) / 32;
+    static constexpr int KSTEPS = HW * 8; // fc0 k-steps: (px*4 + m)*2 + s
+    static constexpr int GRID_ROWS = (N + 2) * (N + 2);
+    static constexpr int GRID_BYTES = GRID_ROWS * GRID_STRIDE * 4;
+    static constexpr int LDS_BYTES = TR_WBYTES + GRID_BYTES + TR_SIDE_FLOATS * 4;
+};
+
+template <int N, bool FROM_F32>
+__global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, const float* __restrict__ in_f32,
+                                                                    const uint4* __restrict__ wt, const float* __restrict__ side,
+                                                                    uint4* __restrict__ a_out, int max_count) {
+    using TG = TrunkGeo<N>;
+    constexpr int HW = TG::HW, NW = Geo<N>::NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const half8* ldsW = (const half8*)smem;
+    float* grid = (float*)(smem + TR_WBYTES);
+    const float* lside = (const float*)(smem + TR_WBYTES + TG::GRID_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, tile = tid >> 6;
+    const int h = lane >> 5;
+    // ---- one-time: weights, side table, zero halo grid ----
+    for (int i = tid; i < TR_WBYTES / 16; i += blockDim.x) ((uint4*)smem)[i] = wt[i];
+    for (int i = tid; i < TR_SIDE_FLOATS; i += blockDim.x) ((float*)lside)[i] = side[i];
+    for (int i = tid; i < TG::GRID_ROWS * GRID_STRIDE; i += blockDim.x) grid[i] = 0.0f;
+    __syncthreads();
+    int count = S.d_count[0];
+    if (count > max_count) count = max_count;
+    const int px = tile * 32 + (lane & 31);
+    const bool valid = px < HW;
+    const int pxc = valid ? px : HW - 1;
+    const int gi = (pxc / N + 1) * (N + 2) + (pxc % N + 1);
+    const float* conv_w = lside + 3 * TR_SIDE_PER_BLOCK;
+    const float* conv_b = conv_w + 3 * NC;
+
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        // ---- conv_in 1x1 3->128 + bias + lrelu on the flat encoder.rs layout (VALU) ----
+        float f0, f1, f2;
+        if (FROM_F32) {
+            const float* f = in_f32 + (size_t)b * 3 * HW + 3 * pxc;
+            f0 = f[0]; f1 = f[1]; f2 = f[2];
+        } else {
+            const uint32_t ref = S.req_ref[b], aux = S.req_aux[b];
+            const size_t tn = (size_t)(ref >> 16) * (size_t)S.cap_nodes + (size_t)(ref & 0xFFFFu);
+            uint64_t bb[2 * NW];
+#pragma unroll
+            for (int i = 0; i < 2 * NW; ++i) bb[i] = S.board[tn * (2 * NW) + i];
+            int turn = S.hdr[tn].turn, mode = 0;
+            if (aux != 0xFFFFFFFFu) { // clone + place_stone(action), Opponent mode (agent.rs:154-158)
+                const int action = (int)(aux & 0xFFFFu);
+                mode = (int)(aux >> 16) & 1;
+                bool occ = false;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) occ = occ || ((action >> 6) == i && (((bb[i] | bb[NW + i]) >> (action & 63)) & 1ULL));
+                if (!occ) {
+#pragma unroll
+                    for (int i = 0; i < NW; ++i) {
+                        const uint64_t bit = (action >> 6) == i ? (1ULL << (action & 63)) : 0ULL;
+                        bb[i] |= turn == 0 ? bit : 0ULL;
+                        bb[NW + i] |= turn == 0 ? 0ULL : bit;
+                    }
+                    turn = 1 - turn;
+                }
+            }
+            const int persp = mode == 0 ? turn : 1 - turn; // encoder.rs:24-27
+            const float tplane = turn == 0 ? 1.0f : 0.0f;  // encoder.rs:34-37
+            float fv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int m = 3 * pxc + c;
+                if (m < 2 * HW) {
+                    const int cell = m >> 1;
+                    uint64_t wb = bb[0], ww = bb[NW];
+#pragma unroll
+                    for (int i = 1; i < NW; ++i) { wb = (cell >> 6) == i ? bb[i] : wb; ww = (cell >> 6) == i ? bb[NW + i] : ww; }
+                    const int isb = (int)((wb >> (cell & 63)) & 1ULL), isw = (int)((ww >> (cell & 63)) & 1ULL);
+                    const int mine = persp == 0 ? isb : isw, theirs = persp == 0 ? isw : isb;
+                    fv[c] = (m & 1) ? (float)theirs : (float)mine;
+                } else {
+                    fv[c] = tplane;
+                }
+            }
+            f0 = fv[0]; f1 = fv[1]; f2 = fv[2];
+        }
+        f32x16 x[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch0 = 32 * m + 8 * g + 4 * h;
+                const f32x4 w0 = *(const f32x4*)(conv_w + ch0), w1 = *(const f32x4*)(conv_w + NC + ch0),
+                            w2 = *(const f32x4*)(conv_w + 2 * NC + ch0), bb4 = *(const f32x4*)(conv_b + ch0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[m][4 * g + i] = lrelu(((f0 * w0[i] + f1 * w1[i]) + f2 * w2[i]) + bb4[i]);
+            }
+        }
+        // ---- 3 bottleneck residual blocks ----
+#pragma unroll 1
+        for (int blk = 0; blk < 3; ++blk) {
+            const half8* W = ldsW + (size_t)blk * TR_FRAGS_PER_BLOCK * 64;
+            const float* sd = lside + blk * TR_SIDE_PER_BLOCK;
+            const float *dwt = sd, *b0 = sd + 9 * NM, *b1 = b0 + NM, *b2 = b1 + NM;
+            // L0: 1x1 128 -> 32, bias as the initial accumulator
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4*)(b0 + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[4 * g + i] = bv[i];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = x[ks >> 1][8 * (ks & 1) + j];
+                half8 bh, bl;
+                split8(v, bh, bl);
+                const half8 ah = W[(0 + ks) * 64 + lane], al = W[(8 + ks) * 64 + lane];
+                MFMA3(ah, al, bh, bl, acc);
+                asm volatile("" ::: "memory");
+            }
+            __syncthreads(); // previous readers of the halo grid are done
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = lrelu(acc[4 * g + i]);
+                    *(f32x4*)(grid + gi * GRID_STRIDE + 8 * g + 4 * h) = o;
+                }
+            }
+            __syncthreads();
+            // depthwise 3x3 SAME (zero halo), taps in (dy,dx) order; no bias
+            float d[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int nrow = gi + (tap / 3 - 1) * (N + 2) + (tap % 3 - 1);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 hv = *(const f32x4*)(grid + nrow * GRID_STRIDE + 8 * g + 4 * h);
+                    const f32x4 wv = *(const f32x4*)(dwt + tap * NM + 8 * g + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d[4 * g + i] += hv[i] * wv[i];
+                }
+            }
+            // L1: pointwise 32 -> 32 + bias + lrelu
+            f32x16 accg;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4*)(b1 + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accg[4 * g + i] = bv[i];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 bh, bl;
+                split8(d + 8 * ks, bh, bl);
+                const half8 ah = W[(16 + ks) * 64 + lane], al = W[(18 + ks) * 64 + lane];
+                MFMA3(ah, al, bh, bl, accg);
+            }
+            // L2: 1x1 32 -> 128 + bias + residual (accumulated onto x), lrelu
+            float gv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gv[i] = lrelu(accg[i]);
+            half8 gh[2], gl[2];
+            split8(gv, gh[0], gl[0]);
+            split8(gv + 8, gh[1], gl[1]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *(const f32x4*)(b2 + 32 * m + 8 * g + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[m][4 * g + i] += bv[i];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const half8 ah = W[(20 + m * 2 + ks) * 64 + lane], al = W[(28 + m * 2 + ks) * 64 + lane];
+                    MFMA3(ah, al, gh[ks], gl[ks], x[m]);
+                    asm volatile("" ::: "memory");
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[m][i] = lrelu(x[m][i]);
+            }
+        }
+        // ---- fc0 operand row: [ks = (px*4 + m)*2 + s][hi h0 | hi h1 | lo h0 | lo h1] (64 B per k-step) ----
+        if (valid) {
+            uint4* row = a_out + (size_t)b * (TG::KSTEPS * 4);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = x[m][8 * s + j];
+                    half8 hi, lo;
+                    split8(v, hi, lo);
+                    const int ks = (px * 4 + m) * 2 + s;
+                    row[ks * 4 + h] = *(const uint4*)&hi;
+                    row[ks * 4 + 2 + h] = *(const uint4*)&lo;
+                }
+        }
+    }
+}
+
+// ===============================================================================================
+// OMOK_NET_F16X3: transposed GEMM  D^T[MT*32 x 128 samples] = Wp * Act^T
+// ===============================================================================================
+// Wp : [ksteps][MT][hi|lo][lane][8] f16 (1 KiB fragments), Act: rows of [ksteps][hi h0|hi h1|lo h0|lo h1]
+// 8 waves: wm = wave>>1 owns MT/4 m-tiles, ws = wave&1 owns 2 of the 4 sample tiles.
+enum { EPI_SPLIT = 0, EPI_LOGITS = 1 };
+constexpr int GT_BS = 128;
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksteps,
+                                                size_t act_row_u4, const float* __restrict__ bias, uint4* __restrict__ out_split,
+                                                size_t out_row_u4, float* __restrict__ out_logits, const int32_t* __restrict__ d_count,
+                                                int max_count) {
+    constexpr int MTW = MT / 4;
+    constexpr int WFR = MT * 2;            // weight fragments per k-step
+    constexpr int NFR = WFR + 8;           // + 4 sample tiles x (hi, lo)
+    constexpr int LPW = (NFR + 7) / 8;     // staging loads per wave per k-step
+    constexpr int STAGE_U4 = NFR * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* lds = (uint4*)smem;
+    int count = d_count[0];
+    if (count > max_count) count = max_count;
+    const int b0 = blockIdx.x * GT_BS;
+    if (b0 >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, ws = wave & 1;
+    const int h = lane >> 5;
+
+    // staging plan: fragment f = wave + 8*i ; f < WFR: weights (linear copy), else activation fragment
+    const uint4* src[LPW];
+    size_t step_u4[LPW];
+    int dst[LPW];
+    bool on[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        const int f = wave + 8 * i;
+        on[i] = f < NFR;
+        dst[i] = f * 64 + lane;
+        if (f < WFR) {
+            src[i] = wp + (size_t)f * 64 + lane;
+            step_u4[i] = (size_t)WFR * 64;
+        } else {
+            const int a = f - WFR, ct = a >> 1, part = a & 1;
+            const size_t row = (size_t)(b0 + 32 * ct + (lane & 31));
+            src[i] = act + row * act_row_u4 + part * 2 + h;
+            step_u4[i] = 4;
+        }
+    }
+    f32x16 acc[MTW][2];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
+
+    uint4 stage[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i)
+        if (on[i]) stage[i] = *src[i];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i)
+        if (on[i]) lds[dst[i]] = stage[i];
+    __syncthreads();
+
+    for (int t = 0; t < ksteps; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ksteps) {
+#pragma unroll
+            for (int i = 0; i < LPW; ++i)
+                if (on[i]) stage[i] = *(src[i] + (size_t)(t + 1) * step_u4[i]);
+        }
+        const half8* L = (const half8*)(lds + cur * STAGE_U4);
+        half8 bh[2], bl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bh[c] = L[(WFR + (2 * ws + c) * 2 + 0) * 64 + lane];
+            bl[c] = L[(WFR + (2 * ws + c) * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int mt = wm * MTW + i;
+            const half8 ah = L[(mt * 2 + 0) * 64 + lane], al = L[(mt * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) MFMA3(ah, al, bh[c], bl[c], acc[i][c]);
+        }
+        if (t + 1 < ksteps) {
+            uint4* Ln = lds + (cur ^ 1) * STAGE_U4;
+#pragma unroll
+            for (int i = 0; i < LPW; ++i)
+                if (on[i]) Ln[dst[i]] = stage[i];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int sample = b0 + 32 * (2 * ws + c) + (lane & 31);
+        if (sample >= count) continue;
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int mt = wm * MTW + i;
+            float y[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4*)(bias + 32 * mt + 8 * g + 4 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[4 * g + q] = acc[i][c][4 * g + q] + bv[q];
+            }
+            if (EPI == EPI_SPLIT) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = lrelu(y[8 * s + j]);
+                    half8 hi, lo;
+                    split8(v, hi, lo);
+                    uint4* row = out_split + (size_t)sample * out_row_u4 + (size_t)(2 * mt + s) * 4;
+                    row[h] = *(const uint4*)&hi;
+                    row[2 + h] = *(const uint4*)&lo;
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = y[4 * g + q];
+                    *(f32x4*)(out_logits + (size_t)sample * (MT * 32) + 32 * mt + 8 * g + 4 * h) = o;
+                }
+            }
+        }
+    }
+}
+
+// policy softmax (network.rs:236-247) + value tanh (network.rs:197-200); one wave per sample
+__global__ __launch_bounds__(64) void k_softmax(const float* __restrict__ logits, int lrow, int hw, int rowp, float* __restrict__ p,
+                                                float* __restrict__ v, const int32_t* __restrict__ d_count, int max_count) {
+    int count = d_count[0];
+    if (count > max_count) count = max_count;
+    const int lane = threadIdx.x;
+    for (int s = blockIdx.x; s < count; s += gridDim.x) {
+        const float* l = logits + (size_t)s * lrow;
+        float mx = -INFINITY;
+        for (int a = lane; a < hw; a += 64) mx = fmaxf(mx, l[a]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.0f;
+        for (int a = lane; a < hw; a += 64) sum += expf(l[a] - mx);
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        for (int a = lane; a < rowp; a += 64) p[(size_t)s * rowp + a] = a < hw ? expf(l[a] - mx) / sum : 0.0f;
+        if (lane == 0) v[s] = tanhf(l[hw]);
+    }
+}
+
+// ===============================================================================================
+// host: packing + launch
+// ===============================================================================================
+static inline void split_h(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+// Packs W (element (k, m) via getw) into [ksteps][MT][hi|lo][lane][8]; kidx(ks, h, j) -> source k
+template <typename GetW, typename KIdx>
+static void pack_A(std::vector<_Float16>& out, int ksteps, int MT, GetW getw, KIdx kidx) {
+    out.assign((size_t)ksteps * MT * 2 * 64 * 8, (_Float16)0.0f);
+    for (int ks = 0; ks < ksteps; ++ks)
+        for (int mt = 0; mt < MT; ++mt)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int r = l & 31, h = l >> 5;
+                    const float w = getw(kidx(ks, h, j), 32 * mt + r);
+                    _Float16 hi, lo;
+                    split_h(w, hi, lo);
+                    const size_t base = (((size_t)ks * MT + mt) * 2) * 512 + (size_t)l * 8 + j;
+                    out[base] = hi;
+                    out[base + 512] = lo;
+                }
+}
+
+static int heads_mt(int hw) { return ((hw + 1 + 31) / 32 + 3) / 4 * 4; }
+
+size_t net_alloc(Net& net) {
+    const size_t hw = net.hw, rp = net.rowp;
+    const size_t mb = ((size_t)net.max_b + GT_BS - 1) / GT_BS * GT_BS;
+    size_t bytes = 0;
+    auto A = [&](void** p, size_t n) {
+        if (hipMalloc(p, n ? n : 16) != hipSuccess) return false;
+        hipMemset(*p, 0, n ? n : 16);
+        bytes += n;
+        return true;
+    };
+    bool ok = true;
+    for (int i = 0; i < NET_TENSORS && ok; ++i) ok = A((void**)&net.w[i], sizeof(float) * (size_t)net.wsize[i]);
+    ok = ok && A((void**)&net.p, sizeof(float) * mb * rp);
+    ok = ok && A((void**)&net.v, sizeof(float) * mb);
+    ok = ok && A((void**)&net.in_f32, sizeof(float) * mb * 3 * hw);
+    if (net.mode == OMOK_NET_F32) {
+        net.chunk = (int)std::min<size_t>(mb, 1024);
+        const size_t c = net.chunk;
+        ok = ok && A((void**)&net.sx, sizeof(float) * c * hw * NC);
+        ok = ok && A((void**)&net.sh, sizeof(float) * c * hw * NM);
+        ok = ok && A((void**)&net.sd, sizeof(float) * c * hw * NM);
+        ok = ok && A((void**)&net.sg, sizeof(float) * c * hw * NM);
+        ok = ok && A((void**)&net.s0, sizeof(float) * c * NF);
+        ok = ok && A((void**)&net.s1, sizeof(float) * c * NF);
+    } else {
+        const size_t ks0 = hw * 8;
+        ok = ok && A(&net.wt_trunk, TR_WBYTES);
+        ok = ok && A((void**)&net.wt_first, sizeof(float) * (TR_SIDE_FLOATS + 2 * NF + heads_mt(net.hw) * 32));
+        ok = ok && A(&net.wt_fc0, ks0 * 16 * 2 * 1024);
+        ok = ok && A(&net.wt_fc1, (size_t)32 * 16 * 2 * 1024);
+        ok = ok && A(&net.wt_heads, (size_t)32 * heads_mt(net.hw) * 2 * 1024);
+        ok = ok && A(&net.a_fc0, mb * ks0 * 64);
+        ok = ok && A(&net.h0, mb * 32 * 64 * 2);       // h0 and h1 rows (2 KiB each)
+        ok = ok && A((void**)&net.s0, sizeof(float) * mb * heads_mt(net.hw) * 32); // logits
+    }
+    if (!ok) { net_free(net); return 0; }
+    net.bytes = bytes;
+    return bytes;
+}
+
+void net_free(Net& net) {
+    void** ptrs[] = {(void**)&net.p, (void**)&net.v, (void**)&net.in_f32, (void**)&net.sx, (void**)&net.sh, (void**)&net.sd,
+                     (void**)&net.sg, (void**)&net.s0, (void**)&net.s1, &net.wt_trunk, (void**)&net.wt_first, &net.wt_fc0,
+                     &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0};
+    for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
+    for (int i = 0; i < NET_TENSORS; ++i) { if (net.w[i]) hipFree(net.w[i]); net.w[i] = nullptr; }
+}
+
+int net_commit(Net& net, hipStream_t st) {
+    if (net.mode == OMOK_NET_F32) return 0;
+    const int hw = net.hw;
+    std::vector<std::vector<float>> T(NET_TENSORS);
+    for (int i = 0; i < NET_TENSORS; ++i) {
+        T[i].resize((size_t)net.wsize[i]);
+        if (hipMemcpy(T[i].data(), net.w[i], sizeof(float) * T[i].size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    // ---- trunk fragments ----
+    std::vector<_Float16> trunk((size_t)TR_WBYTES / 2, (_Float16)0.0f);
+    std::vector<float> side((size_t)TR_SIDE_FLOATS + 2 * NF + heads_mt(hw) * 32, 0.0f);
+    auto put = [&](int blk, int frag, const std::vector<_Float16>& src, int ksteps, int MT, int part, int ks, int mt) {
+        const size_t s = (((size_t)ks * MT + mt) * 2 + part) * 512;
+        memcpy(&trunk[((size_t)blk * TR_FRAGS_PER_BLOCK + frag) * 512], &src[s], 1024);
+    };
+    for (int b = 0; b < 3; ++b) {
+        const float *w0 = T[2 + 7 * b].data(), *b0 = T[3 + 7 * b].data(), *dw = T[4 + 7 * b].data(), *pw = T[5 + 7 * b].data(),
+                    *b1 = T[6 + 7 * b].data(), *w2 = T[7 + 7 * b].data(), *b2 = T[8 + 7 * b].data();
+        std::vector<_Float16> p0, p1, p2;
+        auto kchain = [](int ks, int h, int j) { return kperm(ks >> 1, ks & 1, h, j); };
+        pack_A(p0, 8, 1, [&](int k, int m) { return w0[k * NM + m]; }, kchain);
+        pack_A(p1, 2, 1, [&](int k, int m) { return pw[k * NM + m]; }, kchain);
+        pack_A(p2, 2, 4, [&](int k, int m) { return w2[k * NC + m]; }, kchain);
+        for (int ks = 0; ks < 8; ++ks) { put(b, 0 + ks, p0, 8, 1, 0, ks, 0); put(b, 8 + ks, p0, 8, 1, 1, ks, 0); }
+        for (int ks = 0; ks < 2; ++ks) { put(b, 16 + ks, p1, 2, 1, 0, ks, 0); put(b, 18 + ks, p1, 2, 1, 1, ks, 0); }
+        for (int m = 0; m < 4; ++m)
+            for (int ks = 0; ks < 2; ++ks) { put(b, 20 + m * 2 + ks, p2, 2, 4, 0, ks, m); put(b, 28 + m * 2 + ks, p2, 2, 4, 1, ks, m); }
+        float* sd = side.data() + b * TR_SIDE_PER_BLOCK;
+        memcpy(sd, dw, sizeof(float) * 9 * NM); // [3][3][32][1] -> [tap][c]
+        memcpy(sd + 9 * NM, b0, sizeof(float) * NM);
+        memcpy(sd + 10 * NM, b1, sizeof(float) * NM);
+        memcpy(sd + 11 * NM, b2, sizeof(float) * NC);
+    }
+    memcpy(side.data() + 3 * TR_SIDE_PER_BLOCK, T[0].data(), sizeof(float) * 3 * NC);
+    memcpy(side.data() + 3 * TR_SIDE_PER_BLOCK + 3 * NC, T[1].data(), sizeof(float) * NC);
+    // biases of fc0, fc1, heads behind the trunk side table
+    float* bias_fc0 = side.data() + TR_SIDE_FLOATS;
+    float* bias_fc1 = bias_fc0 + NF;
+    float* bias_heads = bias_fc1 + NF;
+    memcpy(bias_fc0, T[24].data(), sizeof(float) * NF);
+    memcpy(bias_fc1, T[26].data(), sizeof(float) * NF);
+    memcpy(bias_heads, T[30].data(), sizeof(float) * hw);
+    bias_heads[hw] = T[28][0];
+    // ---- fc0: k-step ks = (px*4 + m)*2 + s, source row = px*128 + kperm(m, s, h, j) ----
+    std::vector<_Float16> pk;
+    {
+        const float* w = T[23].data();
+        pack_A(pk, hw * 8, 16, [&](int k, int m) { return w[(size_t)k * NF + m]; },
+               [](int ks, int h, int j) { return (ks >> 3) * NC + kperm((ks >> 1) & 3, ks & 1, h, j); });
+        if (hipMemcpyAsync(net.wt_fc0, pk.data(), pk.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        hipStreamSynchronize(st);
+    }
+    {
+        const float* w = T[25].data();
+        pack_A(pk, 32, 16, [&](int k, int m) { return w[(size_t)k * NF + m]; },
+               [](int ks, int h, int j) { return kperm(ks >> 1, ks & 1, h, j); });
+        if (hipMemcpyAsync(net.wt_fc1, pk.data(), pk.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        hipStreamSynchronize(st);
+    }
+    {
+        const float *pw = T[29].data(), *vw = T[27].data();
+        const int MT = heads_mt(hw);
+        pack_A(pk, 32, MT, [&](int k, int m) { return m < hw ? pw[(size_t)k * hw + m] : (m == hw ? vw[k] : 0.0f); },
+               [](int ks, int h, int j) { return kperm(ks >> 1, ks & 1, h, j); });
+        if (hipMemcpyAsync(net.wt_heads, pk.data(), pk.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        hipStreamSynchronize(st);
+    }
+    if (hipMemcpyAsync(net.wt_trunk, trunk.data(), TR_WBYTES, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(net.wt_first, side.data(), side.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    hipStreamSynchronize(st);
+    return 0;
+}
+
+template <int N, bool FROM_F32>
+static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st) {
+    using TG = TrunkGeo<N>;
+    static bool attr_done = false;
+    auto kern = k_trunk<N, FROM_F32>;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TG::LDS_BYTES);
+        attr_done = true;
+    }
+    const int grid = max_count < 256 ? max_count : 256;
+    kern<<<grid, TG::TILES * 64, TG::LDS_BYTES, st>>>(S, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, max_count);
+}
+
+template <int MT, int EPI>
+static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_row_u4, const float* bias, void* out_split,
+                        size_t out_row_u4, float* out_logits, const Store& S, int max_count, hipStream_t st) {
+    constexpr int LDS = (MT * 2 + 8) * 1024 * 2;
+    static bool attr_done = false;
+    auto kern = k_gemm_t<MT, EPI>;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_done = true;
+    }
+    const int grid = (max_count + GT_BS - 1) / GT_BS;
+    kern<<<grid, 512, LDS, st>>>((const uint4*)wp, (const uint4*)act, ksteps, act_row_u4, bias, (uint4*)out_split, out_row_u4,
+                                  out_logits, S.d_count, max_count);
+}
+
+static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof) {
+    const int hw = net.hw;
+    const int ks0 = hw * 8;
+    if (prof) prof->begin(PC_TRUNK, st);
+    if (net.n == 9) { if (from_f32) launch_trunk<9, true>(net, S, max_count, st); else launch_trunk<9, false>(net, S, max_count, st); }
+    else { if (from_f32) launch_trunk<15, true>(net, S, max_count, st); else launch_trunk<15, false>(net, S, max_count, st); }
+    if (prof) { prof->end(st); prof->begin(PC_FC0, st); }
+    const float* bias_fc0 = net.wt_first + TR_SIDE_FLOATS;
+    const float* bias_fc1 = bias_fc0 + NF;
+    const float* bias_heads = bias_fc1 + NF;
+    uint4* h0 = (uint4*)net.h0;
+    const size_t mb = ((size_t)net.max_b + GT_BS - 1) / GT_BS * GT_BS;
+    uint4* h1 = h0 + mb * 128; // 32 k-steps * 4 uint4 per row
+    launch_gemm<16, EPI_SPLIT>(net.wt_fc0, net.a_fc0, ks0, (size_t)ks0 * 4, bias_fc0, h0, 128, nullptr, S, max_count, st);
+    if (prof) { prof->end(st); prof->begin(PC_TAIL, st); }
+    launch_gemm<16, EPI_SPLIT>(net.wt_fc1, h0, 32, 128, bias_fc1, h1, 128, nullptr, S, max_count, st);
+    const int MT = heads_mt(hw);
+    if (MT == 8) launch_gemm<8, EPI_LOGITS>(net.wt_heads, h1, 32, 128, bias_heads, nullptr, 0, net.s0, S, max_count, st);
+    else launch_gemm<4, EPI_LOGITS>(net.wt_heads, h1, 32, 128, bias_heads, nullptr, 0, net.s0, S, max_count, st);
+    const int sg = max_count < 4096 ? max_count : 4096;
+    k_softmax<<<sg, 64, 0, st>>>(net.s0, MT * 32, hw, net.rowp, net.p, net.v, S.d_count, max_count);
+    if (prof) prof->end(st);
+}
+
+void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, Prof* prof) {
+    if (max_count <= 0) return;
+    if (max_count > net.max_b) max_count = net.max_b;
+    if (net.mode == OMOK_NET_F32) {
+        launch_encode_requests(net.n, S, net.in_f32, max_count, st);
+        forward_f32(net, S, max_count, st, prof);
+    } else {
+        forward_f16x3(net, S, max_count, false, st, prof);
+    }
+}
+
+void net_forward_inputs(Net& net, const Store& S, int count, hipStream_t st, Prof* prof) {
+    if (count <= 0) return;
+    if (net.mode == OMOK_NET_F32) forward_f32(net, S, count, st, prof);
+    else forward_f16x3(net, S, count, true, st, prof);
+}
+
+} // namespace omok

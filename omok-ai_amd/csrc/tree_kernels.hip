@@ -1,0 +1,1141 @@
+// tree_kernels.hip — board rules, PUCT select / expand / backup, scatter, action sampling and
+// re-rooting as hand-written gfx950 kernels.  ONE WAVEFRONT (64 lanes) OWNS ONE TREE.
+//
+// What each kernel replaces in the reference (AcrylicShrimp/omok-ai):
+//   k_round    alpha-zero/src/parallel_mcts_executor.rs:44-192 (generate_requests: root Dirichlet
+//              noise :48-76, K x { select_leaf mcts/src/node.rs:39-59 with PUCT pme.rs:81-90,
+//              277-286; terminal shortcut :92-97; random untried action :101-125; place_stone
+//              environment/src/lib.rs:104-166; expand node.rs:61-81; propagate node.rs:83-99 })
+//   k_scan     the order-preserving request concat of pme.rs:194-205 (tree order, then sim order)
+//   k_scatter  pme.rs:222-265
+//   k_sample   alpha-zero/src/agent.rs:43-137 + src/trainer.rs:138-173 (transition record)
+//   k_advance  agent.rs:144-232 + mcts/src/lib.rs:47-93 (transition) + trainer.rs:156-201
+//
+// Compiled with -ffp-contract=off: every f32 op below must round exactly like the Rust
+// expression it restates (no FMA contraction), div/sqrt are the correctly rounded forms.
+// Work split inside a wave: lanes sweep rows (cell a = 64*j + lane); scalar bookkeeping is
+// computed uniformly by all lanes and stored by lane 0.  A __syncthreads() (single-wave
+// workgroup: a fence + waitcnt) separates global stores from later cross-lane loads.
+#include "common.h"
+
+namespace omok {
+
+#define LANE ((int)(threadIdx.x & 63))
+
+// ---------------------------------------------------------------------------------------------
+// RNG contract (Philox4x32-10 + fixed-order f64 log/exp): must match DESIGN.md "RNG contract".
+// ---------------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ inline U4 philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__device__ inline double det_log(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((b >> 52) & 0x7ff) - 1023;
+    double m = __longlong_as_double((long long)((b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
+    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double s2 = s * s;
+    double poly = 1.0 / 23.0;
+    poly = poly * s2 + 1.0 / 21.0;
+    poly = poly * s2 + 1.0 / 19.0;
+    poly = poly * s2 + 1.0 / 17.0;
+    poly = poly * s2 + 1.0 / 15.0;
+    poly = poly * s2 + 1.0 / 13.0;
+    poly = poly * s2 + 1.0 / 11.0;
+    poly = poly * s2 + 1.0 / 9.0;
+    poly = poly * s2 + 1.0 / 7.0;
+    poly = poly * s2 + 1.0 / 5.0;
+    poly = poly * s2 + 1.0 / 3.0;
+    poly = poly * s2 + 1.0;
+    const double lm = 2.0 * s * poly;
+    return (double)e * 0.6931471805599453 + lm;
+}
+
+__device__ inline double pow2i(int k) { return __longlong_as_double((long long)(1023 + k) << 52); }
+
+__device__ inline double det_exp(double x) {
+    if (x > 709.0) return __longlong_as_double(0x7ff0000000000000LL);
+    if (x < -745.0) return 0.0;
+    const double t = x * 1.4426950408889634 + 0.5;
+    long long ki = (long long)t;
+    if ((double)ki > t) ki = ki - 1;
+    const double k = (double)ki;
+    const double r = (x - k * 0.6931471803691238) - k * 1.9082149292705877e-10;
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600.0;
+    p = p * r + 1.0 / 39916800.0;
+    p = p * r + 1.0 / 3628800.0;
+    p = p * r + 1.0 / 362880.0;
+    p = p * r + 1.0 / 40320.0;
+    p = p * r + 1.0 / 5040.0;
+    p = p * r + 1.0 / 720.0;
+    p = p * r + 1.0 / 120.0;
+    p = p * r + 1.0 / 24.0;
+    p = p * r + 1.0 / 6.0;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    int kk = (int)ki;
+    if (kk < -1000) {
+        p = p * pow2i(-1000);
+        kk = kk + 1000;
+    }
+    return p * pow2i(kk);
+}
+
+__device__ inline float det_expf(float x) { return (float)det_exp((double)x); }
+__device__ inline double u01(uint32_t x) { return ((double)x + 0.5) * 2.3283064365386963e-10; }
+
+// Gamma(alpha,1) draw of one cell: Ahrens-Dieter GS for the fractional part + unit exponentials.
+__device__ float gamma_draw(float alpha_f, uint64_t seed, uint32_t cell, uint32_t ply, uint32_t tree_global) {
+    const double alpha = (double)alpha_f;
+    int k = (int)alpha;
+    if (k > 32) k = 32;
+    const double f = alpha - (double)k;
+    double x = 0.0;
+    if (f > 0.0) {
+        const double b = 1.0 + f * 0.36787944117144233;
+        double g = 0.0;
+        for (uint32_t attempt = 0; attempt < 200; ++attempt) {
+            const U4 o = philox(seed, cell * 256u + attempt, ply, tree_global, RNG_NOISE);
+            const double u1 = u01(o.x), u2 = u01(o.y);
+            const double p = b * u1;
+            if (p <= 1.0) {
+                const double c = det_exp(det_log(p) / f);
+                if (u2 <= det_exp(-c)) { g = c; break; }
+            } else {
+                const double c = -det_log((b - p) / f);
+                if (u2 <= det_exp((f - 1.0) * det_log(c))) { g = c; break; }
+            }
+        }
+        x = g;
+    }
+    for (int i = 0; i < k; ++i) {
+        const U4 o = philox(seed, cell * 256u + 255u - (uint32_t)i, ply, tree_global, RNG_NOISE);
+        x = x + (-det_log(u01(o.x)));
+    }
+    if (x < 1e-30) x = 0.0;
+    return (float)x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long x = __shfl_xor(v, o, 64);
+        v = x > v ? x : v;
+    }
+    return v;
+}
+__device__ inline uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline uint32_t total_key_biased(float f) { // f32::total_cmp order as an unsigned key
+    int b = __float_as_int(f);
+    b ^= (int)(((unsigned)(b >> 31)) >> 1);
+    return (uint32_t)b ^ 0x80000000u;
+}
+__device__ inline int nth_set_bit(unsigned long long m, int r) {
+    for (int i = 0; i < r; ++i) m &= m - 1;
+    return __ffsll((long long)m) - 1;
+}
+template <int NW>
+__device__ inline int get_bit(const uint64_t* w, int c) {
+    uint64_t word = w[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) word = (c >> 6) == i ? w[i] : word;
+    return (int)((word >> (c & 63)) & 1);
+}
+template <int NW>
+__device__ inline void set_bit(uint64_t* w, int c) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+        if ((c >> 6) == i) w[i] |= 1ULL << (c & 63);
+}
+
+// sequential f32 sum of s[0..n) in ascending order (Rust iter().sum::<f32>()), by every lane
+// redundantly from LDS so the result is wave-uniform without a broadcast
+__device__ inline float seq_sum(const float* s, int n) {
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) acc += s[i];
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-tree view
+// ---------------------------------------------------------------------------------------------
+template <int N>
+struct Tree {
+    using G = Geo<N>;
+    NodeHdr* hdr;
+    uint64_t* board;
+    float* pol;
+    uint32_t* cn;
+    float* cw;
+    uint16_t* cidx;
+    uint8_t* corder;
+    uint16_t* owner;
+    TreeState* ts;
+    uint16_t* req;
+    __device__ Tree(const Store& S, int t) {
+        const size_t tn = (size_t)t * (size_t)S.cap_nodes, tt = (size_t)t * (size_t)S.cap_tables;
+        hdr = S.hdr + tn;
+        board = S.board + tn * (2 * G::NW);
+        pol = S.policy + tn * G::ROWP;
+        cn = S.tcn + tt * G::ROWP;
+        cw = S.tcw + tt * G::ROWP;
+        cidx = S.tcidx + tt * G::ROWP;
+        corder = S.tcorder + tt * G::ROWP;
+        owner = S.towner + tt;
+        ts = S.ts + t;
+        req = S.req_node + (size_t)t * KMAX;
+    }
+};
+
+struct Regs { // wave-uniform running state of a tree
+    uint32_t n_nodes, n_tables, root_n, n_req, error;
+    float root_w;
+    unsigned long long bytes;
+};
+
+// environment/src/lib.rs:104-166 on bitboards, wave-cooperative (all 64 lanes must call).
+// `own` already contains the new stone.  Returns 1 if any of the 4 lines is EXACTLY five.
+template <int N>
+__device__ inline int exactly_five(const uint64_t* own, int a) {
+    constexpr int NW = Geo<N>::NW;
+    const int lane = LANE;
+    const int d = lane / 5, k = lane % 5 + 1;
+    // ray order: (-1,0) (1,0) | (0,-1) (0,1) | (-1,-1) (1,1) | (-1,1) (1,-1)   (lib.rs:112-145)
+    const int dx = (d == 0 || d == 4 || d == 6) ? -1 : ((d == 1 || d == 5 || d == 7) ? 1 : 0);
+    const int dy = (d == 2 || d == 4 || d == 7) ? -1 : ((d == 3 || d == 5 || d == 6) ? 1 : 0);
+    bool hit = false;
+    if (lane < 40) {
+        const int x = a % N + dx * k, y = a / N + dy * k;
+        if (x >= 0 && x < N && y >= 0 && y < N) hit = get_bit<NW>(own, y * N + x) != 0;
+    }
+    const unsigned long long m = __ballot(hit);
+    int run[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t f = (uint32_t)(m >> (5 * i)) & 31u;
+        run[i] = __ffs((int)(~f & 63u)) - 1; // consecutive hits from k=1 (lib.rs:179-190)
+    }
+    return (1 + run[0] + run[1] == 5) | (1 + run[2] + run[3] == 5) | (1 + run[4] + run[5] == 5) |
+           (1 + run[6] + run[7] == 5);
+}
+
+
+// clone + place_stone on bitboards (static register indexing only).  bb = black NW | white NW.
+template <int N>
+__device__ inline int place_and_status(uint64_t* bb, int turn, int legal_before, int action) {
+    constexpr int NW = Geo<N>::NW;
+    uint64_t mine[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) mine[i] = turn == 0 ? bb[i] : bb[NW + i];
+    set_bit<NW>(mine, action);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        bb[i] = turn == 0 ? mine[i] : bb[i];
+        bb[NW + i] = turn == 0 ? bb[NW + i] : mine[i];
+    }
+    const int five = exactly_five<N>(mine, action);
+    return five ? (turn == 0 ? ST_BLACK_WIN : ST_WHITE_WIN) : (legal_before == 1 ? ST_DRAW : ST_IN_PROGRESS);
+}
+
+// mcts/src/node.rs:83-99.  All lanes walk the path (uniform loads); lane 0 stores.
+template <int N>
+__device__ inline void backup(const Tree<N>& T, Regs& R, int x, float v) {
+    constexpr int ROWP = Geo<N>::ROWP;
+    const int lane = LANE;
+    while (x != 0) {
+        const NodeHdr h = T.hdr[x];
+        const size_t slot = (size_t)T.hdr[h.parent].table * ROWP + h.action;
+        const uint32_t n = T.cn[slot] + 1u;
+        const float w = T.cw[slot] + v;
+        if (lane == 0) { T.cn[slot] = n; T.cw[slot] = w; }
+        v = -v;
+        x = h.parent;
+        R.bytes += 16;
+    }
+    R.root_n += 1u;
+    R.root_w += v;
+    R.bytes += 16;
+}
+
+// Adds a child under `parent` (hp = its header as currently stored).  Returns the node index,
+// or -1 on arena overflow.  Board words `bb` (black NW, white NW) are the child's board.
+template <int N>
+__device__ inline int add_child(const Store& S, const Tree<N>& T, Regs& R, int parent, const NodeHdr& hp, int action,
+                                const uint64_t* bb, int status, int turn, int has_policy) {
+    using G = Geo<N>;
+    const int lane = LANE;
+    if (R.n_nodes >= (uint32_t)S.cap_nodes) { R.error |= 1u; return -1; }
+    int tab = hp.table;
+    if (tab == NONE16) {
+        if (R.n_tables >= (uint32_t)S.cap_tables) { R.error |= 1u; return -1; }
+        tab = (int)R.n_tables++;
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) T.corder[(size_t)tab * G::ROWP + j * 64 + lane] = NONE8;
+        if (lane == 0) { T.owner[tab] = (uint16_t)parent; T.hdr[parent].table = (uint16_t)tab; }
+        __syncthreads(); // corder row init must land before the slot store below
+    }
+    const int idx = (int)R.n_nodes++;
+    if (lane == 0) {
+        const size_t slot = (size_t)tab * G::ROWP + action;
+        T.corder[slot] = (uint8_t)hp.nch;
+        T.cidx[slot] = (uint16_t)idx;
+        T.cn[slot] = 0u;
+        T.cw[slot] = 0.0f;
+        T.hdr[parent].nch = (uint16_t)(hp.nch + 1);
+        NodeHdr c;
+        c.parent = (uint16_t)parent;
+        c.table = NONE16;
+        c.legal = (uint16_t)(hp.legal - 1);
+        c.nch = 0;
+        c.action = (uint8_t)action;
+        c.status = (uint8_t)status;
+        c.turn = (uint8_t)turn;
+        c.has_policy = (uint8_t)has_policy;
+        c.pad = 0;
+        T.hdr[idx] = c;
+    }
+    if (lane < 2 * G::NW) {
+        uint64_t w = bb[0];
+#pragma unroll
+        for (int i = 1; i < 2 * G::NW; ++i) w = lane == i ? bb[i] : w;
+        T.board[(size_t)idx * (2 * G::NW) + lane] = w;
+    }
+    R.bytes += 24 + 8 * 2 * G::NW;
+    return idx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_round: Dirichlet noise (round 0) + K simulations for one tree
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ void apply_noise(const Tree<N>& T, const RoundArgs& A, uint32_t tree_global, float* s_row) {
+    using G = Geo<N>;
+    const int lane = LANE;
+    NodeHdr h0 = T.hdr[0];
+    uint64_t bb[2 * G::NW];
+#pragma unroll
+    for (int i = 0; i < 2 * G::NW; ++i) bb[i] = T.board[i];
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        s_row[a] = a < G::HW ? gamma_draw(A.alpha, A.seed, (uint32_t)a, (uint32_t)A.ply, tree_global) : 0.0f;
+    }
+    __syncthreads();
+    const float total = seq_sum(s_row, G::HW);
+    __syncthreads();
+    const bool ok = total > 0.0f;
+    const float inv = ok ? __fdiv_rn(1.0f, total) : 0.0f;
+    const float ph = h0.legal ? __fdiv_rn(1.0f, (float)h0.legal) : 0.0f;
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        float m = 0.0f;
+        if (a < G::HW) {
+            const float noise = ok ? s_row[a] * inv : __fdiv_rn(1.0f, (float)G::HW);
+            const bool empty = !(((bb[j] | bb[G::NW + j]) >> lane) & 1ULL);
+            const float p = h0.has_policy ? T.pol[a] : (empty ? ph : 0.0f);
+            m = (1.0f - A.epsilon) * p + A.epsilon * noise; // pme.rs:59
+        }
+        s_row[a] = m;
+    }
+    __syncthreads();
+    const float sum = seq_sum(s_row, G::HW);
+    const float sum_inv = __fdiv_rn(1.0f, sum); // pme.rs:63-68 (no epsilon guard)
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        T.pol[a] = a < G::HW ? s_row[a] * sum_inv : 0.0f;
+    }
+    if (lane == 0 && !h0.has_policy) T.hdr[0].has_policy = 1;
+    __syncthreads();
+}
+
+template <int N>
+__device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, const RoundArgs& A, uint32_t sim_index,
+                        uint32_t tree_global) {
+    using G = Geo<N>;
+    constexpr int ROWP = G::ROWP, NW = G::NW;
+    const int lane = LANE;
+    int node = 0;
+    uint32_t node_n = R.root_n;
+    NodeHdr h = T.hdr[0];
+    // ---- select_leaf (node.rs:43-58) with the PUCT selector (pme.rs:81-90) ----
+    while (h.nch == h.legal && h.nch != 0) {
+        const uint32_t pn = node_n > 1u ? node_n : 1u;
+        const float sq = __fsqrt_rn((float)pn);
+        const size_t tb = (size_t)h.table * ROWP;
+        const float ph = __fdiv_rn(1.0f, (float)h.legal); // placeholder prior of a not-yet-evaluated node
+        unsigned long long best = 0ULL;
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const int a = j * 64 + lane;
+            const uint8_t ord = T.corder[tb + a];
+            if (ord != NONE8) {
+                const uint32_t n = T.cn[tb + a];
+                const float w = T.cw[tb + a];
+                const float p = h.has_policy ? T.pol[(size_t)node * ROWP + a] : ph;
+                const float q = __fdiv_rn(w, (float)n + F32_EPS);
+                const float bias = __fdiv_rn(sq, (float)(1u + n));
+                const float score = q + (1.0f * p) * bias;
+                const unsigned long long v = ((unsigned long long)total_key_biased(score) << 32) |
+                                             ((unsigned long long)ord << 16) | (unsigned long long)a;
+                best = v > best ? v : best; // last max in insertion order wins ties (max_by)
+            }
+        }
+        best = wave_max_u64(best);
+        const int a_best = (int)(best & 0xFFFFu);
+        R.bytes += 12ull * h.nch;
+        node_n = T.cn[tb + a_best];
+        node = (int)T.cidx[tb + a_best];
+        h = T.hdr[node];
+    }
+    // ---- terminal leaf (pme.rs:92-97) ----
+    if (h.status != ST_IN_PROGRESS) {
+        backup<N>(T, R, node, h.status >= ST_BLACK_WIN ? 1.0f : 0.0f);
+        __syncthreads();
+        return;
+    }
+    // ---- random untried legal action (pme.rs:101-125) ----
+    uint64_t bb[2 * NW];
+#pragma unroll
+    for (int i = 0; i < 2 * NW; ++i) bb[i] = T.board[(size_t)node * (2 * NW) + i];
+    unsigned long long cand[G::IT];
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        bool c = a < G::HW && !(((bb[j] | bb[NW + j]) >> lane) & 1ULL);
+        if (c && h.table != NONE16) c = T.corder[(size_t)h.table * ROWP + a] == NONE8;
+        cand[j] = __ballot(c);
+        total += __popcll(cand[j]);
+    }
+    R.bytes += 2 * (G::HW / 8);
+    if (total == 0) return; // "There's no action for now": the simulation is consumed
+    const U4 o = philox(A.seed, sim_index, (uint32_t)A.ply, tree_global, RNG_EXPAND);
+    int r = (int)__umulhi(o.x, (uint32_t)total);
+    int action = 0;
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int c = __popcll(cand[j]);
+        if (!found) {
+            if (r < c) { action = j * 64 + nth_set_bit(cand[j], r); found = true; }
+            else r -= c;
+        }
+    }
+    // ---- place the stone on a copy of the leaf's board (pme.rs:128-135) ----
+    const int status = place_and_status<N>(bb, h.turn, h.legal, action);
+    // ---- expand (node.rs:61-81); the placeholder policy of pme.rs:140-156 is implicit ----
+    const int child = add_child<N>(S, T, R, node, h, action, bb, status, 1 - h.turn, 0);
+    if (child < 0) return;
+    __syncthreads();
+    if (status != ST_IN_PROGRESS) { // pme.rs:177-181
+        backup<N>(T, R, child, status == ST_DRAW ? 0.0f : 1.0f);
+    } else {
+        if (lane == 0) T.req[R.n_req] = (uint16_t)child;
+        R.n_req += 1u;
+        R.bytes += 4 + (G::HW + 2);
+    }
+    __syncthreads();
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_round(Store S, RoundArgs A) {
+    using G = Geo<N>;
+    __shared__ float s_row[G::ROWP];
+    const int g = blockIdx.x;
+    if (!S.gs[g].alive) return;
+    const int t = A.side * S.games + g;
+    const Tree<N> T(S, t);
+    const TreeState ts = *T.ts;
+    Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
+    const uint32_t tree_global = (uint32_t)((A.game_offset + g) * 2 + A.side);
+    if (A.round == 0) apply_noise<N>(T, A, tree_global, s_row);
+    for (int i = 0; i < A.K; ++i) run_sim<N>(S, T, R, A, (uint32_t)(A.round * A.K + i), tree_global);
+    if (LANE == 0) {
+        TreeState o = ts;
+        o.n_nodes = R.n_nodes; o.n_tables = R.n_tables; o.root_n = R.root_n; o.root_w = R.root_w;
+        o.error = R.error; o.n_req = R.n_req;
+        *T.ts = o;
+        atomicAdd(S.d_bytes, R.bytes);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scan: dense, order-preserving request list over the live trees of one side
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan(Store S, int side) {
+    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < S.games; base += 1024) {
+        const int g = base + tid;
+        uint32_t cnt = 0;
+        int t = 0;
+        if (g < S.games && S.gs[g].alive) { t = side * S.games + g; cnt = S.ts[t].n_req; }
+        s_part[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+            const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+            __syncthreads();
+            s_part[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t excl = s_part[tid] - cnt + s_carry;
+        if (cnt) {
+            S.ts[t].req_base = excl;
+            const uint16_t* rq = S.req_node + (size_t)t * KMAX;
+            for (uint32_t r = 0; r < cnt; ++r) {
+                S.req_ref[excl + r] = ((uint32_t)t << 16) | rq[r];
+                S.req_aux[excl + r] = 0xFFFFFFFFu;
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) S.d_count[0] = (int32_t)s_carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_scatter (pme.rs:222-265): requests of a tree applied in simulation order
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(64) void k_scatter(Store S, int side, const float* __restrict__ P, const float* __restrict__ V) {
+    using G = Geo<N>;
+    constexpr int ROWP = G::ROWP, NW = G::NW;
+    __shared__ float s_row[ROWP];
+    const int g = blockIdx.x;
+    if (!S.gs[g].alive) return;
+    const int t = side * S.games + g;
+    const Tree<N> T(S, t);
+    const TreeState ts = *T.ts;
+    if (ts.n_req == 0) return;
+    const int lane = LANE;
+    Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
+    for (uint32_t r = 0; r < ts.n_req; ++r) {
+        const int node = T.req[r];
+        const size_t d = (size_t)ts.req_base + r;
+        uint64_t occ[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) occ[i] = T.board[(size_t)node * (2 * NW) + i] | T.board[(size_t)node * (2 * NW) + NW + i];
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const int a = j * 64 + lane;
+            const bool empty = a < G::HW && !((occ[j] >> lane) & 1ULL);
+            s_row[a] = empty ? P[d * ROWP + a] : 0.0f; // pme.rs:235-239
+        }
+        __syncthreads();
+        const float sum = seq_sum(s_row, G::HW);
+        const bool renorm = F32_EPS <= sum;
+        const float inv = renorm ? __fdiv_rn(1.0f, sum) : 1.0f;
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const int a = j * 64 + lane;
+            const float x = s_row[a];
+            T.pol[(size_t)node * ROWP + a] = renorm ? x * inv : x;
+        }
+        if (lane == 0) T.hdr[node].has_policy = 1;
+        backup<N>(T, R, node, -V[d]); // pme.rs:229,264
+        __syncthreads();
+        R.bytes += 8ull * G::HW + 4;
+    }
+    if (lane == 0) {
+        TreeState o = ts;
+        o.root_n = R.root_n; o.root_w = R.root_w; o.n_req = 0;
+        *T.ts = o;
+        atomicAdd(S.d_bytes, R.bytes);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_reset: Agent::new (agent.rs:16-35) for both trees of every game
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(64) void k_reset(Store S, const float* __restrict__ root_policy) {
+    using G = Geo<N>;
+    const int t = blockIdx.x;
+    const int lane = LANE;
+    const Tree<N> T(S, t);
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        T.pol[a] = a < G::HW ? root_policy[a] : 0.0f;
+    }
+    if (lane < 2 * G::NW) T.board[lane] = 0ULL;
+    if (lane == 0) {
+        NodeHdr h;
+        h.parent = NONE16; h.table = NONE16; h.legal = (uint16_t)G::HW; h.nch = 0;
+        h.action = NONE8; h.status = ST_IN_PROGRESS; h.turn = 0; h.has_policy = 1; h.pad = 0;
+        T.hdr[0] = h;
+        TreeState s{1u, 0u, 0u, 0.0f, 0u, 0u, 0u, 0u};
+        *T.ts = s;
+        if (t < S.games) {
+            GameState gs{1, ST_IN_PROGRESS, 0, 0, 0, -1, -1};
+            S.gs[t] = gs;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sample: Agent::compute_policy + sample_action (agent.rs:43-137), transition record
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(64) void k_sample(Store S, int side, int ply, float temperature, int threshold,
+                                               uint64_t seed, int64_t game_offset, int32_t* __restrict__ actions) {
+    using G = Geo<N>;
+    constexpr int ROWP = G::ROWP, NW = G::NW;
+    __shared__ float s_row[ROWP];
+    __shared__ int s_action;
+    const int g = blockIdx.x;
+    const int lane = LANE;
+    if (!S.gs[g].alive) {
+        if (lane == 0) { actions[g] = -1; S.gs[g].last_action = -1; }
+        return;
+    }
+    const int t = side * S.games + g;
+    const Tree<N> T(S, t);
+    const NodeHdr h0 = T.hdr[0];
+    if (h0.table == NONE16 || h0.nch == 0) {
+        if (lane == 0) { actions[g] = -1; S.gs[g].last_action = -1; T.ts->error |= 4u; }
+        return;
+    }
+    const size_t tb = (size_t)h0.table * ROWP;
+    uint32_t nv[G::IT];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        nv[j] = T.corder[tb + a] != NONE8 ? T.cn[tb + a] : 0u;
+        tot += nv[j];
+    }
+    tot = wave_sum_u32(tot); // visit counts are integers < 2^24: the f32 sum of agent.rs:58-63 is exact
+    const float sum = (float)tot;
+    if (sum < F32_EPS) {
+        if (lane == 0) { actions[g] = -1; S.gs[g].last_action = -1; T.ts->error |= 4u; }
+        return;
+    }
+    const float sum_inv = __fdiv_rn(1.0f, sum);
+    float pi[G::IT];
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) pi[j] = (float)nv[j] * sum_inv;
+    int action;
+    const int plies = S.gs[g].plies;
+    if (plies < threshold) { // Boltzmann (agent.rs:106-133)
+        const float tinv = __fdiv_rn(1.0f, temperature);
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const int a = j * 64 + lane;
+            s_row[a] = (a < G::HW && !(pi[j] < F32_EPS)) ? det_expf(pi[j] * tinv) : 0.0f;
+        }
+        __syncthreads();
+        const float hsum = seq_sum(s_row, G::HW);
+        const float hinv = __fdiv_rn(1.0f, hsum);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) s_row[j * 64 + lane] *= hinv;
+        __syncthreads();
+        if (lane == 0) {
+            const float total = seq_sum(s_row, G::HW);
+            const U4 o = philox(seed, 0u, (uint32_t)ply, (uint32_t)((game_offset + g) * 2 + side), RNG_SAMPLE);
+            const float u = (float)(o.x >> 8) * 5.9604644775390625e-8f;
+            const float target = u * total;
+            float cum = 0.0f;
+            int chosen = -1, last_nz = 0;
+            for (int a = 0; a < G::HW; ++a) {
+                const float x = s_row[a];
+                if (!(x > 0.0f)) continue;
+                last_nz = a;
+                cum += x;
+                if (chosen < 0 && cum > target) chosen = a;
+            }
+            s_action = chosen < 0 ? last_nz : chosen;
+        }
+        __syncthreads();
+        action = s_action;
+    } else { // Best: last max by total_cmp over all cells (agent.rs:98-105)
+        unsigned long long best = 0ULL;
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const int a = j * 64 + lane;
+            if (a < G::HW) {
+                const unsigned long long v = ((unsigned long long)total_key_biased(pi[j]) << 32) | (unsigned long long)a;
+                best = v > best ? v : best;
+            }
+        }
+        best = wave_max_u64(best);
+        action = (int)(best & 0xFFFFFFFFu);
+    }
+    // transition record (trainer.rs:150-173): env before the move, unheated pi; z is set by k_advance
+    const size_t rec = (size_t)g * G::HW + (size_t)plies;
+    if (plies < G::HW) {
+        if (lane < 2 * NW) S.rp_board[rec * (2 * NW) + lane] = T.board[lane];
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) S.rp_pi[rec * ROWP + j * 64 + lane] = pi[j];
+        if (lane == 0) { S.rp_turn[rec] = h0.turn; S.rp_z[rec] = 0.0f; }
+    }
+    if (lane == 0) { actions[g] = action; S.gs[g].last_action = action; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_mirror_scan: NN requests of ensure_action_exists (agent.rs:153-158) for every live game
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_mirror_scan(Store S, int side) {
+    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < S.games; base += 1024) {
+        const int g = base + tid;
+        const uint32_t cnt = (g < S.games && S.gs[g].alive && S.gs[g].last_action >= 0) ? 1u : 0u;
+        s_part[tid] = cnt;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+            __syncthreads();
+            s_part[tid] += v;
+            __syncthreads();
+        }
+        if (g < S.games) {
+            if (cnt) {
+                const uint32_t d = s_part[tid] - 1u + s_carry;
+                const int topp = (1 - side) * S.games + g; // the opponent's tree still has the pre-move root
+                S.req_ref[d] = (uint32_t)topp << 16;
+                S.req_aux[d] = (uint32_t)S.gs[g].last_action | (1u << 16); // add the stone, Opponent mode
+                S.gs[g].mirror_idx = (int32_t)d;
+            } else {
+                S.gs[g].mirror_idx = -1;
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) S.d_count[0] = (int32_t)s_carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transition (mcts/src/lib.rs:47-78): keep the chosen child's subtree by stable compaction
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ int transition(const Store& S, const Tree<N>& T, int action, uint8_t* s_alive, uint16_t* s_nmap,
+                          uint16_t* s_tmap) {
+    using G = Geo<N>;
+    constexpr int ROWP = G::ROWP, NW = G::NW;
+    const int lane = LANE;
+    const TreeState ts = *T.ts;
+    const NodeHdr h0 = T.hdr[0];
+    if (h0.table == NONE16) return -1;
+    const size_t tb0 = (size_t)h0.table * ROWP;
+    if (T.corder[tb0 + action] == NONE8) return -1;
+    const int c = T.cidx[tb0 + action];
+    const float new_w = T.cw[tb0 + action];
+    const NodeHdr hc = T.hdr[c];
+    uint32_t new_n = 0; // lib.rs:65-71
+    if (hc.table != NONE16) {
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const size_t s = (size_t)hc.table * ROWP + j * 64 + lane;
+            new_n += T.corder[s] != NONE8 ? T.cn[s] : 0u;
+        }
+        new_n = wave_sum_u32(new_n);
+    }
+    const int nn = (int)ts.n_nodes, nt = (int)ts.n_tables;
+    // 1. mark the subtree (parent index < child index, so one ascending pass resolves it)
+    for (int i = lane; i < nn; i += 64) s_alive[i] = i == c ? 1 : (i < c ? 0 : 2);
+    __syncthreads();
+    for (int base = c + 1; base < nn; base += 64) {
+        const int i = base + lane;
+        const int par = i < nn ? (int)T.hdr[i].parent : 0;
+        bool pending = i < nn;
+        while (__any(pending)) {
+            if (pending) {
+                const uint8_t v = s_alive[par];
+                if (v != 2) { s_alive[i] = v; pending = false; }
+            }
+            __syncthreads();
+        }
+    }
+    // 2. stable renumbering
+    int cnt = 0;
+    for (int base = 0; base < nn; base += 64) {
+        const int i = base + lane;
+        const bool a = i < nn && s_alive[i] == 1;
+        const unsigned long long m = __ballot(a);
+        if (i < nn) s_nmap[i] = a ? (uint16_t)(cnt + __popcll(m & ((1ULL << lane) - 1ULL))) : NONE16;
+        cnt += __popcll(m);
+    }
+    const int new_nodes = cnt;
+    __syncthreads();
+    cnt = 0;
+    for (int base = 0; base < nt; base += 64) {
+        const int k = base + lane;
+        const bool a = k < nt && s_alive[T.owner[k]] == 1;
+        const unsigned long long m = __ballot(a);
+        if (k < nt) s_tmap[k] = a ? (uint16_t)(cnt + __popcll(m & ((1ULL << lane) - 1ULL))) : NONE16;
+        cnt += __popcll(m);
+    }
+    const int new_tables = cnt;
+    __syncthreads();
+    // 3. move nodes, ascending (dst <= src, so an unread survivor is never overwritten)
+    for (int base = 0; base < nn; base += 64) {
+        const int i = base + lane;
+        const bool a = i < nn && s_alive[i] == 1;
+        NodeHdr h{};
+        uint64_t bw[2 * NW];
+        int dst = 0;
+        if (a) {
+            h = T.hdr[i];
+            dst = s_nmap[i];
+#pragma unroll
+            for (int q = 0; q < 2 * NW; ++q) bw[q] = T.board[(size_t)i * (2 * NW) + q];
+            h.parent = i == c ? NONE16 : s_nmap[h.parent];
+            if (h.table != NONE16) h.table = s_tmap[h.table];
+        }
+        __syncthreads();
+        if (a) {
+            T.hdr[dst] = h;
+#pragma unroll
+            for (int q = 0; q < 2 * NW; ++q) T.board[(size_t)dst * (2 * NW) + q] = bw[q];
+        }
+        unsigned long long m = __ballot(a && h.has_policy && dst != i);
+        while (m) { // policy rows, one node at a time, whole wave copies
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int src = base + l, d = s_nmap[src];
+            float v[G::IT];
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) v[j] = T.pol[(size_t)src * ROWP + j * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) T.pol[(size_t)d * ROWP + j * 64 + lane] = v[j];
+        }
+        __syncthreads();
+    }
+    // 4. move tables, ascending
+    for (int k = 0; k < nt; ++k) {
+        const int d = s_tmap[k];
+        if (d == NONE16) continue;
+        uint32_t vn[G::IT];
+        float vw[G::IT];
+        uint16_t vi[G::IT];
+        uint8_t vo[G::IT];
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const size_t s = (size_t)k * ROWP + j * 64 + lane;
+            vn[j] = T.cn[s]; vw[j] = T.cw[s]; vi[j] = T.cidx[s]; vo[j] = T.corder[s];
+        }
+        const uint16_t own = s_nmap[T.owner[k]];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const size_t s = (size_t)d * ROWP + j * 64 + lane;
+            T.cn[s] = vn[j]; T.cw[s] = vw[j]; T.corder[s] = vo[j];
+            T.cidx[s] = vo[j] != NONE8 ? s_nmap[vi[j]] : (uint16_t)0;
+        }
+        if (lane == 0) T.owner[d] = own;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        TreeState o = ts;
+        o.n_nodes = (uint32_t)new_nodes; o.n_tables = (uint32_t)new_tables; o.root_n = new_n; o.root_w = new_w;
+        *T.ts = o;
+    }
+    __syncthreads();
+    return 0;
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_advance(Store S, int side, const float* __restrict__ P) {
+    using G = Geo<N>;
+    constexpr int ROWP = G::ROWP, NW = G::NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* s_row = (float*)smem;
+    uint16_t* s_nmap = (uint16_t*)(smem + ROWP * 4);
+    uint16_t* s_tmap = s_nmap + S.cap_nodes;
+    uint8_t* s_alive = (uint8_t*)(s_tmap + S.cap_tables);
+    const int g = blockIdx.x;
+    const int lane = LANE;
+    const GameState gs = S.gs[g];
+    if (!gs.alive || gs.last_action < 0) return;
+    const int action = gs.last_action;
+    const Tree<N> own(S, side * S.games + g);
+    const Tree<N> opp(S, (1 - side) * S.games + g);
+    // ---- opposite_agent.ensure_action_exists (agent.rs:144-197) on the pre-move root ----
+    {
+        const NodeHdr h0 = opp.hdr[0];
+        uint64_t bb[2 * NW];
+#pragma unroll
+        for (int i = 0; i < 2 * NW; ++i) bb[i] = opp.board[i];
+        const size_t d = (size_t)gs.mirror_idx;
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const int a = j * 64 + lane;
+            const bool empty = a < G::HW && !(((bb[j] | bb[NW + j]) >> lane) & 1ULL);
+            s_row[a] = (empty && a != action) ? P[d * ROWP + a] : 0.0f; // agent.rs:166-171
+        }
+        __syncthreads();
+        const float sum = seq_sum(s_row, G::HW);
+        const bool renorm = F32_EPS <= sum;
+        const float inv = renorm ? __fdiv_rn(1.0f, sum) : 1.0f;
+        const bool exists = h0.table != NONE16 && opp.corder[(size_t)h0.table * ROWP + action] != NONE8;
+        if (!exists) { // node.rs:69-71 returns None when the child is already there
+            const TreeState ts = *opp.ts;
+            Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
+            if (!get_bit<NW>(bb, action) && !get_bit<NW>(bb + NW, action)) (void)place_and_status<N>(bb, h0.turn, h0.legal, action);
+            const int idx = add_child<N>(S, opp, R, 0, h0, action, bb, ST_IN_PROGRESS, 1 - h0.turn, 1);
+            if (idx >= 0) {
+#pragma unroll
+                for (int j = 0; j < G::IT; ++j) {
+                    const int a = j * 64 + lane;
+                    const float x = s_row[a];
+                    opp.pol[(size_t)idx * ROWP + a] = renorm ? x * inv : x;
+                }
+            }
+            if (lane == 0) {
+                TreeState o = ts;
+                o.n_nodes = R.n_nodes; o.n_tables = R.n_tables; o.error = R.error;
+                *opp.ts = o;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- agent.play_action (agent.rs:206-232): status from the real rules on the root board ----
+    int status;
+    {
+        const NodeHdr h0 = own.hdr[0];
+        uint64_t bb[2 * NW];
+#pragma unroll
+        for (int i = 0; i < 2 * NW; ++i) bb[i] = own.board[i];
+        status = place_and_status<N>(bb, h0.turn, h0.legal, action);
+    }
+    int err = 0;
+    if (transition<N>(S, own, action, s_alive, s_nmap, s_tmap) != 0) err |= 16;
+    if (transition<N>(S, opp, action, s_alive, s_nmap, s_tmap) != 0) err |= 32;
+    if (lane == 0) {
+        if (err) own.ts->error |= (uint32_t)err;
+        GameState o = gs;
+        if (gs.plies < G::HW)
+            S.rp_z[(size_t)g * G::HW + gs.plies] = (status == ST_BLACK_WIN || status == ST_WHITE_WIN) ? 1.0f : 0.0f;
+        o.plies = gs.plies + 1;
+        o.status = (uint8_t)status;
+        o.alive = status == ST_IN_PROGRESS ? 1 : 0;
+        o.last_action = -1;
+        o.mirror_idx = -1;
+        S.gs[g] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// request -> f32 NN input (encoder.rs:10-46), used by the step-wise test API
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ inline void load_request_board(const Store& S, uint32_t ref, uint32_t aux, uint64_t* bb, int& turn, int& mode) {
+    constexpr int NW = Geo<N>::NW;
+    const int t = (int)(ref >> 16), node = (int)(ref & 0xFFFFu);
+    const size_t tn = (size_t)t * (size_t)S.cap_nodes + (size_t)node;
+    const NodeHdr h = S.hdr[tn];
+#pragma unroll
+    for (int i = 0; i < 2 * NW; ++i) bb[i] = S.board[tn * (2 * NW) + i];
+    turn = h.turn;
+    mode = 0;
+    if (aux != 0xFFFFFFFFu) { // env.clone() + place_stone(action) (agent.rs:154-155)
+        const int action = (int)(aux & 0xFFFFu);
+        mode = (int)(aux >> 16) & 1;
+        if (!get_bit<NW>(bb, action) && !get_bit<NW>(bb + NW, action)) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const uint64_t bit = (action >> 6) == i ? (1ULL << (action & 63)) : 0ULL;
+                bb[i] |= turn == 0 ? bit : 0ULL;
+                bb[NW + i] |= turn == 0 ? 0ULL : bit;
+            }
+            turn = 1 - turn;
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_encode_requests(Store S, float* __restrict__ out, int max_b) {
+    using G = Geo<N>;
+    constexpr int NW = G::NW;
+    const int b = blockIdx.x;
+    if (b >= S.d_count[0] || b >= max_b) return;
+    uint64_t bb[2 * NW];
+    int turn, mode;
+    load_request_board<N>(S, S.req_ref[b], S.req_aux[b], bb, turn, mode);
+    const int persp = mode == 0 ? turn : 1 - turn; // encoder.rs:24-27
+    uint64_t mine[NW], theirs[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        mine[i] = persp == 0 ? bb[i] : bb[NW + i];
+        theirs[i] = persp == 0 ? bb[NW + i] : bb[i];
+    }
+    for (int m = threadIdx.x; m < 3 * G::HW; m += blockDim.x) {
+        float v;
+        if (m < 2 * G::HW) {
+            const int cell = m >> 1;
+            v = (m & 1) ? (float)get_bit<NW>(theirs, cell) : (float)get_bit<NW>(mine, cell);
+        } else {
+            v = turn == 0 ? 1.0f : 0.0f; // encoder.rs:34-37
+        }
+        out[(size_t)b * 3 * G::HW + m] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// environment crate on device, batched (environment/src/lib.rs:73-166; encoder.rs:10-46)
+// ---------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(64) void k_env_play(const int32_t* __restrict__ moves, int len, int32_t* __restrict__ status_out,
+                                                 uint8_t* __restrict__ boards, uint8_t* __restrict__ turns, uint16_t* __restrict__ legal) {
+    using G = Geo<N>;
+    constexpr int NW = G::NW;
+    const int b = blockIdx.x;
+    const int lane = LANE;
+    uint64_t bb[2 * NW];
+#pragma unroll
+    for (int i = 0; i < 2 * NW; ++i) bb[i] = 0ULL;
+    int turn = 0, lg = G::HW;
+    for (int i = 0; i < len; ++i) {
+        const int a = moves[(size_t)b * len + i];
+        int st = -1;
+        if (a >= 0 && a < G::HW && !get_bit<NW>(bb, a) && !get_bit<NW>(bb + NW, a)) {
+            st = place_and_status<N>(bb, turn, lg, a);
+            lg -= 1;
+            turn = 1 - turn;
+        }
+        if (lane == 0) status_out[(size_t)b * len + i] = st;
+    }
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        if (a < G::HW) boards[(size_t)b * G::HW + a] = (uint8_t)(((bb[j] >> lane) & 1ULL) ? 1 : (((bb[NW + j] >> lane) & 1ULL) ? 2 : 0));
+    }
+    if (lane == 0) { turns[b] = (uint8_t)turn; legal[b] = (uint16_t)lg; }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_encode_boards(const uint8_t* __restrict__ boards, const uint8_t* __restrict__ turns,
+                                                       int mode, float* __restrict__ out) {
+    using G = Geo<N>;
+    const int b = blockIdx.x;
+    const int turn = turns[b];
+    const int persp = mode == 0 ? turn : 1 - turn;
+    const int mine = persp == 0 ? 1 : 2;
+    for (int m = threadIdx.x; m < 3 * G::HW; m += blockDim.x) {
+        float v;
+        if (m < 2 * G::HW) {
+            const int s = boards[(size_t)b * G::HW + (m >> 1)];
+            v = s == 0 ? 0.0f : (((m & 1) == 0) == (s == mine) ? 1.0f : 0.0f);
+        } else {
+            v = turn == 0 ? 1.0f : 0.0f;
+        }
+        out[(size_t)b * 3 * G::HW + m] = v;
+    }
+}
+
+// replay tuples packed for an RCCL gather: board u8[HW], turn u8, pad to 4, pi f32[HW], z f32
+template <int N>
+__global__ __launch_bounds__(64) void k_replay_pack(Store S, uint8_t* __restrict__ dst, long long cap, long long* __restrict__ d_total) {
+    using G = Geo<N>;
+    constexpr int NW = G::NW, ROWP = G::ROWP;
+    constexpr int BRD = (G::HW + 1 + 3) / 4 * 4, REC = BRD + 4 * G::HW + 4;
+    const int g = blockIdx.x;
+    const int lane = LANE;
+    const int plies = S.gs[g].plies < G::HW ? S.gs[g].plies : G::HW;
+    long long base = 0;
+    if (lane == 0) base = (long long)atomicAdd((unsigned long long*)d_total, (unsigned long long)plies);
+    base = __shfl(base, 0, 64);
+    for (int p = 0; p < plies; ++p) {
+        if (base + p >= cap) break;
+        uint8_t* r = dst + (size_t)(base + p) * REC;
+        const size_t rec = (size_t)g * G::HW + p;
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const int a = j * 64 + lane;
+            if (a < G::HW) {
+                const uint64_t bw = S.rp_board[rec * (2 * NW) + j], ww = S.rp_board[rec * (2 * NW) + NW + j];
+                r[a] = (uint8_t)(((bw >> lane) & 1ULL) ? 1 : (((ww >> lane) & 1ULL) ? 2 : 0));
+                ((float*)(r + BRD))[a] = S.rp_pi[rec * ROWP + a];
+            }
+        }
+        if (lane == 0) {
+            r[G::HW] = S.rp_turn[rec];
+            ((float*)(r + BRD))[G::HW] = S.rp_z[rec];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+#define DISPATCH_N(n, CALL9, CALL15) \
+    do { if ((n) == 9) { CALL9; } else { CALL15; } } while (0)
+
+size_t advance_lds_bytes(int cap_nodes, int cap_tables) {
+    return 256 * 4 + (size_t)cap_nodes * 2 + (size_t)cap_tables * 2 + (size_t)cap_nodes + 16;
+}
+
+void launch_reset(int n, const Store& S, const float* rp, hipStream_t st) {
+    DISPATCH_N(n, (k_reset<9><<<2 * S.games, 64, 0, st>>>(S, rp)), (k_reset<15><<<2 * S.games, 64, 0, st>>>(S, rp)));
+}
+void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st) {
+    DISPATCH_N(n, (k_round<9><<<S.games, 64, 0, st>>>(S, a)), (k_round<15><<<S.games, 64, 0, st>>>(S, a)));
+}
+void launch_scan(int n, const Store& S, int side, hipStream_t st) { k_scan<<<1, 1024, 0, st>>>(S, side); }
+void launch_scatter(int n, const Store& S, int side, const float* p, const float* v, hipStream_t st) {
+    DISPATCH_N(n, (k_scatter<9><<<S.games, 64, 0, st>>>(S, side, p, v)), (k_scatter<15><<<S.games, 64, 0, st>>>(S, side, p, v)));
+}
+void launch_sample(int n, const Store& S, int side, int ply, float temperature, int threshold, uint64_t seed,
+                   int64_t game_offset, int32_t* actions, hipStream_t st) {
+    DISPATCH_N(n, (k_sample<9><<<S.games, 64, 0, st>>>(S, side, ply, temperature, threshold, seed, game_offset, actions)),
+               (k_sample<15><<<S.games, 64, 0, st>>>(S, side, ply, temperature, threshold, seed, game_offset, actions)));
+}
+void launch_mirror_scan(int n, const Store& S, int side, hipStream_t st) { k_mirror_scan<<<1, 1024, 0, st>>>(S, side); }
+void launch_advance(int n, const Store& S, int side, const float* p, hipStream_t st) {
+    const size_t lds = advance_lds_bytes(S.cap_nodes, S.cap_tables);
+    DISPATCH_N(n, (k_advance<9><<<S.games, 64, lds, st>>>(S, side, p)), (k_advance<15><<<S.games, 64, lds, st>>>(S, side, p)));
+}
+void launch_encode_requests(int n, const Store& S, float* out, int max_b, hipStream_t st) {
+    if (max_b <= 0) return;
+    DISPATCH_N(n, (k_encode_requests<9><<<max_b, 256, 0, st>>>(S, out, max_b)), (k_encode_requests<15><<<max_b, 256, 0, st>>>(S, out, max_b)));
+}
+void launch_env_play(int n, const int32_t* moves, int batch, int len, int32_t* status, uint8_t* boards, uint8_t* turns,
+                     uint16_t* legal, hipStream_t st) {
+    DISPATCH_N(n, (k_env_play<9><<<batch, 64, 0, st>>>(moves, len, status, boards, turns, legal)),
+               (k_env_play<15><<<batch, 64, 0, st>>>(moves, len, status, boards, turns, legal)));
+}
+void launch_encode_boards(int n, const uint8_t* boards, const uint8_t* turns, int batch, int mode, float* out, hipStream_t st) {
+    DISPATCH_N(n, (k_encode_boards<9><<<batch, 256, 0, st>>>(boards, turns, mode, out)),
+               (k_encode_boards<15><<<batch, 256, 0, st>>>(boards, turns, mode, out)));
+}
+void launch_replay_pack(int n, const Store& S, uint8_t* dst, long long cap, long long* d_total, hipStream_t st) {
+    DISPATCH_N(n, (k_replay_pack<9><<<S.games, 64, 0, st>>>(S, dst, cap, d_total)),
+               (k_replay_pack<15><<<S.games, 64, 0, st>>>(S, dst, cap, d_total)));
+}
+
+} // namespace omok

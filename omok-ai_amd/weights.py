@@ -6,7 +6,7 @@ network-utils/src/lib.rs:76-93: N(0,1) * scale with He = 2/sqrt(fan_in), Xavier 
 2/sqrt(fan_in+fan_out); conv fan_in = kh*kw*cin (lib.rs:131-134); the depthwise kernel uses
 He(kh*kw*cin) (lib.rs:192-195), the pointwise kernel He(cin) (lib.rs:223); biases are 0.
 The reference draws from TF's unseeded RandomStandardNormal; this build draws from numpy's
-seeded Generator so that CPU oracle and GPU engine load identical tensors.
+seeded Generator so that every consumer of a (board size, seed) pair loads identical tensors.
 """
 import numpy as np
 

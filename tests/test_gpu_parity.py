@@ -1,0 +1,261 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI.
+
+ - rules: the reference's 8 environment tests (environment/src/lib.rs:201-426) on the device kernel
+ - net: evaluate_pv vs the oracle's fp32 restatement, tolerance 1e-3 (BASELINE.json north_star)
+ - tree search: bit-exact canonical tree dumps, request boards, sampled moves and replay tuples vs
+   the oracle, with the GPU net's (p, v) fed to both sides so the comparison isolates the tree
+   arithmetic (select / expand / backup / noise / sampling / re-rooting)
+"""
+import os
+
+import numpy as np
+import pytest
+
+import omok_ai_amd as oa
+from omok_ai_amd import binding as B
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-3  # north_star: policy/value within 1e-3 of the reference CPU path
+
+
+@pytest.fixture(scope="module", params=[9, 15])
+def eng_env(request):
+    e = oa.Engine(board_size=request.param, games=1, max_nodes=64, max_tables=32, max_batch_k=1)
+    yield e
+    e.close()
+
+
+# ---- environment crate known answers ----------------------------------------------------------
+def test_place_stone(eng_env):  # lib.rs:201-252
+    env = oa.Environment(eng_env)
+    assert env.turn == oa.api.TURN_BLACK
+    for i in range(12):
+        assert env.place_stone(i) == oa.api.IN_PROGRESS
+        assert env.board[i] == (oa.api.BLACK if i % 2 == 0 else oa.api.WHITE)
+        assert env.turn == (oa.api.TURN_WHITE if i % 2 == 0 else oa.api.TURN_BLACK)
+    assert env.place_stone(3) is None
+    assert env.legal_move_count == eng_env.hw - 12
+
+
+def test_game_endings(eng_env):  # lib.rs:255-372
+    n = eng_env.n
+    horiz = [x + r * n for x in range(4) for r in (0, 1)] + [4]
+    vert = [c + y * n for y in range(4) for c in (0, 2)] + [4 * n]
+    fill = list(range(n * 4))
+    moves = np.full((4, n * 4 + 1), -1, dtype=np.int32)
+    moves[0, :9], moves[1, :9] = horiz, vert
+    moves[2, :] = fill + [n * 4 + 4]
+    moves[3, :] = fill + [n * 4]
+    st, boards, turns, legal = eng_env.env_play(moves)
+    assert list(st[0, :9]) == [0] * 8 + [oa.api.BLACK_WIN]
+    assert list(st[1, :9]) == [0] * 8 + [oa.api.BLACK_WIN]
+    assert st[2, -1] == oa.api.BLACK_WIN and st[3, -1] == oa.api.BLACK_WIN
+    assert np.all(st[0, 9:] == -1)  # index -1 is rejected like Option::None
+
+
+def test_rules_match_oracle_on_random_games(eng_env):
+    n, hw = eng_env.n, eng_env.hw
+    rng = np.random.default_rng(5)
+    moves = np.stack([rng.permutation(hw) for _ in range(64)]).astype(np.int32)
+    moves[:, 7] = moves[:, 3]  # an occupied cell -> None
+    st, boards, turns, legal = eng_env.env_play(moves)
+    for b in range(moves.shape[0]):
+        env = O.Environment(n)
+        for i, m in enumerate(moves[b]):
+            s = env.place_stone(int(m))
+            assert (s if s is not None else -1) == st[b, i], (b, i)
+        assert np.array_equal(env.board, boards[b]) and env.turn == turns[b] and env.legal_move_count == legal[b]
+
+
+def test_encodings(eng_env):  # lib.rs:375-426 + encoder.rs:10-46
+    n, hw = eng_env.n, eng_env.hw
+    env = oa.Environment(eng_env)
+    for i in (0, 10, 2, 30):
+        env.place_stone(i)
+    exp = np.zeros(2 * hw, dtype=np.float32)
+    exp[[0, 10 * 2 + 1, 2 * 2, 30 * 2 + 1]] = 1.0
+    assert np.array_equal(env.encode_board(oa.api.TURN_BLACK), exp)
+    exp = np.zeros(2 * hw, dtype=np.float32)
+    exp[[1, 10 * 2, 2 * 2 + 1, 30 * 2]] = 1.0
+    assert np.array_equal(env.encode_board(oa.api.TURN_WHITE), exp)
+    oenv = O.Environment(n)
+    for i in (0, 10, 2):
+        oenv.place_stone(i)
+    for mode in (0, 1):
+        got = eng_env.encode_nn_input(oenv.board[None], np.array([oenv.turn], dtype=np.uint8), mode).reshape(-1)
+        assert np.array_equal(got, oenv.encode_nn_input(mode))
+
+
+# ---- net ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [9, 15])
+@pytest.mark.parametrize("mode", [B.NET_F16X3, B.NET_F32])
+def test_net_parity(n, mode):
+    g = np.load(os.path.join(GOLD, f"net_n{n}.npz"))
+    tensors = oa.weights.init_random(n, seed=int(g["seed"]))
+    eng = oa.Engine(board_size=n, games=8, max_nodes=16, max_tables=8, max_batch_k=16, net_mode=mode)
+    eng.load_weights(tensors)
+    rng = np.random.default_rng(3)
+    extra = []
+    for _ in range(150):  # more positions than the fixture, incl. a batch that is not a multiple of the tile
+        env = O.Environment(n)
+        for c in rng.permutation(n * n)[: int(rng.integers(0, n * n - 1))]:
+            env.place_stone(int(c))
+        extra.append(env.encode_nn_input(int(rng.integers(0, 2))))
+    inputs = np.concatenate([g["inputs"], np.stack(extra)])
+    p, v = eng.evaluate_pv(inputs)
+    p, v = p.reshape(len(inputs), -1), v.reshape(-1)
+    k = len(g["inputs"])
+    assert np.abs(p[:k] - g["p"]).max() < TOL and np.abs(v[:k] - g["v"]).max() < TOL  # vs torch float64 fixture
+    pc, vc = O.Net(n, tensors).forward(inputs, threads=8)
+    dp, dv = np.abs(p - pc).max(), np.abs(v - vc).max()
+    print(f"n={n} mode={mode}: max|dp|={dp:.3e} max|dv|={dv:.3e}")
+    assert dp < TOL and dv < TOL
+    if mode == B.NET_F16X3:
+        assert dp < 2e-4 and dv < 2e-4, "split-fp16 should be ~1e-5; a larger error means lost lo terms"
+    assert np.allclose(p.sum(axis=1), 1.0, atol=1e-4)
+    eng.close()
+
+
+# ---- self-play: tree arithmetic bit-exact ---------------------------------------------------------
+def _compare_trees(sp, osp, games, tag):
+    for g in range(games):
+        for side in (0, 1):
+            gi, gf = sp.tree_dump(g, side)
+            oi, of = osp.tree_dump(g, side)
+            assert gi.shape == oi.shape, f"{tag}: game {g} side {side}: {gi.shape[0]} vs {oi.shape[0]} nodes"
+            assert np.array_equal(gi, oi), f"{tag}: node records differ (game {g} side {side})"
+            assert np.array_equal(gf.view(np.uint32), of.view(np.uint32)), f"{tag}: w/policy bits differ (game {g} side {side})"
+            assert sp.tree_root(g, side)[0] == osp.tree_root(g, side)[0]
+            assert np.float32(sp.tree_root(g, side)[1]).tobytes() == np.float32(osp.tree_root(g, side)[1]).tobytes()
+
+
+@pytest.mark.parametrize("n,games,count,k,max_plies,mode", [
+    (9, 6, 48, 8, 0, B.NET_F16X3),     # whole games to the end on the reference's board size
+    (9, 3, 40, 16, 12, B.NET_F32),     # count not a multiple of K (rounds up), fp32 net path
+    (15, 3, 64, 16, 6, B.NET_F16X3),   # the benchmark board
+])
+def test_selfplay_bit_exact_vs_oracle(n, games, count, k, max_plies, mode):
+    tensors = oa.weights.init_random(n, seed=0)
+    eng = oa.Engine(board_size=n, games=games, max_nodes=2048, max_tables=1024, max_batch_k=k, seed=7, game_offset=5,
+                    net_mode=mode)
+    eng.load_weights(tensors)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    root_p = eng.evaluate_p(O.Environment(n).encode_nn_input(0)[None]).reshape(-1)
+    osp = O.SelfPlay(n, games, cap_nodes=2048, cap_tables=1024, seed=7, game_offset=5)
+    osp.reset(root_p)
+    _compare_trees(sp, osp, games, "reset")
+    threshold = 6
+    ply = 0
+    while osp.alive_count > 0 and (max_plies == 0 or ply < max_plies):
+        for rnd in range((count + k - 1) // k):
+            nreq = sp.round_generate(rnd, k, 0.25, 0.03)
+            oin = osp.round_generate(rnd, k, 0.25, 0.03)
+            assert nreq == len(oin), f"ply {ply} round {rnd}: request count"
+            assert np.array_equal(sp.round_inputs(), oin), f"ply {ply} round {rnd}: request boards"
+            if rnd == 0:
+                _compare_trees(sp, osp, games, f"ply {ply} after noise+round0")
+            p, v = sp.round_eval()
+            sp.round_scatter()
+            osp.round_scatter(p, v)
+        _compare_trees(sp, osp, games, f"ply {ply} after execute")
+        a = sp.sample_actions(1.0, threshold)
+        assert np.array_equal(a, osp.sample(1.0, threshold)), f"ply {ply}: actions"
+        nm = sp.mirror_generate()
+        om = osp.mirror_generate()
+        assert nm == len(om) and np.array_equal(sp.mirror_inputs(), om)
+        pm = sp.mirror_eval()
+        sp.mirror_apply()
+        osp.advance(pm)
+        _compare_trees(sp, osp, games, f"ply {ply} after advance")
+        alive, status, plies = sp.game_info()
+        assert [int(x) for x in alive] == [osp.game_alive(g) for g in range(games)]
+        assert [int(x) for x in status] == [osp.game_status(g) for g in range(games)]
+        ply += 1
+    assert sp.alive_count == osp.alive_count
+    for g in range(games):
+        gb, gt, gp, gz = sp.replay(g)
+        ob, ot, op, oz = osp.replay(g)
+        assert np.array_equal(gb, ob) and np.array_equal(gt, ot) and np.array_equal(gz, oz)
+        assert np.array_equal(gp.view(np.uint32), op.view(np.uint32))
+    eng.close()
+
+
+def test_execute_matches_stepwise_and_is_deterministic():
+    """omok_execute (all rounds enqueued without host round trips) == the step-wise path."""
+    n, games, count, k = 9, 5, 32, 8
+    tensors = oa.weights.init_random(n, seed=0)
+    dumps = []
+    for variant in ("execute", "stepwise", "execute"):
+        eng = oa.Engine(board_size=n, games=games, max_nodes=1024, max_tables=512, max_batch_k=k, seed=3)
+        eng.load_weights(tensors)
+        sp = oa.SelfPlay(eng)
+        sp.reset()
+        for _ in range(3):
+            if variant == "execute":
+                sp.execute(count, k)
+                sp.sample_actions(1.0, 2)
+                sp.advance()
+            else:
+                for rnd in range(count // k):
+                    sp.round_generate(rnd, k)
+                    sp.round_eval()
+                    sp.round_scatter()
+                sp.sample_actions(1.0, 2)
+                sp.mirror_generate()
+                sp.mirror_eval()
+                sp.mirror_apply()
+        dumps.append([sp.tree_dump(g, s) for g in range(games) for s in (0, 1)])
+        eng.close()
+    for a, b in ((0, 1), (0, 2)):
+        for (ai, af), (bi, bf) in zip(dumps[a], dumps[b]):
+            assert np.array_equal(ai, bi) and np.array_equal(af.view(np.uint32), bf.view(np.uint32))
+
+
+def test_selfplay_run_whole_episode_properties():
+    """Size-independent properties of a full episode through omok_selfplay_run."""
+    n, games, count, k = 9, 64, 32, 16
+    eng = oa.Engine(board_size=n, games=games, max_nodes=1024, max_tables=512, max_batch_k=k, seed=1)
+    eng.load_random_weights(0)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    st = sp.run(count, k)
+    assert sp.alive_count == 0 and st["finished"] == games
+    alive, status, plies = sp.game_info()
+    assert np.all(alive == 0) and np.all(status != 0)
+    assert st["ply_games"] == plies.sum()
+    assert st["sims"] == plies.sum() * count
+    for g in range(0, games, 7):
+        boards, turns, pi, z = sp.replay(g)
+        assert len(boards) == plies[g]
+        assert np.all((boards != 0).sum(axis=1) == np.arange(len(boards)))
+        assert np.allclose(pi.sum(axis=1), 1.0, atol=1e-5)
+        assert np.all(z[:-1] == 0) and z[-1] == (1.0 if status[g] >= 2 else 0.0)
+        # the recorded game replays to the recorded status under the rules kernel
+        moves = []
+        for i in range(len(boards) - 1):
+            moves.append(int(np.flatnonzero(boards[i + 1] != boards[i])[0]))
+        s, _, _, _ = eng.env_play(np.array([moves], dtype=np.int32))
+        assert np.all(s == 0)
+    eng.close()
+
+
+def test_error_paths():
+    eng = oa.Engine(board_size=9, games=2, max_nodes=8, max_tables=4, max_batch_k=8)
+    sp = oa.SelfPlay(eng)
+    with pytest.raises(B.OmokError):  # net not loaded
+        sp.reset()
+    eng.load_random_weights(0)
+    with pytest.raises(B.OmokError):  # reset not called
+        sp.execute(8, 8)
+    sp.reset()
+    with pytest.raises(B.OmokError):  # batch_size above max_batch_k
+        sp.execute(8, 16)
+    with pytest.raises(B.OmokError) as ei:  # arena of 8 nodes overflows
+        sp.execute(64, 8)
+    assert ei.value.code == -4
+    eng.close()
+    with pytest.raises(B.OmokError):
+        oa.Engine(board_size=10, games=1)
