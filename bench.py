@@ -101,7 +101,7 @@ def main():
     from omok_ai_amd import binding as B
 
     n, games, k = args.board, args.games, args.batch_k
-    max_nodes = args.max_nodes or min(16384, 2 * args.sims + 512)
+    max_nodes = args.max_nodes or min(16384, 8 * args.sims + 1792)
     max_tables = args.max_tables or max(256, max_nodes // 2)
     eng = oa.Engine(board_size=n, games=games, max_nodes=max_nodes, max_tables=max_tables, max_batch_k=k,
                     device=local_rank, net_mode=B.NET_F16X3 if args.net_mode == "f16x3" else B.NET_F32,
@@ -193,6 +193,7 @@ def main():
                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": (st["tree_bytes"] / round_s / 1e9 / HBM_PEAK_GBS) if round_s > 0 else 0.0, "traffic": None},
         "rank0_kernel_ms": {kk: st[kk] for kk in ("ms_round", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply")},
+        "arena": {"max_nodes": max_nodes, "max_tables": max_tables, "peak_nodes": st["peak_nodes"], "peak_tables": st["peak_tables"]},
     }
     if args.cpu_seconds > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, max(mean_plies, 1.0))

@@ -156,6 +156,8 @@ int32_t omok_replay_record_bytes(const omok_engine* e);
 #define OMOK_STAT_TREE_BYTES 11 /* kernel-counted algorithmic bytes of the round kernels */
 #define OMOK_STAT_ROUND_LAUNCHES 12
 #define OMOK_STAT_MS_ROUND 13   /* HIP-event ms in the round (select/expand/backup) kernel only */
+#define OMOK_STAT_PEAK_NODES 14  /* largest node / table arena use seen so far */
+#define OMOK_STAT_PEAK_TABLES 15
 #define OMOK_STAT_COUNT 16
 int omok_get_stats(omok_engine* e, double* stats /* [OMOK_STAT_COUNT] */);
 int omok_reset_stats(omok_engine* e);

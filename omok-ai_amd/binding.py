@@ -13,7 +13,7 @@ OK = 0
 NET_F16X3, NET_F32 = 0, 1
 MODE_PLAYER, MODE_OPPONENT = 0, 1
 STAT_NAMES = ["sims", "evals", "ply_games", "finished", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply",
-              "fc0_launches", "fc0_rows", "tree_bytes", "round_launches", "ms_round", "_14", "_15"]
+              "fc0_launches", "fc0_rows", "tree_bytes", "round_launches", "ms_round", "peak_nodes", "peak_tables"]
 
 # every symbol include/omok_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

@@ -90,6 +90,7 @@ struct omok_engine {
     long long* d_pack_total = nullptr;
     // host-side stats
     double sims = 0, evals = 0, ply_games = 0, finished = 0;
+    uint32_t peak_nodes = 0, peak_tables = 0;
     size_t bytes = 0;
 };
 
@@ -125,18 +126,23 @@ static int dalloc(omok_engine* e, Tp** p, size_t count) {
 
 // tiny helper kernels --------------------------------------------------------------------------
 __global__ void k_count_alive(Store S, uint32_t* d_error, unsigned long long* d_evals) {
-    __shared__ uint32_t s_cnt, s_err;
-    if (threadIdx.x == 0) { s_cnt = 0; s_err = 0; }
+    __shared__ uint32_t s_cnt, s_err, s_mn, s_mt;
+    if (threadIdx.x == 0) { s_cnt = 0; s_err = 0; s_mn = 0; s_mt = 0; }
     __syncthreads();
-    uint32_t c = 0, er = 0;
+    uint32_t c = 0, er = 0, mn = 0, mt = 0;
     for (int g = threadIdx.x; g < S.games; g += blockDim.x) {
         c += S.gs[g].alive ? 1u : 0u;
-        er |= S.ts[g].error | S.ts[S.games + g].error;
+        const TreeState a = S.ts[g], b = S.ts[S.games + g];
+        er |= a.error | b.error;
+        mn = max(mn, max(a.n_nodes, b.n_nodes));
+        mt = max(mt, max(a.n_tables, b.n_tables));
     }
     atomicAdd(&s_cnt, c);
     atomicOr(&s_err, er);
+    atomicMax(&s_mn, mn);
+    atomicMax(&s_mt, mt);
     __syncthreads();
-    if (threadIdx.x == 0) { d_error[0] = s_err; d_error[1] = s_cnt; }
+    if (threadIdx.x == 0) { d_error[0] = s_err; d_error[1] = s_cnt; d_error[2] = s_mn; d_error[3] = s_mt; }
 }
 __global__ void k_add_evals(const int32_t* d_count, unsigned long long* d_evals) {
     if (threadIdx.x == 0 && blockIdx.x == 0) d_evals[0] += (unsigned long long)d_count[0];
@@ -370,16 +376,18 @@ extern "C" int omok_encode_nn_input(omok_engine* e, const uint8_t* boards, const
 // ---- self-play ---------------------------------------------------------------------------------
 static int read_status(omok_engine* e, uint32_t* err_bits, uint32_t* alive) {
     k_count_alive<<<1, 1024, 0, e->st>>>(e->S, e->d_error, e->d_evals);
-    uint32_t h[2] = {0, 0};
-    HIPCHK(e, hipMemcpyAsync(h, e->d_error, 8, hipMemcpyDeviceToHost, e->st));
+    uint32_t h[4] = {0, 0, 0, 0};
+    HIPCHK(e, hipMemcpyAsync(h, e->d_error, 16, hipMemcpyDeviceToHost, e->st));
     if (sync_and_check(e, "status readback")) return OMOK_ERR_HIP;
     if (err_bits) *err_bits = h[0];
     if (alive) *alive = h[1];
+    if (h[2] > e->peak_nodes) e->peak_nodes = h[2];
+    if (h[3] > e->peak_tables) e->peak_tables = h[3];
     return 0;
 }
 
 static int tree_error(omok_engine* e, uint32_t bits) {
-    if (bits & 1u) return fail(e, OMOK_ERR_OVERFLOW, "a tree arena overflowed (max_nodes=%d, max_tables=%d): raise them", e->cfg.max_nodes, e->cfg.max_tables);
+    if (bits & 1u) return fail(e, OMOK_ERR_OVERFLOW, "a tree arena overflowed (max_nodes=%d, max_tables=%d; peak use %u nodes, %u tables): raise them", e->cfg.max_nodes, e->cfg.max_tables, e->peak_nodes, e->peak_tables);
     if (bits & 4u) return fail(e, OMOK_ERR_ILLEGAL, "sample_action on a tree with no visited children (run execute first)");
     if (bits) return fail(e, OMOK_ERR_ILLEGAL, "illegal tree operation (error bits 0x%x)", bits);
     return 0;
@@ -817,6 +825,8 @@ extern "C" int omok_get_stats(omok_engine* e, double* stats) {
     stats[OMOK_STAT_TREE_BYTES] = (double)by;
     stats[OMOK_STAT_ROUND_LAUNCHES] = (double)e->prof.launches[PC_ROUND];
     stats[OMOK_STAT_MS_ROUND] = e->prof.ms[PC_ROUND];
+    stats[OMOK_STAT_PEAK_NODES] = (double)e->peak_nodes;
+    stats[OMOK_STAT_PEAK_TABLES] = (double)e->peak_tables;
     return OMOK_OK;
 }
 
@@ -826,6 +836,7 @@ extern "C" int omok_reset_stats(omok_engine* e) {
     e->prof.resolve();
     for (int i = 0; i < PC_COUNT; ++i) { e->prof.ms[i] = 0; e->prof.launches[i] = 0; }
     e->sims = e->evals = e->ply_games = e->finished = 0;
+    e->peak_nodes = e->peak_tables = 0;
     hipMemset(e->d_evals, 0, 16);
     hipMemset(e->S.d_bytes, 0, 16);
     return OMOK_OK;

@@ -370,8 +370,9 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
 // 8 waves: wm = wave>>1 owns MT/4 m-tiles, ws = wave&1 owns 2 of the 4 sample tiles.
 enum { EPI_SPLIT = 0, EPI_LOGITS = 1 };
 constexpr int GT_BS = 128;
+constexpr int GT_STAGES = 3;
 
-template <int MT, int EPI>
+template <int MT, int EPI, int TAG>
 __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksteps,
                                                 size_t act_row_u4, const float* __restrict__ bias, uint4* __restrict__ out_split,
                                                 size_t out_row_u4, float* __restrict__ out_logits, const int32_t* __restrict__ d_count,
@@ -379,28 +380,29 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
     constexpr int MTW = MT / 4;
     constexpr int WFR = MT * 2;            // weight fragments per k-step
     constexpr int NFR = WFR + 8;           // + 4 sample tiles x (hi, lo)
-    constexpr int LPW = (NFR + 7) / 8;     // staging loads per wave per k-step
+    constexpr int LPW = NFR / 8;           // LDS-DMA instructions per wave per k-step (NFR is a multiple of 8)
     constexpr int STAGE_U4 = NFR * 64;
+    constexpr int NST = GT_STAGES;         // ring slots; two k-steps stay in flight behind the one being read
+    static_assert(NFR % 8 == 0, "fragment count must split evenly over 8 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* lds = (uint4*)smem;
     int count = d_count[0];
     if (count > max_count) count = max_count;
     const int b0 = blockIdx.x * GT_BS;
     if (b0 >= count) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, ws = wave & 1;
     const int h = lane >> 5;
 
-    // staging plan: fragment f = wave + 8*i ; f < WFR: weights (linear copy), else activation fragment
+    // staging plan: this wave owns fragments f = wave + 8*i of every k-step.
+    // f < WFR: weight fragment (1 KiB, linear);  else activation fragment (sample tile ct, part hi/lo):
+    // lane (c = lane&31, h) fetches the 16-byte piece [ks][part*2 + h] of sample row b0 + 32*ct + c.
     const uint4* src[LPW];
     size_t step_u4[LPW];
-    int dst[LPW];
-    bool on[LPW];
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
         const int f = wave + 8 * i;
-        on[i] = f < NFR;
-        dst[i] = f * 64 + lane;
         if (f < WFR) {
             src[i] = wp + (size_t)f * 64 + lane;
             step_u4[i] = (size_t)WFR * 64;
@@ -411,6 +413,15 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
             step_u4[i] = 4;
         }
     }
+    auto issue = [&](int slot) { // LDS-DMA of the next k-step into ring slot `slot`; advances the sources
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                             (__attribute__((address_space(3))) void*)(lds + slot * STAGE_U4 + (wave + 8 * i) * 64),
+                                             16, 0, 0);
+            src[i] += step_u4[i];
+        }
+    };
     f32x16 acc[MTW][2];
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
@@ -419,23 +430,17 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
 
-    uint4 stage[LPW];
-#pragma unroll
-    for (int i = 0; i < LPW; ++i)
-        if (on[i]) stage[i] = *src[i];
-#pragma unroll
-    for (int i = 0; i < LPW; ++i)
-        if (on[i]) lds[dst[i]] = stage[i];
-    __syncthreads();
-
+    issue(0);
+    if (ksteps > 1) issue(1);
+    int slot = 0, nslot = 2;
     for (int t = 0; t < ksteps; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < ksteps) {
-#pragma unroll
-            for (int i = 0; i < LPW; ++i)
-                if (on[i]) stage[i] = *(src[i] + (size_t)(t + 1) * step_u4[i]);
-        }
-        const half8* L = (const half8*)(lds + cur * STAGE_U4);
+        // retire k-step t (this wave's share), then make every wave's share visible
+        if (t + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < ksteps) issue(nslot); // slot (t+2)%NST was last read at k-step t-1: safe behind the barrier
+        const half8* L = (const half8*)(lds + slot * STAGE_U4);
         half8 bh[2], bl[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -449,13 +454,8 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
 #pragma unroll
             for (int c = 0; c < 2; ++c) MFMA3(ah, al, bh[c], bl[c], acc[i][c]);
         }
-        if (t + 1 < ksteps) {
-            uint4* Ln = lds + (cur ^ 1) * STAGE_U4;
-#pragma unroll
-            for (int i = 0; i < LPW; ++i)
-                if (on[i]) Ln[dst[i]] = stage[i];
-        }
-        __syncthreads();
+        slot = slot + 1 == NST ? 0 : slot + 1;
+        nslot = nslot + 1 == NST ? 0 : nslot + 1;
     }
 
     // ---- epilogue ----
@@ -679,12 +679,12 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
     kern<<<grid, TG::TILES * 64, TG::LDS_BYTES, st>>>(S, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, max_count);
 }
 
-template <int MT, int EPI>
+template <int MT, int EPI, int TAG>
 static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_row_u4, const float* bias, void* out_split,
                         size_t out_row_u4, float* out_logits, const Store& S, int max_count, hipStream_t st) {
-    constexpr int LDS = (MT * 2 + 8) * 1024 * 2;
+    constexpr int LDS = (MT * 2 + 8) * 1024 * GT_STAGES;
     static bool attr_done = false;
-    auto kern = k_gemm_t<MT, EPI>;
+    auto kern = k_gemm_t<MT, EPI, TAG>;
     if (!attr_done) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;
@@ -707,12 +707,12 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     uint4* h0 = (uint4*)net.h0;
     const size_t mb = ((size_t)net.max_b + GT_BS - 1) / GT_BS * GT_BS;
     uint4* h1 = h0 + mb * 128; // 32 k-steps * 4 uint4 per row
-    launch_gemm<16, EPI_SPLIT>(net.wt_fc0, net.a_fc0, ks0, (size_t)ks0 * 4, bias_fc0, h0, 128, nullptr, S, max_count, st);
+    launch_gemm<16, EPI_SPLIT, 0>(net.wt_fc0, net.a_fc0, ks0, (size_t)ks0 * 4, bias_fc0, h0, 128, nullptr, S, max_count, st);
     if (prof) { prof->end(st); prof->begin(PC_TAIL, st); }
-    launch_gemm<16, EPI_SPLIT>(net.wt_fc1, h0, 32, 128, bias_fc1, h1, 128, nullptr, S, max_count, st);
+    launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, bias_fc1, h1, 128, nullptr, S, max_count, st);
     const int MT = heads_mt(hw);
-    if (MT == 8) launch_gemm<8, EPI_LOGITS>(net.wt_heads, h1, 32, 128, bias_heads, nullptr, 0, net.s0, S, max_count, st);
-    else launch_gemm<4, EPI_LOGITS>(net.wt_heads, h1, 32, 128, bias_heads, nullptr, 0, net.s0, S, max_count, st);
+    if (MT == 8) launch_gemm<8, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, bias_heads, nullptr, 0, net.s0, S, max_count, st);
+    else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, bias_heads, nullptr, 0, net.s0, S, max_count, st);
     const int sg = max_count < 4096 ? max_count : 4096;
     k_softmax<<<sg, 64, 0, st>>>(net.s0, MT * 32, hw, net.rowp, net.p, net.v, S.d_count, max_count);
     if (prof) prof->end(st);
