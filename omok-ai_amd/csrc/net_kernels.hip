@@ -34,15 +34,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline int kperm(int T, int s, int h, int j) { return 32 * T + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
-__device__ inline float lrelu(float x) { return fmaxf(x, 0.2f * x); } // LeakyRelu alpha 0.2 (TF default)
+// LeakyRelu alpha 0.2 (TF default) = max(x, 0.2x).  One v_mul + one v_max: fmaxf() would add a
+// canonicalising v_max per operand under IEEE mode.
+__device__ inline float lrelu(float x) {
+    const float y = 0.2f * x;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 
+typedef __fp16 half2r __attribute__((ext_vector_type(2)));
+// x = hi + lo with hi = x truncated to 11 significant bits (exactly an f16 in the normal range)
+// and lo = f16(x - hi): 3 VALU per value (and, sub, half a packed convert each for hi and lo).
 __device__ inline void split8(const float* v, half8& hi, half8& lo) {
+    union { uint32_t u[4]; half8 h; } H, L;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const _Float16 h = (_Float16)v[j];
-        hi[j] = h;
-        lo[j] = (_Float16)(v[j] - (float)h);
+    for (int j = 0; j < 4; ++j) {
+        const float a = v[2 * j], b = v[2 * j + 1];
+        const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u);
+        const float bh = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
+        const half2r ph = __builtin_amdgcn_cvt_pkrtz(ah, bh);
+        const half2r pl = __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh);
+        H.u[j] = *(const uint32_t*)&ph;
+        L.u[j] = *(const uint32_t*)&pl;
     }
+    hi = H.h;
+    lo = L.h;
 }
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define MFMA3(ah, al, bh, bl, c)   \
@@ -302,6 +319,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
 #pragma unroll
                     for (int i = 0; i < 4; ++i) d[4 * g + i] += hv[i] * wv[i];
                 }
+                asm volatile("" ::: "memory"); // keep at most one tap's loads in flight (register pressure)
             }
             // L1: pointwise 32 -> 32 + bias + lrelu
             f32x16 accg;
