@@ -101,8 +101,8 @@ def main():
     from omok_ai_amd import binding as B
 
     n, games, k = args.board, args.games, args.batch_k
-    max_nodes = args.max_nodes or min(16384, 8 * args.sims + 1792)
-    max_tables = args.max_tables or max(256, max_nodes // 2)
+    max_nodes = args.max_nodes or min(16384, 4 * args.sims + 1024)
+    max_tables = args.max_tables or max(256, max_nodes // 4)
     eng = oa.Engine(board_size=n, games=games, max_nodes=max_nodes, max_tables=max_tables, max_batch_k=k,
                     device=local_rank, net_mode=B.NET_F16X3 if args.net_mode == "f16x3" else B.NET_F32,
                     seed=args.seed, game_offset=rank * games)

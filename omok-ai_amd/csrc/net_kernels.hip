@@ -292,7 +292,6 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                 split8(v, bh, bl);
                 const half8 ah = W[(0 + ks) * 64 + lane], al = W[(8 + ks) * 64 + lane];
                 MFMA3(ah, al, bh, bl, acc);
-                asm volatile("" ::: "memory");
             }
             __syncthreads(); // previous readers of the halo grid are done
             if (valid) {
@@ -355,7 +354,6 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                 for (int ks = 0; ks < 2; ++ks) {
                     const half8 ah = W[(20 + m * 2 + ks) * 64 + lane], al = W[(28 + m * 2 + ks) * 64 + lane];
                     MFMA3(ah, al, gh[ks], gl[ks], x[m]);
-                    asm volatile("" ::: "memory");
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) x[m][i] = lrelu(x[m][i]);
