@@ -32,6 +32,7 @@ struct Net {
     void* wt_heads = nullptr;
     void* a_fc0 = nullptr;    // [max_b][KSTEPS][hi 16 | lo 16] f16 : trunk output = fc0 A operand
     void* h0 = nullptr;       // [max_b][512] hi|lo f16 : fc0 output = fc1 A operand
+    size_t row_u4 = 0;        // a_fc0 row stride in uint4
     size_t bytes = 0;         // device bytes held
 };
 

@@ -165,27 +165,37 @@ static void forward_f32(Net& net, const Store& S, int max_count, hipStream_t st,
 // ===============================================================================================
 // Packed trunk weights (f16, 1 KiB fragments of [lane 64][8]): per block 36 fragments:
 //   L0 hi[8 ks] | L0 lo[8] | L1 hi[2] | L1 lo[2] | L2 hi[4 m][2 ks] | L2 lo[4][2]
-// fp32 side table (floats): per block { dw[9][32], b0[32], b1[32], b2[128] } then conv_w[3][128], conv_b[128]
+// followed (global memory only, not LDS-resident) by the conv_in fragments hi[4 m] | lo[4 m]:
+//   k-step of 16 with k = 0..2 the three input floats of the pixel, k = 3 the bias (input 1.0).
+// fp32 side table (floats): per block { dw[9][32], b0[32], b1[32], b2[128] }
 constexpr int TR_FRAGS_PER_BLOCK = 36;
 constexpr int TR_WBYTES = 3 * TR_FRAGS_PER_BLOCK * 1024;
+constexpr int TR_CONV_FRAGS = 8;
 constexpr int TR_SIDE_PER_BLOCK = 9 * NM + NM + NM + NC; // 480 floats
-constexpr int TR_SIDE_FLOATS = 3 * TR_SIDE_PER_BLOCK + 3 * NC + NC; // 1952
+constexpr int TR_SIDE_FLOATS = 3 * TR_SIDE_PER_BLOCK;    // 1440
 constexpr int GRID_STRIDE = 36; // floats per halo-grid row (32 + 4 pad: conflict-free b128 reads)
 
 template <int N>
 struct TrunkGeo {
     static constexpr int HW = N * N;
     static constexpr int TILES = (HW + 31) / 32;
-    static constexpr int KSTEPS = HW * 8; // fc0 k-steps: (px*4 + m)*2 + s
-    static constexpr int GRID_ROWS = (N + 2) * (N + 2);
+    static constexpr int KSTEPS = HW * 8;          // fc0 k-steps (valid pixels only)
+    // fc0 operand row: [tile][m][s] blocks of [pxl 32][hi h0|hi h1|lo h0|lo h1] uint4 (+ Net::row_pad so the row
+    // stride is not a power of two, which would put every sample row on the same memory channels)
+    static constexpr int ROW_U4 = TILES * 8 * 128;
+    static constexpr int GRID_ROWS = (N + 2) * (N + 2) + 1; // +1: the 3x6 window of the last strip may touch one row more
     static constexpr int GRID_BYTES = GRID_ROWS * GRID_STRIDE * 4;
     static constexpr int LDS_BYTES = TR_WBYTES + GRID_BYTES + TR_SIDE_FLOATS * 4;
+    static constexpr int SPR = (N + 3) / 4;        // depthwise strips (4 pixels) per board row
+    static constexpr int DW_ITEMS = N * SPR * 8;   // (row, strip, 4-channel group)
+    static constexpr int THREADS = TILES * 64;
+    static constexpr int DW_ITER = (DW_ITEMS + THREADS - 1) / THREADS;
 };
 
 template <int N, bool FROM_F32>
 __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, const float* __restrict__ in_f32,
                                                                     const uint4* __restrict__ wt, const float* __restrict__ side,
-                                                                    uint4* __restrict__ a_out, int max_count) {
+                                                                    uint4* __restrict__ a_out, size_t row_u4, int max_count) {
     using TG = TrunkGeo<N>;
     constexpr int HW = TG::HW, NW = Geo<N>::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -201,15 +211,22 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
     __syncthreads();
     int count = S.d_count[0];
     if (count > max_count) count = max_count;
-    const int px = tile * 32 + (lane & 31);
+    const int pxl = lane & 31;
+    const int px = tile * 32 + pxl;
     const bool valid = px < HW;
     const int pxc = valid ? px : HW - 1;
     const int gi = (pxc / N + 1) * (N + 2) + (pxc % N + 1);
-    const float* conv_w = lside + 3 * TR_SIDE_PER_BLOCK;
-    const float* conv_b = conv_w + 3 * NC;
+    const half8* convW = (const half8*)(wt + TR_WBYTES / 16);
 
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
-        // ---- conv_in 1x1 3->128 + bias + lrelu on the flat encoder.rs layout (VALU) ----
+        // conv_in fragments (L2-resident, issued first so they land under the board decode)
+        half8 cwh[4], cwl[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            cwh[m] = convW[m * 64 + lane];
+            cwl[m] = convW[(4 + m) * 64 + lane];
+        }
+        // ---- the pixel's three input floats in the flat encoder.rs layout ----
         float f0, f1, f2;
         if (FROM_F32) {
             const float* f = in_f32 + (size_t)b * 3 * HW + 3 * pxc;
@@ -257,16 +274,21 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
             }
             f0 = fv[0]; f1 = fv[1]; f2 = fv[2];
         }
+        // ---- conv_in 1x1 3->128 + bias + lrelu as one 16-deep k-step: k = (f0, f1, f2, 1, 0...) on lane-half 0 ----
         f32x16 x[4];
+        {
+            float v[8];
+            v[0] = h == 0 ? f0 : 0.0f; v[1] = h == 0 ? f1 : 0.0f; v[2] = h == 0 ? f2 : 0.0f; v[3] = h == 0 ? 1.0f : 0.0f;
+            v[4] = 0.0f; v[5] = 0.0f; v[6] = 0.0f; v[7] = 0.0f;
+            half8 bh, bl;
+            split8(v, bh, bl);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < 4; ++m) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch0 = 32 * m + 8 * g + 4 * h;
-                const f32x4 w0 = *(const f32x4*)(conv_w + ch0), w1 = *(const f32x4*)(conv_w + NC + ch0),
-                            w2 = *(const f32x4*)(conv_w + 2 * NC + ch0), bb4 = *(const f32x4*)(conv_b + ch0);
+                for (int i = 0; i < 16; ++i) x[m][i] = 0.0f;
+                MFMA3(cwh[m], cwl[m], bh, bl, x[m]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) x[m][4 * g + i] = lrelu(((f0 * w0[i] + f1 * w1[i]) + f2 * w2[i]) + bb4[i]);
+                for (int i = 0; i < 16; ++i) x[m][i] = lrelu(x[m][i]);
             }
         }
         // ---- 3 bottleneck residual blocks ----
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                 const half8 ah = W[(0 + ks) * 64 + lane], al = W[(8 + ks) * 64 + lane];
                 MFMA3(ah, al, bh, bl, acc);
             }
-            __syncthreads(); // previous readers of the halo grid are done
+            __syncthreads(); // B1: every wave has read its depthwise result of the previous block
             if (valid) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -303,22 +325,56 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                     *(f32x4*)(grid + gi * GRID_STRIDE + 8 * g + 4 * h) = o;
                 }
             }
-            __syncthreads();
-            // depthwise 3x3 SAME (zero halo), taps in (dy,dx) order; no bias
+            __syncthreads(); // B2: h of the whole sample is in the halo grid
+            // depthwise 3x3 SAME (zero halo), no bias.  Work item = (board row, 4-pixel strip, 4-channel
+            // group): one 3x6 window of b128 loads serves 4 output pixels; taps in (dy,dx) order.
+            f32x4 dout[TG::DW_ITER][4];
+#pragma unroll
+            for (int it = 0; it < TG::DW_ITER; ++it) {
+                const int item = tid + it * TG::THREADS;
+                const int itc = item < TG::DW_ITEMS ? item : 0;
+                const int cg = itc & 7, strip = itc >> 3;
+                const int y = strip / TG::SPR, x0 = (strip % TG::SPR) * 4;
+                const float* gp = grid + (y * (N + 2) + x0) * GRID_STRIDE + 4 * cg;
+                f32x4 win[3][6];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 6; ++dx) win[dy][dx] = *(const f32x4*)(gp + (dy * (N + 2) + dx) * GRID_STRIDE);
+                f32x4 w9[9];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) w9[tap] = *(const f32x4*)(dwt + tap * NM + 4 * cg);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const f32x4 hv = win[tap / 3][p + tap % 3];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] += hv[c] * w9[tap][c];
+                    }
+                    dout[it][p] = o;
+                }
+            }
+            __syncthreads(); // B3: all windows are in registers; the grid can be overwritten in place
+#pragma unroll
+            for (int it = 0; it < TG::DW_ITER; ++it) {
+                const int item = tid + it * TG::THREADS;
+                if (item < TG::DW_ITEMS) {
+                    const int cg = item & 7, strip = item >> 3;
+                    const int y = strip / TG::SPR, x0 = (strip % TG::SPR) * 4;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        if (x0 + p < N) *(f32x4*)(grid + ((y + 1) * (N + 2) + x0 + p + 1) * GRID_STRIDE + 4 * cg) = dout[it][p];
+                }
+            }
+            __syncthreads(); // B4: depthwise output of the whole sample is in the grid
             float d[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) d[i] = 0.0f;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 dv = *(const f32x4*)(grid + gi * GRID_STRIDE + 8 * g + 4 * h);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int nrow = gi + (tap / 3 - 1) * (N + 2) + (tap % 3 - 1);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 hv = *(const f32x4*)(grid + nrow * GRID_STRIDE + 8 * g + 4 * h);
-                    const f32x4 wv = *(const f32x4*)(dwt + tap * NM + 8 * g + 4 * h);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) d[4 * g + i] += hv[i] * wv[i];
-                }
-                asm volatile("" ::: "memory"); // keep at most one tap's loads in flight (register pressure)
+                for (int i = 0; i < 4; ++i) d[4 * g + i] = dv[i];
             }
             // L1: pointwise 32 -> 32 + bias + lrelu
             f32x16 accg;
@@ -359,9 +415,10 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                 for (int i = 0; i < 16; ++i) x[m][i] = lrelu(x[m][i]);
             }
         }
-        // ---- fc0 operand row: [ks = (px*4 + m)*2 + s][hi h0 | hi h1 | lo h0 | lo h1] (64 B per k-step) ----
+        // ---- fc0 operand row: block (tile, m, s) = [pxl 32][hi h0 | hi h1 | lo h0 | lo h1]: a k-step of one sample
+        //      is 64 contiguous bytes (one DMA line per row in fc0); the hi and lo stores of a wave fill 2 KiB ----
         if (valid) {
-            uint4* row = a_out + (size_t)b * (TG::KSTEPS * 4);
+            uint4* row = a_out + (size_t)b * row_u4;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -371,9 +428,9 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                     for (int j = 0; j < 8; ++j) v[j] = x[m][8 * s + j];
                     half8 hi, lo;
                     split8(v, hi, lo);
-                    const int ks = (px * 4 + m) * 2 + s;
-                    row[ks * 4 + h] = *(const uint4*)&hi;
-                    row[ks * 4 + 2 + h] = *(const uint4*)&lo;
+                    uint4* blkp = row + ((tile * 4 + m) * 2 + s) * 128 + pxl * 4 + h;
+                    blkp[0] = *(const uint4*)&hi;
+                    blkp[2] = *(const uint4*)&lo;
                 }
         }
     }
@@ -390,7 +447,8 @@ constexpr int GT_STAGES = 3;
 
 template <int MT, int EPI, int TAG>
 __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksteps,
-                                                size_t act_row_u4, const float* __restrict__ bias, uint4* __restrict__ out_split,
+                                                size_t act_row_u4, int k_full, int last_cnt, int lo_off,
+                                                const float* __restrict__ bias, uint4* __restrict__ out_split,
                                                 size_t out_row_u4, float* __restrict__ out_logits, const int32_t* __restrict__ d_count,
                                                 int max_count) {
     constexpr int MTW = MT / 4;
@@ -412,31 +470,36 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
     const int h = lane >> 5;
 
     // staging plan: this wave owns fragments f = wave + 8*i of every k-step.
-    // f < WFR: weight fragment (1 KiB, linear);  else activation fragment (sample tile ct, part hi/lo):
-    // lane (c = lane&31, h) fetches the 16-byte piece [ks][part*2 + h] of sample row b0 + 32*ct + c.
+    // f < WFR: weight fragment (1 KiB, linear, advancing WFR KiB per k-step);  else activation fragment
+    // (sample tile ct, part hi/lo): lane (c = lane&31, h) fetches the 16-byte piece at uint4 offset
+    // ko(k-step) + part*lo_off + h of sample row b0 + 32*ct + c.
     const uint4* src[LPW];
-    size_t step_u4[LPW];
+    bool is_w[LPW];
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
         const int f = wave + 8 * i;
+        is_w[i] = f < WFR;
         if (f < WFR) {
             src[i] = wp + (size_t)f * 64 + lane;
-            step_u4[i] = (size_t)WFR * 64;
         } else {
             const int a = f - WFR, ct = a >> 1, part = a & 1;
             const size_t row = (size_t)(b0 + 32 * ct + (lane & 31));
-            src[i] = act + row * act_row_u4 + part * 2 + h;
-            step_u4[i] = 4;
+            src[i] = act + row * act_row_u4 + (size_t)(part * lo_off + h);
         }
     }
-    auto issue = [&](int slot) { // LDS-DMA of the next k-step into ring slot `slot`; advances the sources
+    int kt = 0; // next k-step to stage
+    auto issue = [&](int slot) { // LDS-DMA of k-step kt into ring slot `slot`
+        // uint4 offset of k-step kt inside an activation row: 4 per k-step; the k-steps of a partial last pixel
+        // tile (fc0 only) sit in 128-uint4 blocks holding last_cnt k-steps each
+        const int ko = kt < k_full ? 4 * kt : ((k_full >> 5) + (kt - k_full) / last_cnt) * 128 + ((kt - k_full) % last_cnt) * 4;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+            const uint4* g = is_w[i] ? src[i] + (size_t)kt * (WFR * 64) : src[i] + ko;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)(lds + slot * STAGE_U4 + (wave + 8 * i) * 64),
                                              16, 0, 0);
-            src[i] += step_u4[i];
         }
+        kt += 1;
     };
     f32x16 acc[MTW][2];
 #pragma unroll
@@ -587,12 +650,14 @@ size_t net_alloc(Net& net) {
         ok = ok && A((void**)&net.s1, sizeof(float) * c * NF);
     } else {
         const size_t ks0 = hw * 8;
-        ok = ok && A(&net.wt_trunk, TR_WBYTES);
+        net.row_u4 = (size_t)((hw + 31) / 32) * 8 * 128 + (getenv("OMOK_ROWPAD_U4") ? atoi(getenv("OMOK_ROWPAD_U4")) : 80);
+        const size_t row_u4 = net.row_u4;
+        ok = ok && A(&net.wt_trunk, TR_WBYTES + TR_CONV_FRAGS * 1024);
         ok = ok && A((void**)&net.wt_first, sizeof(float) * (TR_SIDE_FLOATS + 2 * NF + heads_mt(net.hw) * 32));
         ok = ok && A(&net.wt_fc0, ks0 * 16 * 2 * 1024);
         ok = ok && A(&net.wt_fc1, (size_t)32 * 16 * 2 * 1024);
         ok = ok && A(&net.wt_heads, (size_t)32 * heads_mt(net.hw) * 2 * 1024);
-        ok = ok && A(&net.a_fc0, mb * ks0 * 64);
+        ok = ok && A(&net.a_fc0, mb * row_u4 * 16);
         ok = ok && A(&net.h0, mb * 32 * 64 * 2);       // h0 and h1 rows (2 KiB each)
         ok = ok && A((void**)&net.s0, sizeof(float) * mb * heads_mt(net.hw) * 32); // logits
     }
@@ -618,7 +683,7 @@ int net_commit(Net& net, hipStream_t st) {
         if (hipMemcpy(T[i].data(), net.w[i], sizeof(float) * T[i].size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     }
     // ---- trunk fragments ----
-    std::vector<_Float16> trunk((size_t)TR_WBYTES / 2, (_Float16)0.0f);
+    std::vector<_Float16> trunk((size_t)(TR_WBYTES + TR_CONV_FRAGS * 1024) / 2, (_Float16)0.0f);
     std::vector<float> side((size_t)TR_SIDE_FLOATS + 2 * NF + heads_mt(hw) * 32, 0.0f);
     auto put = [&](int blk, int frag, const std::vector<_Float16>& src, int ksteps, int MT, int part, int ks, int mt) {
         const size_t s = (((size_t)ks * MT + mt) * 2 + part) * 512;
@@ -642,8 +707,16 @@ int net_commit(Net& net, hipStream_t st) {
         memcpy(sd + 10 * NM, b1, sizeof(float) * NM);
         memcpy(sd + 11 * NM, b2, sizeof(float) * NC);
     }
-    memcpy(side.data() + 3 * TR_SIDE_PER_BLOCK, T[0].data(), sizeof(float) * 3 * NC);
-    memcpy(side.data() + 3 * TR_SIDE_PER_BLOCK + 3 * NC, T[1].data(), sizeof(float) * NC);
+    { // conv_in as one 16-deep k-step: k = 0..2 input floats, k = 3 bias (network.rs:65-76)
+        const float *cw = T[0].data(), *cb = T[1].data();
+        std::vector<_Float16> pc;
+        pack_A(pc, 1, 4, [&](int k, int m) { return k < 3 ? cw[k * NC + m] : (k == 3 ? cb[m] : 0.0f); },
+               [](int, int h, int j) { return 8 * h + j; });
+        for (int m = 0; m < 4; ++m) {
+            memcpy(&trunk[((size_t)3 * TR_FRAGS_PER_BLOCK + m) * 512], &pc[((size_t)m * 2 + 0) * 512], 1024);
+            memcpy(&trunk[((size_t)3 * TR_FRAGS_PER_BLOCK + 4 + m) * 512], &pc[((size_t)m * 2 + 1) * 512], 1024);
+        }
+    }
     // biases of fc0, fc1, heads behind the trunk side table
     float* bias_fc0 = side.data() + TR_SIDE_FLOATS;
     float* bias_fc1 = bias_fc0 + NF;
@@ -652,12 +725,21 @@ int net_commit(Net& net, hipStream_t st) {
     memcpy(bias_fc1, T[26].data(), sizeof(float) * NF);
     memcpy(bias_heads, T[30].data(), sizeof(float) * hw);
     bias_heads[hw] = T[28][0];
-    // ---- fc0: k-step ks = (px*4 + m)*2 + s, source row = px*128 + kperm(m, s, h, j) ----
+    // ---- fc0: k-steps enumerate (tile, m, s, pixel-in-tile) over the valid pixels, matching the trunk's
+    //      operand row; source row of fc0_w = px*128 + kperm(m, s, h, j) (flatten index (y*N+x)*128 + c) ----
     std::vector<_Float16> pk;
     {
         const float* w = T[23].data();
+        const int tiles = (hw + 31) / 32;
+        std::vector<int> kpx, km, ks_;
+        for (int tile = 0; tile < tiles; ++tile)
+            for (int m = 0; m < 4; ++m)
+                for (int s2 = 0; s2 < 2; ++s2)
+                    for (int pl = 0; pl < 32 && tile * 32 + pl < hw; ++pl) {
+                        kpx.push_back(tile * 32 + pl); km.push_back(m); ks_.push_back(s2);
+                    }
         pack_A(pk, hw * 8, 16, [&](int k, int m) { return w[(size_t)k * NF + m]; },
-               [](int ks, int h, int j) { return (ks >> 3) * NC + kperm((ks >> 1) & 3, ks & 1, h, j); });
+               [&](int ks, int h, int j) { return kpx[ks] * NC + kperm(km[ks], ks_[ks], h, j); });
         if (hipMemcpyAsync(net.wt_fc0, pk.data(), pk.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
         hipStreamSynchronize(st);
     }
@@ -676,7 +758,7 @@ int net_commit(Net& net, hipStream_t st) {
         if (hipMemcpyAsync(net.wt_heads, pk.data(), pk.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
         hipStreamSynchronize(st);
     }
-    if (hipMemcpyAsync(net.wt_trunk, trunk.data(), TR_WBYTES, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(net.wt_trunk, trunk.data(), trunk.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     if (hipMemcpyAsync(net.wt_first, side.data(), side.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
     hipStreamSynchronize(st);
     return 0;
@@ -692,12 +774,13 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
         attr_done = true;
     }
     const int grid = max_count < 256 ? max_count : 256;
-    kern<<<grid, TG::TILES * 64, TG::LDS_BYTES, st>>>(S, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, max_count);
+    kern<<<grid, TG::TILES * 64, TG::LDS_BYTES, st>>>(S, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4, max_count);
 }
 
 template <int MT, int EPI, int TAG>
-static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_row_u4, const float* bias, void* out_split,
-                        size_t out_row_u4, float* out_logits, const Store& S, int max_count, hipStream_t st) {
+static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_row_u4, int k_full, int last_cnt, int lo_off,
+                        const float* bias, void* out_split, size_t out_row_u4, float* out_logits, const Store& S, int max_count,
+                        hipStream_t st) {
     constexpr int LDS = (MT * 2 + 8) * 1024 * GT_STAGES;
     static bool attr_done = false;
     auto kern = k_gemm_t<MT, EPI, TAG>;
@@ -706,8 +789,8 @@ static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_
         attr_done = true;
     }
     const int grid = (max_count + GT_BS - 1) / GT_BS;
-    kern<<<grid, 512, LDS, st>>>((const uint4*)wp, (const uint4*)act, ksteps, act_row_u4, bias, (uint4*)out_split, out_row_u4,
-                                  out_logits, S.d_count, max_count);
+    kern<<<grid, 512, LDS, st>>>((const uint4*)wp, (const uint4*)act, ksteps, act_row_u4, k_full, last_cnt, lo_off, bias, (uint4*)out_split,
+                                  out_row_u4, out_logits, S.d_count, max_count);
 }
 
 static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof) {
@@ -723,12 +806,12 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     uint4* h0 = (uint4*)net.h0;
     const size_t mb = ((size_t)net.max_b + GT_BS - 1) / GT_BS * GT_BS;
     uint4* h1 = h0 + mb * 128; // 32 k-steps * 4 uint4 per row
-    launch_gemm<16, EPI_SPLIT, 0>(net.wt_fc0, net.a_fc0, ks0, (size_t)ks0 * 4, bias_fc0, h0, 128, nullptr, S, max_count, st);
+    launch_gemm<16, EPI_SPLIT, 0>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, h0, 128, nullptr, S, max_count, st);
     if (prof) { prof->end(st); prof->begin(PC_TAIL, st); }
-    launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, bias_fc1, h1, 128, nullptr, S, max_count, st);
+    launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st);
     const int MT = heads_mt(hw);
-    if (MT == 8) launch_gemm<8, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, bias_heads, nullptr, 0, net.s0, S, max_count, st);
-    else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, bias_heads, nullptr, 0, net.s0, S, max_count, st);
+    if (MT == 8) launch_gemm<8, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st);
+    else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st);
     const int sg = max_count < 4096 ? max_count : 4096;
     k_softmax<<<sg, 64, 0, st>>>(net.s0, MT * 32, hw, net.rowp, net.p, net.v, S.d_count, max_count);
     if (prof) prof->end(st);
