@@ -193,6 +193,7 @@ def main():
                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": (st["tree_bytes"] / round_s / 1e9 / HBM_PEAK_GBS) if round_s > 0 else 0.0, "traffic": None},
         "rank0_kernel_ms": {kk: st[kk] for kk in ("ms_round", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply")},
+        "game_length_percentiles": {str(q): float(np.percentile(plies, q)) for q in (0, 10, 25, 50, 75, 90, 99, 100)},
         "arena": {"max_nodes": max_nodes, "max_tables": max_tables, "peak_nodes": st["peak_nodes"], "peak_tables": st["peak_tables"]},
     }
     if args.cpu_seconds > 0 and world == 1:

@@ -445,7 +445,7 @@ enum { EPI_SPLIT = 0, EPI_LOGITS = 1 };
 constexpr int GT_BS = 128;
 constexpr int GT_STAGES = 3;
 
-template <int MT, int EPI, int TAG>
+template <int MT, int EPI, int TAG, int NST, int PRIO>
 __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksteps,
                                                 size_t act_row_u4, int k_full, int last_cnt, int lo_off,
                                                 const float* __restrict__ bias, uint4* __restrict__ out_split,
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
     constexpr int NFR = WFR + 8;           // + 4 sample tiles x (hi, lo)
     constexpr int LPW = NFR / 8;           // LDS-DMA instructions per wave per k-step (NFR is a multiple of 8)
     constexpr int STAGE_U4 = NFR * 64;
-    constexpr int NST = GT_STAGES;         // ring slots; two k-steps stay in flight behind the one being read
+    // NST ring slots: NST-2 k-steps stay in flight behind the one being read
     static_assert(NFR % 8 == 0, "fragment count must split evenly over 8 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* lds = (uint4*)smem;
@@ -488,17 +488,21 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
         }
     }
     int kt = 0; // next k-step to stage
-    auto issue = [&](int slot) { // LDS-DMA of k-step kt into ring slot `slot`
-        // uint4 offset of k-step kt inside an activation row: 4 per k-step; the k-steps of a partial last pixel
-        // tile (fc0 only) sit in 128-uint4 blocks holding last_cnt k-steps each
-        const int ko = kt < k_full ? 4 * kt : ((k_full >> 5) + (kt - k_full) / last_cnt) * 128 + ((kt - k_full) % last_cnt) * 4;
+    int ko_cur = 0;
+    auto issue_begin = [&]() { // uint4 offset of k-step kt inside an activation row: 4 per k-step; the k-steps of a
+        // partial last pixel tile (fc0 only) sit in 128-uint4 blocks holding last_cnt k-steps each
+        ko_cur = kt < k_full ? 4 * kt : ((k_full >> 5) + (kt - k_full) / last_cnt) * 128 + ((kt - k_full) % last_cnt) * 4;
+    };
+    auto issue_one = [&](int i, int slot) { // one LDS-DMA instruction (1 KiB fragment) of k-step kt into ring slot `slot`
+        const uint4* g = is_w[i] ? src[i] + (size_t)kt * (WFR * 64) : src[i] + ko_cur;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(lds + slot * STAGE_U4 + (wave + 8 * i) * 64),
+                                         16, 0, 0);
+    };
+    auto issue = [&](int slot) {
+        issue_begin();
 #pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            const uint4* g = is_w[i] ? src[i] + (size_t)kt * (WFR * 64) : src[i] + ko;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(lds + slot * STAGE_U4 + (wave + 8 * i) * 64),
-                                             16, 0, 0);
-        }
+        for (int i = 0; i < LPW; ++i) issue_one(i, slot);
         kt += 1;
     };
     f32x16 acc[MTW][2];
@@ -509,18 +513,24 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
 
-    issue(0);
-    if (ksteps > 1) issue(1);
-    int slot = 0, nslot = 2;
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+        if (p < ksteps) issue(p);
+    int slot = 0, nslot = NST - 1;
     for (int t = 0; t < ksteps; ++t) {
-        // retire k-step t (this wave's share), then make every wave's share visible
-        if (t + 1 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        // retire k-step t (this wave's share; later k-steps stay in flight), then make every wave's share visible
+        const int rem = ksteps - 1 - t;
+        if (rem >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW * (NST - 2)) : "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < ksteps) issue(nslot); // slot (t+2)%NST was last read at k-step t-1: safe behind the barrier
+        // the staging of k-step t+NST-1 (its slot was last read at k-step t-1: safe behind the barrier) is
+        // interleaved with the MFMAs so that the DMA issue cost hides under matrix-pipe time
+        const bool stage = t + NST - 1 < ksteps;
+        if (stage) issue_begin();
         const half8* L = (const half8*)(lds + slot * STAGE_U4);
-        half8 bh[2], bl[2];
+        half8 bh[2], bl[2], ah[MTW], al[MTW];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             bh[c] = L[(WFR + (2 * ws + c) * 2 + 0) * 64 + lane];
@@ -528,11 +538,21 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
         }
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
-            const int mt = wm * MTW + i;
-            const half8 ah = L[(mt * 2 + 0) * 64 + lane], al = L[(mt * 2 + 1) * 64 + lane];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) MFMA3(ah, al, bh[c], bl[c], acc[i][c]);
+            ah[i] = L[((wm * MTW + i) * 2 + 0) * 64 + lane];
+            al[i] = L[((wm * MTW + i) * 2 + 1) * 64 + lane];
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) MFMA3(ah[i], al[i], bh[c], bl[c], acc[i][c]);
+            if (stage) {
+#pragma unroll
+                for (int q = i; q < LPW; q += MTW) issue_one(q, nslot);
+            }
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (stage) kt += 1;
         slot = slot + 1 == NST ? 0 : slot + 1;
         nslot = nslot + 1 == NST ? 0 : nslot + 1;
     }
@@ -777,13 +797,13 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
     kern<<<grid, TG::TILES * 64, TG::LDS_BYTES, st>>>(S, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4, max_count);
 }
 
-template <int MT, int EPI, int TAG>
+template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
 static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_row_u4, int k_full, int last_cnt, int lo_off,
                         const float* bias, void* out_split, size_t out_row_u4, float* out_logits, const Store& S, int max_count,
                         hipStream_t st) {
-    constexpr int LDS = (MT * 2 + 8) * 1024 * GT_STAGES;
+    constexpr int LDS = (MT * 2 + 8) * 1024 * NST;
     static bool attr_done = false;
-    auto kern = k_gemm_t<MT, EPI, TAG>;
+    auto kern = k_gemm_t<MT, EPI, TAG, NST, PRIO>;
     if (!attr_done) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;
@@ -806,7 +826,11 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     uint4* h0 = (uint4*)net.h0;
     const size_t mb = ((size_t)net.max_b + GT_BS - 1) / GT_BS * GT_BS;
     uint4* h1 = h0 + mb * 128; // 32 k-steps * 4 uint4 per row
-    launch_gemm<16, EPI_SPLIT, 0>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, h0, 128, nullptr, S, max_count, st);
+    static const int gv = getenv("OMOK_GEMM_VARIANT") ? atoi(getenv("OMOK_GEMM_VARIANT")) : 0;
+    if (gv == 1) launch_gemm<16, EPI_SPLIT, 0, 3, 1>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, h0, 128, nullptr, S, max_count, st);
+    else if (gv == 2) launch_gemm<16, EPI_SPLIT, 0, 4, 0>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, h0, 128, nullptr, S, max_count, st);
+    else if (gv == 3) launch_gemm<16, EPI_SPLIT, 0, 4, 1>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, h0, 128, nullptr, S, max_count, st);
+    else launch_gemm<16, EPI_SPLIT, 0, 3, 0>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, h0, 128, nullptr, S, max_count, st);
     if (prof) { prof->end(st); prof->begin(PC_TAIL, st); }
     launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st);
     const int MT = heads_mt(hw);
