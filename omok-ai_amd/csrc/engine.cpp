@@ -82,6 +82,7 @@ struct omok_engine {
     bool reset_done = false;
     bool sampled = false;
     int round_reqs = -1;   // step-wise API state
+    int round_cap = 0;     // alive * batch_size of the generated round: the net's max_count (same as omok_execute uses)
     int mirror_reqs = -1;
     float* d_root_policy = nullptr;
     int32_t* d_actions = nullptr;
@@ -421,7 +422,7 @@ static int need_reset(omok_engine* e) {
     return 0;
 }
 
-static void enqueue_round(omok_engine* e, int round, int K, float eps, float alpha, bool eval_and_scatter) {
+static void enqueue_round(omok_engine* e, int round, int K, float eps, float alpha, bool eval_and_scatter, int alive) {
     const int side = e->ply & 1;
     RoundArgs a{side, round, K, e->ply, eps, alpha, e->cfg.seed, e->cfg.game_offset};
     e->prof.begin(PC_ROUND, e->st);
@@ -432,17 +433,17 @@ static void enqueue_round(omok_engine* e, int round, int K, float eps, float alp
     k_add_evals<<<1, 64, 0, e->st>>>(e->S.d_count, e->d_evals);
     e->prof.end(e->st);
     if (eval_and_scatter) {
-        net_forward_requests(e->net, e->S, e->cfg.games * K, e->st, &e->prof);
+        net_forward_requests(e->net, e->S, alive * K, e->st, &e->prof);
         e->prof.begin(PC_TREE_OTHER, e->st);
         launch_scatter(e->n, e->S, side, e->net.p, e->net.v, e->st);
         e->prof.end(e->st);
     }
 }
 
-static int enqueue_execute(omok_engine* e, int count, int K, float eps, float alpha) {
+static int enqueue_execute(omok_engine* e, int count, int K, float eps, float alpha, int alive) {
     int processed = 0, round = 0;
     while (processed < count) { // pme.rs:39-42,207
-        enqueue_round(e, round, K, eps, alpha, true);
+        enqueue_round(e, round, K, eps, alpha, true, alive);
         processed += K;
         round += 1;
     }
@@ -464,7 +465,7 @@ extern "C" int omok_execute(omok_engine* e, int32_t count, int32_t batch_size, f
     HIPCHK(e, hipSetDevice(e->cfg.device));
     uint32_t bits = 0, alive = 0;
     if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
-    const int rounds = enqueue_execute(e, count, batch_size, epsilon, alpha);
+    const int rounds = enqueue_execute(e, count, batch_size, epsilon, alpha, (int)alive);
     e->sims += (double)rounds * batch_size * alive;
     if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
     return tree_error(e, bits);
@@ -489,13 +490,13 @@ extern "C" int omok_sample_actions(omok_engine* e, float temperature, int32_t th
     return tree_error(e, bits);
 }
 
-static void enqueue_mirror_and_advance(omok_engine* e) {
+static void enqueue_mirror_and_advance(omok_engine* e, int alive) {
     const int side = e->ply & 1;
     e->prof.begin(PC_PLY, e->st);
     launch_mirror_scan(e->n, e->S, side, e->st);
     k_add_evals<<<1, 64, 0, e->st>>>(e->S.d_count, e->d_evals);
     e->prof.end(e->st);
-    net_forward_requests(e->net, e->S, e->cfg.games, e->st, &e->prof);
+    net_forward_requests(e->net, e->S, alive, e->st, &e->prof);
     e->prof.begin(PC_PLY, e->st);
     launch_advance(e->n, e->S, side, e->net.p, e->st);
     e->prof.end(e->st);
@@ -508,7 +509,7 @@ extern "C" int omok_advance(omok_engine* e) {
     HIPCHK(e, hipSetDevice(e->cfg.device));
     uint32_t bits = 0, before = 0, after = 0;
     if (read_status(e, &bits, &before)) return OMOK_ERR_HIP;
-    enqueue_mirror_and_advance(e);
+    enqueue_mirror_and_advance(e, (int)before);
     if (read_status(e, &bits, &after)) return OMOK_ERR_HIP;
     e->ply_games += before;
     e->finished += (double)before - (double)after;
@@ -528,9 +529,9 @@ extern "C" int omok_selfplay_run(omok_engine* e, int32_t count, int32_t batch_si
     if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
     int plies = 0;
     while (alive > 0 && (max_plies <= 0 || plies < max_plies)) { // trainer.rs:95
-        const int rounds = enqueue_execute(e, count, batch_size, epsilon, alpha);
+        const int rounds = enqueue_execute(e, count, batch_size, epsilon, alpha, (int)alive);
         enqueue_sample(e, temperature, threshold);
-        enqueue_mirror_and_advance(e);
+        enqueue_mirror_and_advance(e, (int)alive);
         e->sims += (double)rounds * batch_size * alive;
         e->ply_games += alive;
         e->ply += 1;
@@ -552,13 +553,14 @@ extern "C" int omok_round_generate(omok_engine* e, int32_t round, int32_t batch_
     if (need_reset(e)) return OMOK_ERR_STATE;
     if (check_exec_args(e, 1, batch_size, epsilon, alpha)) return OMOK_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->cfg.device));
-    enqueue_round(e, round, batch_size, epsilon, alpha, false);
+    enqueue_round(e, round, batch_size, epsilon, alpha, false, e->cfg.games);
     int32_t cnt = 0;
     HIPCHK(e, hipMemcpyAsync(&cnt, e->S.d_count, sizeof(int32_t), hipMemcpyDeviceToHost, e->st));
     uint32_t bits = 0, alive = 0;
     if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
     e->sims += (double)batch_size * alive;
     e->round_reqs = cnt;
+    e->round_cap = (int)alive * batch_size;
     if (n_requests) *n_requests = cnt;
     return tree_error(e, bits);
 }
@@ -600,7 +602,7 @@ extern "C" int omok_round_eval(omok_engine* e) {
     if (need_net(e)) return OMOK_ERR_STATE;
     if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
     if (e->round_reqs == 0) return OMOK_OK;
-    net_forward_requests(e->net, e->S, e->round_reqs, e->st, &e->prof);
+    net_forward_requests(e->net, e->S, e->round_cap, e->st, &e->prof);
     return sync_and_check(e, "round_eval") ? OMOK_ERR_HIP : OMOK_OK;
 }
 extern "C" int omok_round_outputs(omok_engine* e, float* p, float* v) {

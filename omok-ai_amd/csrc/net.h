@@ -33,6 +33,7 @@ struct Net {
     void* a_fc0 = nullptr;    // [max_b][KSTEPS][hi 16 | lo 16] f16 : trunk output = fc0 A operand
     void* h0 = nullptr;       // [max_b][512] hi|lo f16 : fc0 output = fc1 A operand
     size_t row_u4 = 0;        // a_fc0 row stride in uint4
+    float* part = nullptr;    // split-K fp32 partials of fc0 for small batches
     size_t bytes = 0;         // device bytes held
 };
 

@@ -441,7 +441,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
 // ===============================================================================================
 // Wp : [ksteps][MT][hi|lo][lane][8] f16 (1 KiB fragments), Act: rows of [ksteps][hi h0|hi h1|lo h0|lo h1]
 // 8 waves: wm = wave>>1 owns MT/4 m-tiles, ws = wave&1 owns 2 of the 4 sample tiles.
-enum { EPI_SPLIT = 0, EPI_LOGITS = 1 };
+enum { EPI_SPLIT = 0, EPI_LOGITS = 1, EPI_PARTIAL = 2 };
 constexpr int GT_BS = 128;
 constexpr int GT_STAGES = 3;
 
@@ -487,7 +487,9 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
             src[i] = act + row * act_row_u4 + (size_t)(part * lo_off + h);
         }
     }
-    int kt = 0; // next k-step to stage
+    // split-K (EPI_PARTIAL, small batches): blockIdx.y owns the k-steps [kbeg, kbeg + ksteps)
+    const int kbeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksteps : 0;
+    int kt = kbeg; // next k-step to stage
     int ko_cur = 0;
     auto issue_begin = [&]() { // uint4 offset of k-step kt inside an activation row: 4 per k-step; the k-steps of a
         // partial last pixel tile (fc0 only) sit in 128-uint4 blocks holding last_cnt k-steps each
@@ -572,7 +574,15 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
 #pragma unroll
                 for (int q = 0; q < 4; ++q) y[4 * g + q] = acc[i][c][4 * g + q] + bv[q];
             }
-            if (EPI == EPI_SPLIT) {
+            if (EPI == EPI_PARTIAL) { // raw fp32 partial sums [split][row][MT*32]; bias/activation in k_splitk_finish
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = acc[i][c][4 * g + q];
+                    *(f32x4*)(out_logits + ((size_t)blockIdx.y * out_row_u4 + sample) * (MT * 32) + 32 * mt + 8 * g + 4 * h) = o;
+                }
+            } else if (EPI == EPI_SPLIT) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     float v[8];
@@ -595,6 +605,36 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
             }
         }
     }
+}
+
+// split-K finish: sums the partials in split order (deterministic), + bias, LeakyReLU, writes the hi|lo operand row
+__global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ part, int nsplit, size_t cap_rows,
+                                                       const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
+                                                       const int32_t* __restrict__ d_count, int max_count) {
+    int count = d_count[0];
+    if (count > max_count) count = max_count;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // (sample, mt 16, s 2, h 2)
+    const size_t sample = i >> 6;
+    if (sample >= (size_t)count) return;
+    const int piece = (int)(i & 63), mt = piece >> 2, s = (piece >> 1) & 1, h = piece & 1;
+    const int n0 = 32 * mt + 16 * s + 4 * h; // j = 0..3 -> n0 + j ; j = 4..7 -> n0 + 8 + (j - 4)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float* p = part + ((size_t)sp * cap_rows + sample) * NF + n0;
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
+    }
+    const f32x4 ba = *(const f32x4*)(bias + n0), bb = *(const f32x4*)(bias + n0 + 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = lrelu(v[j] + ba[j]); v[4 + j] = lrelu(v[4 + j] + bb[j]); }
+    half8 hi, lo;
+    split8(v, hi, lo);
+    uint4* row = out_split + sample * out_row_u4 + (size_t)(2 * mt + s) * 4;
+    row[h] = *(const uint4*)&hi;
+    row[2 + h] = *(const uint4*)&lo;
 }
 
 // policy softmax (network.rs:236-247) + value tanh (network.rs:197-200); one wave per sample
@@ -680,6 +720,7 @@ size_t net_alloc(Net& net) {
         ok = ok && A(&net.a_fc0, mb * row_u4 * 16);
         ok = ok && A(&net.h0, mb * 32 * 64 * 2);       // h0 and h1 rows (2 KiB each)
         ok = ok && A((void**)&net.s0, sizeof(float) * mb * heads_mt(net.hw) * 32); // logits
+        ok = ok && A((void**)&net.part, sizeof(float) * (size_t)2 * 16384 * NF);       // split-K partials (<= 64 MiB)
     }
     if (!ok) { net_free(net); return 0; }
     net.bytes = bytes;
@@ -689,7 +730,7 @@ size_t net_alloc(Net& net) {
 void net_free(Net& net) {
     void** ptrs[] = {(void**)&net.p, (void**)&net.v, (void**)&net.in_f32, (void**)&net.sx, (void**)&net.sh, (void**)&net.sd,
                      (void**)&net.sg, (void**)&net.s0, (void**)&net.s1, &net.wt_trunk, (void**)&net.wt_first, &net.wt_fc0,
-                     &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0};
+                     &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     for (int i = 0; i < NET_TENSORS; ++i) { if (net.w[i]) hipFree(net.w[i]); net.w[i] = nullptr; }
 }
@@ -800,7 +841,7 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
 template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
 static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_row_u4, int k_full, int last_cnt, int lo_off,
                         const float* bias, void* out_split, size_t out_row_u4, float* out_logits, const Store& S, int max_count,
-                        hipStream_t st) {
+                        hipStream_t st, int nsplit = 1) {
     constexpr int LDS = (MT * 2 + 8) * 1024 * NST;
     static bool attr_done = false;
     auto kern = k_gemm_t<MT, EPI, TAG, NST, PRIO>;
@@ -808,7 +849,7 @@ static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;
     }
-    const int grid = (max_count + GT_BS - 1) / GT_BS;
+    const dim3 grid((max_count + GT_BS - 1) / GT_BS, nsplit);
     kern<<<grid, 512, LDS, st>>>((const uint4*)wp, (const uint4*)act, ksteps, act_row_u4, k_full, last_cnt, lo_off, bias, (uint4*)out_split,
                                   out_row_u4, out_logits, S.d_count, max_count);
 }
@@ -826,11 +867,21 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     uint4* h0 = (uint4*)net.h0;
     const size_t mb = ((size_t)net.max_b + GT_BS - 1) / GT_BS * GT_BS;
     uint4* h1 = h0 + mb * 128; // 32 k-steps * 4 uint4 per row
-    static const int gv = getenv("OMOK_GEMM_VARIANT") ? atoi(getenv("OMOK_GEMM_VARIANT")) : 0;
-    if (gv == 1) launch_gemm<16, EPI_SPLIT, 0, 3, 1>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, h0, 128, nullptr, S, max_count, st);
-    else if (gv == 2) launch_gemm<16, EPI_SPLIT, 0, 4, 0>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, h0, 128, nullptr, S, max_count, st);
-    else if (gv == 3) launch_gemm<16, EPI_SPLIT, 0, 4, 1>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, h0, 128, nullptr, S, max_count, st);
-    else launch_gemm<16, EPI_SPLIT, 0, 3, 0>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, h0, 128, nullptr, S, max_count, st);
+    // fc0.  Small batches (late plies of an episode) cannot fill 256 CUs with 128-sample tiles: split K over
+    // blockIdx.y into fp32 partials and finish (sum in split order + bias + LeakyReLU + hi|lo) in a second kernel.
+    const int nsplit = max_count > 16384 ? 1 : (max_count > 8192 ? 2 : (max_count > 4096 ? 4 : 8));
+    if (nsplit == 1) {
+        launch_gemm<16, EPI_SPLIT, 0, 4, 0>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2,
+                                             bias_fc0, h0, 128, nullptr, S, max_count, st);
+    } else {
+        const size_t cap_rows = 16384 / nsplit * 2; // rows per split slab (>= padded max_count)
+        launch_gemm<16, EPI_PARTIAL, 3, 4, 0>(net.wt_fc0, net.a_fc0, ks0 / nsplit, net.row_u4, (hw / 32) * 256,
+                                               (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, nullptr, cap_rows, net.part, S, max_count, st,
+                                               nsplit);
+        const size_t threads = (size_t)max_count * 64;
+        k_splitk_finish<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(net.part, nsplit, cap_rows, bias_fc0, h0, 128, S.d_count,
+                                                                            max_count);
+    }
     if (prof) { prof->end(st); prof->begin(PC_TAIL, st); }
     launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st);
     const int MT = heads_mt(hw);
