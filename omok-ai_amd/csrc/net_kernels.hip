@@ -192,7 +192,7 @@ struct TrunkGeo {
     static constexpr int DW_ITER = (DW_ITEMS + THREADS - 1) / THREADS;
 };
 
-template <int N, bool FROM_F32>
+template <int N, bool FROM_F32, int ABL = 0> // ABL: timing-only ablations (1 = no depthwise exchange, 2 = no output stores, 4 = no conv_in)
 __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, const float* __restrict__ in_f32,
                                                                     const uint4* __restrict__ wt, const float* __restrict__ side,
                                                                     uint4* __restrict__ a_out, size_t row_u4, int max_count) {
@@ -218,26 +218,59 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
     const int gi = (pxc / N + 1) * (N + 2) + (pxc % N + 1);
     const half8* convW = (const half8*)(wt + TR_WBYTES / 16);
 
-    for (int b = blockIdx.x; b < count; b += gridDim.x) {
-        // conv_in fragments (L2-resident, issued first so they land under the board decode)
+    // Inputs of a sample are fetched one sample ahead, BEFORE the output stores of the current sample are
+    // issued: vmcnt retires in order, so the (younger) stores never sit in front of a load we wait for and
+    // they drain to HBM underneath the next sample's compute.  Barriers below wait for LDS only.
+    struct SampleIn {
+        uint64_t bb[2 * NW];
+        uint32_t aux;
+        int turn;
+        float f[3];
         half8 cwh[4], cwl[4];
+    };
+    auto load_in = [&](int b, uint32_t ref, uint32_t aux) {
+        SampleIn in;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            cwh[m] = convW[m * 64 + lane];
-            cwl[m] = convW[(4 + m) * 64 + lane];
+        for (int m = 0; m < 4; ++m) { // conv_in fragments (L2-resident)
+            in.cwh[m] = convW[m * 64 + lane];
+            in.cwl[m] = convW[(4 + m) * 64 + lane];
         }
+        in.aux = aux;
+        in.turn = 0;
+        in.f[0] = in.f[1] = in.f[2] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2 * NW; ++i) in.bb[i] = 0ULL;
+        if (FROM_F32) {
+            const float* f = in_f32 + (size_t)b * 3 * HW + 3 * pxc;
+            in.f[0] = f[0]; in.f[1] = f[1]; in.f[2] = f[2];
+        } else {
+            const size_t tn = (size_t)(ref >> 16) * (size_t)S.cap_nodes + (size_t)(ref & 0xFFFFu);
+#pragma unroll
+            for (int i = 0; i < 2 * NW; ++i) in.bb[i] = S.board[tn * (2 * NW) + i];
+            in.turn = S.hdr[tn].turn;
+        }
+        return in;
+    };
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    const int b_first = blockIdx.x;
+    uint32_t ref_n = 0, aux_n = 0xFFFFFFFFu;
+    if (!FROM_F32 && b_first < count) { ref_n = S.req_ref[b_first]; aux_n = S.req_aux[b_first]; }
+    SampleIn in = load_in(b_first < count ? b_first : 0, ref_n, aux_n);
+
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        const int b_next = b + (int)gridDim.x;
+        const bool has_next = b_next < count;
+        if (!FROM_F32 && has_next) { ref_n = S.req_ref[b_next]; aux_n = S.req_aux[b_next]; } // used at the end of this sample
         // ---- the pixel's three input floats in the flat encoder.rs layout ----
         float f0, f1, f2;
         if (FROM_F32) {
-            const float* f = in_f32 + (size_t)b * 3 * HW + 3 * pxc;
-            f0 = f[0]; f1 = f[1]; f2 = f[2];
+            f0 = in.f[0]; f1 = in.f[1]; f2 = in.f[2];
         } else {
-            const uint32_t ref = S.req_ref[b], aux = S.req_aux[b];
-            const size_t tn = (size_t)(ref >> 16) * (size_t)S.cap_nodes + (size_t)(ref & 0xFFFFu);
             uint64_t bb[2 * NW];
 #pragma unroll
-            for (int i = 0; i < 2 * NW; ++i) bb[i] = S.board[tn * (2 * NW) + i];
-            int turn = S.hdr[tn].turn, mode = 0;
+            for (int i = 0; i < 2 * NW; ++i) bb[i] = in.bb[i];
+            const uint32_t aux = in.aux;
+            int turn = in.turn, mode = 0;
             if (aux != 0xFFFFFFFFu) { // clone + place_stone(action), Opponent mode (agent.rs:154-158)
                 const int action = (int)(aux & 0xFFFFu);
                 mode = (int)(aux >> 16) & 1;
@@ -274,9 +307,17 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
             }
             f0 = fv[0]; f1 = fv[1]; f2 = fv[2];
         }
+        half8 cwh[4], cwl[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { cwh[m] = in.cwh[m]; cwl[m] = in.cwl[m]; }
         // ---- conv_in 1x1 3->128 + bias + lrelu as one 16-deep k-step: k = (f0, f1, f2, 1, 0...) on lane-half 0 ----
         f32x16 x[4];
-        {
+        if (ABL & 4) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[m][i] = f0 + 0.01f * (float)(i + 16 * m);
+        } else {
             float v[8];
             v[0] = h == 0 ? f0 : 0.0f; v[1] = h == 0 ? f1 : 0.0f; v[2] = h == 0 ? f2 : 0.0f; v[3] = h == 0 ? 1.0f : 0.0f;
             v[4] = 0.0f; v[5] = 0.0f; v[6] = 0.0f; v[7] = 0.0f;
@@ -315,7 +356,12 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                 const half8 ah = W[(0 + ks) * 64 + lane], al = W[(8 + ks) * 64 + lane];
                 MFMA3(ah, al, bh, bl, acc);
             }
-            __syncthreads(); // B1: every wave has read its depthwise result of the previous block
+            float d[16];
+            if (ABL & 1) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) d[i] = lrelu(acc[i]);
+            } else {
+            lds_barrier(); // B1: every wave has read its depthwise result of the previous block
             if (valid) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -325,7 +371,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                     *(f32x4*)(grid + gi * GRID_STRIDE + 8 * g + 4 * h) = o;
                 }
             }
-            __syncthreads(); // B2: h of the whole sample is in the halo grid
+            lds_barrier(); // B2: h of the whole sample is in the halo grid
             // depthwise 3x3 SAME (zero halo), no bias.  Work item = (board row, 4-pixel strip, 4-channel
             // group): one 3x6 window of b128 loads serves 4 output pixels; taps in (dy,dx) order.
             f32x4 dout[TG::DW_ITER][4];
@@ -356,7 +402,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                     dout[it][p] = o;
                 }
             }
-            __syncthreads(); // B3: all windows are in registers; the grid can be overwritten in place
+            lds_barrier(); // B3: all windows are in registers; the grid can be overwritten in place
 #pragma unroll
             for (int it = 0; it < TG::DW_ITER; ++it) {
                 const int item = tid + it * TG::THREADS;
@@ -368,13 +414,13 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                         if (x0 + p < N) *(f32x4*)(grid + ((y + 1) * (N + 2) + x0 + p + 1) * GRID_STRIDE + 4 * cg) = dout[it][p];
                 }
             }
-            __syncthreads(); // B4: depthwise output of the whole sample is in the grid
-            float d[16];
+            lds_barrier(); // B4: depthwise output of the whole sample is in the grid
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 dv = *(const f32x4*)(grid + gi * GRID_STRIDE + 8 * g + 4 * h);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) d[4 * g + i] = dv[i];
+            }
             }
             // L1: pointwise 32 -> 32 + bias + lrelu
             f32x16 accg;
@@ -415,9 +461,10 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                 for (int i = 0; i < 16; ++i) x[m][i] = lrelu(x[m][i]);
             }
         }
+        in = load_in(has_next ? b_next : b, ref_n, aux_n); // next sample's inputs first (see load_in)
         // ---- fc0 operand row: block (tile, m, s) = [pxl 32][hi h0 | hi h1 | lo h0 | lo h1]: a k-step of one sample
         //      is 64 contiguous bytes (one DMA line per row in fc0); the hi and lo stores of a wave fill 2 KiB ----
-        if (valid) {
+        if (valid && !(ABL & 2)) {
             uint4* row = a_out + (size_t)b * row_u4;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -825,11 +872,11 @@ int net_commit(Net& net, hipStream_t st) {
     return 0;
 }
 
-template <int N, bool FROM_F32>
+template <int N, bool FROM_F32, int ABL = 0>
 static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st) {
     using TG = TrunkGeo<N>;
     static bool attr_done = false;
-    auto kern = k_trunk<N, FROM_F32>;
+    auto kern = k_trunk<N, FROM_F32, ABL>;
     if (!attr_done) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TG::LDS_BYTES);
         attr_done = true;
@@ -859,7 +906,15 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     const int ks0 = hw * 8;
     if (prof) prof->begin(PC_TRUNK, st);
     if (net.n == 9) { if (from_f32) launch_trunk<9, true>(net, S, max_count, st); else launch_trunk<9, false>(net, S, max_count, st); }
-    else { if (from_f32) launch_trunk<15, true>(net, S, max_count, st); else launch_trunk<15, false>(net, S, max_count, st); }
+    else {
+        static const int abl = getenv("OMOK_ABL_TRUNK") ? atoi(getenv("OMOK_ABL_TRUNK")) : 0; // timing experiments only
+        if (from_f32 && abl == 1) launch_trunk<15, true, 1>(net, S, max_count, st);
+        else if (from_f32 && abl == 2) launch_trunk<15, true, 2>(net, S, max_count, st);
+        else if (from_f32 && abl == 3) launch_trunk<15, true, 3>(net, S, max_count, st);
+        else if (from_f32 && abl == 7) launch_trunk<15, true, 7>(net, S, max_count, st);
+        else if (from_f32) launch_trunk<15, true>(net, S, max_count, st);
+        else launch_trunk<15, false>(net, S, max_count, st);
+    }
     if (prof) { prof->end(st); prof->begin(PC_FC0, st); }
     const float* bias_fc0 = net.wt_first + TR_SIDE_FLOATS;
     const float* bias_fc1 = bias_fc0 + NF;
