@@ -99,8 +99,8 @@ struct RoundArgs {
 // ---- tree_kernels.hip launchers (all asynchronous on `st`) ---------------------------------
 void launch_reset(int n, const Store& S, const float* root_policy_dev /*ROWP*/, hipStream_t st);
 void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st);
-void launch_scan(int n, const Store& S, int side, hipStream_t st);
-void launch_scatter(int n, const Store& S, int side, const float* p_dev, const float* v_dev, hipStream_t st);
+void launch_scan(int n, const Store& S, int side, int K, hipStream_t st);
+void launch_scatter(int n, const Store& S, int side, const float* p_dev, const float* v_dev, int max_count, hipStream_t st);
 void launch_sample(int n, const Store& S, int side, int ply, float temperature, int threshold, uint64_t seed,
                    int64_t game_offset, int32_t* actions_dev, hipStream_t st);
 void launch_mirror_scan(int n, const Store& S, int side, hipStream_t st);

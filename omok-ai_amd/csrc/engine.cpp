@@ -429,13 +429,13 @@ static void enqueue_round(omok_engine* e, int round, int K, float eps, float alp
     launch_round(e->n, e->S, a, e->st);
     e->prof.end(e->st);
     e->prof.begin(PC_TREE_OTHER, e->st);
-    launch_scan(e->n, e->S, side, e->st);
+    launch_scan(e->n, e->S, side, K, e->st);
     k_add_evals<<<1, 64, 0, e->st>>>(e->S.d_count, e->d_evals);
     e->prof.end(e->st);
     if (eval_and_scatter) {
         net_forward_requests(e->net, e->S, alive * K, e->st, &e->prof);
         e->prof.begin(PC_TREE_OTHER, e->st);
-        launch_scatter(e->n, e->S, side, e->net.p, e->net.v, e->st);
+        launch_scatter(e->n, e->S, side, e->net.p, e->net.v, alive * K, e->st);
         e->prof.end(e->st);
     }
 }
@@ -618,7 +618,7 @@ extern "C" int omok_round_inject(omok_engine* e, const float* p, const float* v)
 extern "C" int omok_round_scatter(omok_engine* e) {
     if (!e) return OMOK_ERR_INVALID;
     if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
-    if (e->round_reqs > 0) launch_scatter(e->n, e->S, e->ply & 1, e->net.p, e->net.v, e->st);
+    if (e->round_reqs > 0) launch_scatter(e->n, e->S, e->ply & 1, e->net.p, e->net.v, e->round_reqs, e->st);
     e->round_reqs = -1;
     return sync_and_check(e, "round_scatter") ? OMOK_ERR_HIP : OMOK_OK;
 }

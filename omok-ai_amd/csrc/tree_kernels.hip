@@ -487,67 +487,80 @@ __global__ __launch_bounds__(64) void k_round(Store S, RoundArgs A) {
 // k_scan: dense, order-preserving request list over the live trees of one side
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_scan(Store S, int side) {
-    __shared__ uint32_t s_part[1024];
-    __shared__ uint32_t s_carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < S.games; base += 1024) {
-        const int g = base + tid;
-        uint32_t cnt = 0;
-        int t = 0;
-        if (g < S.games && S.gs[g].alive) { t = side * S.games + g; cnt = S.ts[t].n_req; }
-        s_part[tid] = cnt;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
-            const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
-            __syncthreads();
-            s_part[tid] += v;
-            __syncthreads();
-        }
-        const uint32_t excl = s_part[tid] - cnt + s_carry;
-        if (cnt) {
-            S.ts[t].req_base = excl;
-            const uint16_t* rq = S.req_node + (size_t)t * KMAX;
-            for (uint32_t r = 0; r < cnt; ++r) {
-                S.req_ref[excl + r] = ((uint32_t)t << 16) | rq[r];
-                S.req_aux[excl + r] = 0xFFFFFFFFu;
-            }
-        }
-        __syncthreads();
-        if (tid == 1023) s_carry += s_part[1023];
-        __syncthreads();
+    // exclusive scan of the per-tree request counts in game order: each thread owns a contiguous chunk of
+    // games, chunk sums are scanned with wave shuffles (64 lanes) and a 16-entry LDS table
+    __shared__ uint32_t s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = (S.games + 1023) / 1024;
+    const int g0 = tid * chunk;
+    uint32_t local = 0;
+    for (int i = 0; i < chunk; ++i) {
+        const int g = g0 + i;
+        if (g < S.games && S.gs[g].alive) local += S.ts[side * S.games + g].n_req;
     }
-    if (tid == 0) S.d_count[0] = (int32_t)s_carry;
+    uint32_t incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t v = s_wave[w];
+        if (w < wave) wbase += v;
+        total += v;
+    }
+    uint32_t run = wbase + incl - local;
+    for (int i = 0; i < chunk; ++i) {
+        const int g = g0 + i;
+        if (g < S.games && S.gs[g].alive) {
+            const int t = side * S.games + g;
+            S.ts[t].req_base = run;
+            run += S.ts[t].n_req;
+        }
+    }
+    if (tid == 0) S.d_count[0] = (int32_t)total;
+}
+
+// dense request list (tree, node) in tree order then simulation order (pme.rs:194-205)
+__global__ __launch_bounds__(256) void k_fill(Store S, int side, int K) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int g = i / K, r = i % K;
+    if (g >= S.games || !S.gs[g].alive) return;
+    const int t = side * S.games + g;
+    const TreeState ts = S.ts[t];
+    if ((uint32_t)r >= ts.n_req) return;
+    S.req_ref[ts.req_base + r] = ((uint32_t)t << 16) | S.req_node[(size_t)t * KMAX + r];
+    S.req_aux[ts.req_base + r] = 0xFFFFFFFFu;
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_scatter (pme.rs:222-265): requests of a tree applied in simulation order
 // ---------------------------------------------------------------------------------------------
+// part 1, one wave per REQUEST (requests are independent here): mask the occupied cells, renormalise with
+// the sequential f32 sum of pme.rs:241-249, overwrite the node's policy row (pme.rs:235-252)
 template <int N>
-__global__ __launch_bounds__(64) void k_scatter(Store S, int side, const float* __restrict__ P, const float* __restrict__ V) {
+__global__ __launch_bounds__(64) void k_scatter_policy(Store S, const float* __restrict__ P, int max_count) {
     using G = Geo<N>;
     constexpr int ROWP = G::ROWP, NW = G::NW;
     __shared__ float s_row[ROWP];
-    const int g = blockIdx.x;
-    if (!S.gs[g].alive) return;
-    const int t = side * S.games + g;
-    const Tree<N> T(S, t);
-    const TreeState ts = *T.ts;
-    if (ts.n_req == 0) return;
+    int count = S.d_count[0];
+    if (count > max_count) count = max_count;
     const int lane = LANE;
-    Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
-    for (uint32_t r = 0; r < ts.n_req; ++r) {
-        const int node = T.req[r];
-        const size_t d = (size_t)ts.req_base + r;
+    for (int d = blockIdx.x; d < count; d += gridDim.x) {
+        const uint32_t ref = S.req_ref[d];
+        const size_t tn = (size_t)(ref >> 16) * (size_t)S.cap_nodes + (size_t)(ref & 0xFFFFu);
         uint64_t occ[NW];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) occ[i] = T.board[(size_t)node * (2 * NW) + i] | T.board[(size_t)node * (2 * NW) + NW + i];
+        for (int i = 0; i < NW; ++i) occ[i] = S.board[tn * (2 * NW) + i] | S.board[tn * (2 * NW) + NW + i];
 #pragma unroll
         for (int j = 0; j < G::IT; ++j) {
             const int a = j * 64 + lane;
             const bool empty = a < G::HW && !((occ[j] >> lane) & 1ULL);
-            s_row[a] = empty ? P[d * ROWP + a] : 0.0f; // pme.rs:235-239
+            s_row[a] = empty ? P[(size_t)d * ROWP + a] : 0.0f; // pme.rs:235-239
         }
         __syncthreads();
         const float sum = seq_sum(s_row, G::HW);
@@ -557,14 +570,30 @@ __global__ __launch_bounds__(64) void k_scatter(Store S, int side, const float* 
         for (int j = 0; j < G::IT; ++j) {
             const int a = j * 64 + lane;
             const float x = s_row[a];
-            T.pol[(size_t)node * ROWP + a] = renorm ? x * inv : x;
+            S.policy[tn * ROWP + a] = renorm ? x * inv : x;
         }
-        if (lane == 0) T.hdr[node].has_policy = 1;
-        backup<N>(T, R, node, -V[d]); // pme.rs:229,264
+        if (lane == 0) S.hdr[tn].has_policy = 1;
+        __syncthreads();
+    }
+}
+
+// part 2, one wave per TREE: backups in simulation order (the f32 sums of w depend on the order), pme.rs:229,264
+template <int N>
+__global__ __launch_bounds__(64) void k_scatter(Store S, int side, const float* __restrict__ V) {
+    using G = Geo<N>;
+    const int g = blockIdx.x;
+    if (!S.gs[g].alive) return;
+    const int t = side * S.games + g;
+    const Tree<N> T(S, t);
+    const TreeState ts = *T.ts;
+    if (ts.n_req == 0) return;
+    Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
+    for (uint32_t r = 0; r < ts.n_req; ++r) {
+        backup<N>(T, R, T.req[r], -V[(size_t)ts.req_base + r]);
         __syncthreads();
         R.bytes += 8ull * G::HW + 4;
     }
-    if (lane == 0) {
+    if (LANE == 0) {
         TreeState o = ts;
         o.root_n = R.root_n; o.root_w = R.root_w; o.n_req = 0;
         *T.ts = o;
@@ -1106,9 +1135,14 @@ void launch_reset(int n, const Store& S, const float* rp, hipStream_t st) {
 void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st) {
     DISPATCH_N(n, (k_round<9><<<S.games, 64, 0, st>>>(S, a)), (k_round<15><<<S.games, 64, 0, st>>>(S, a)));
 }
-void launch_scan(int n, const Store& S, int side, hipStream_t st) { k_scan<<<1, 1024, 0, st>>>(S, side); }
-void launch_scatter(int n, const Store& S, int side, const float* p, const float* v, hipStream_t st) {
-    DISPATCH_N(n, (k_scatter<9><<<S.games, 64, 0, st>>>(S, side, p, v)), (k_scatter<15><<<S.games, 64, 0, st>>>(S, side, p, v)));
+void launch_scan(int n, const Store& S, int side, int K, hipStream_t st) {
+    k_scan<<<1, 1024, 0, st>>>(S, side);
+    k_fill<<<(S.games * K + 255) / 256, 256, 0, st>>>(S, side, K);
+}
+void launch_scatter(int n, const Store& S, int side, const float* p, const float* v, int max_count, hipStream_t st) {
+    const int grid = max_count < 8192 ? (max_count > 0 ? max_count : 1) : 8192;
+    DISPATCH_N(n, (k_scatter_policy<9><<<grid, 64, 0, st>>>(S, p, max_count)), (k_scatter_policy<15><<<grid, 64, 0, st>>>(S, p, max_count)));
+    DISPATCH_N(n, (k_scatter<9><<<S.games, 64, 0, st>>>(S, side, v)), (k_scatter<15><<<S.games, 64, 0, st>>>(S, side, v)));
 }
 void launch_sample(int n, const Store& S, int side, int ply, float temperature, int threshold, uint64_t seed,
                    int64_t game_offset, int32_t* actions, hipStream_t st) {
