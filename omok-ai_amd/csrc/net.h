@@ -34,6 +34,7 @@ struct Net {
     void* h0 = nullptr;       // [max_b][512] hi|lo f16 : fc0 output = fc1 A operand
     size_t row_u4 = 0;        // a_fc0 row stride in uint4
     float* part = nullptr;    // split-K fp32 partials of fc0 for small batches
+    int mx_sw = 0;            // fc0 weights: fp8 copies are w * 2^mx_sw (hi) and (w - f16(w)) * 2^(mx_sw + 11) (lo)
     size_t bytes = 0;         // device bytes held
 };
 

@@ -33,6 +33,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+enum { EPI_SPLIT = 0, EPI_LOGITS = 1, EPI_PARTIAL = 2 }; // GEMM epilogues
+constexpr int GT_BS = 128;                               // samples per GEMM workgroup
+
 __host__ __device__ inline int kperm(int T, int s, int h, int j) { return 32 * T + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 // LeakyRelu alpha 0.2 (TF default) = max(x, 0.2x).  One v_mul + one v_max: fmaxf() would add a
 // canonicalising v_max per operand under IEEE mode.
@@ -174,6 +177,7 @@ constexpr int TR_CONV_FRAGS = 8;
 constexpr int TR_SIDE_PER_BLOCK = 9 * NM + NM + NM + NC; // 480 floats
 constexpr int TR_SIDE_FLOATS = 3 * TR_SIDE_PER_BLOCK;    // 1440
 constexpr int GRID_STRIDE = 36; // floats per halo-grid row (32 + 4 pad: conflict-free b128 reads)
+constexpr int MX_SA = 2;        // fp8 copies of the fc0 operand are x * 2^MX_SA (|x| <= 112 representable; clamped beyond)
 
 template <int N>
 struct TrunkGeo {
@@ -182,7 +186,7 @@ struct TrunkGeo {
     static constexpr int KSTEPS = HW * 8;          // fc0 k-steps (valid pixels only)
     // fc0 operand row: [tile][m][s] blocks of [pxl 32][hi h0|hi h1|lo h0|lo h1] uint4 (+ Net::row_pad so the row
     // stride is not a power of two, which would put every sample row on the same memory channels)
-    static constexpr int ROW_U4 = TILES * 8 * 128;
+    static constexpr int ROW_U4 = TILES * 2 * 32 * 16;
     static constexpr int GRID_ROWS = (N + 2) * (N + 2) + 1; // +1: the 3x6 window of the last strip may touch one row more
     static constexpr int GRID_BYTES = GRID_ROWS * GRID_STRIDE * 4;
     static constexpr int LDS_BYTES = TR_WBYTES + GRID_BYTES + TR_SIDE_FLOATS * 4;
@@ -462,23 +466,208 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
             }
         }
         in = load_in(has_next ? b_next : b, ref_n, aux_n); // next sample's inputs first (see load_in)
-        // ---- fc0 operand row: block (tile, m, s) = [pxl 32][hi h0 | hi h1 | lo h0 | lo h1]: a k-step of one sample
-        //      is 64 contiguous bytes (one DMA line per row in fc0); the hi and lo stores of a wave fill 2 KiB ----
+        // ---- fc0 operand row (k_fc0_mx): block (tile, q) = [pxl 32][256 B], one K=64 super-step per pixel and
+        //      channel half q:  [0,128) f16 hi pieces of k-steps j = 2*(m&1)+s as [h0|h1];  [128,192) fp8 x*2^SA
+        //      as [h0 32 B | h1 32 B];  [192,256) fp8 (x - hi)*2^(SA+11).  Byte slot of a lane = 16*(m&1) + reg. ----
         if (valid && !(ABL & 2)) {
             uint4* row = a_out + (size_t)b * row_u4;
+            const float sc_hi = __uint_as_float((uint32_t)(127 + MX_SA) << 23), sc_lo = __uint_as_float((uint32_t)(127 + MX_SA + 11) << 23);
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int q = 0; q < 2; ++q) {
+                uint4* blkp = row + ((size_t)((tile * 2 + q) * 32 + pxl)) * 16;
+                uint32_t p8h[8], p8l[8];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx) {
+                        union { uint32_t u[4]; uint4 v; } H;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const float v0 = x[2 * q + mm][8 * sx + 2 * jj], v1 = x[2 * q + mm][8 * sx + 2 * jj + 1];
+                            // round-to-nearest hi (not the truncating split8): the fp8 residual term is then half as
+                            // large and unbiased
+                            const _Float16 r0 = (_Float16)v0, r1 = (_Float16)v1;
+                            const float h0 = (float)r0, h1 = (float)r1;
+                            H.u[jj] = (uint32_t)__builtin_bit_cast(unsigned short, r0) | ((uint32_t)__builtin_bit_cast(unsigned short, r1) << 16);
+                            const float a0 = __builtin_amdgcn_fmed3f(v0 * sc_hi, -448.0f, 448.0f), a1 = __builtin_amdgcn_fmed3f(v1 * sc_hi, -448.0f, 448.0f);
+                            const float l0 = __builtin_amdgcn_fmed3f((v0 - h0) * sc_lo, -448.0f, 448.0f), l1 = __builtin_amdgcn_fmed3f((v1 - h1) * sc_lo, -448.0f, 448.0f);
+                            const int slot = 16 * mm + 8 * sx + 2 * jj; // byte slot of v0
+                            const int w = slot >> 2;
+                            if ((slot & 3) == 0) {
+                                p8h[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false);
+                                p8l[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, 0, false);
+                            } else {
+                                p8h[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, (int)p8h[w], true);
+                                p8l[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, (int)p8l[w], true);
+                            }
+                        }
+                        blkp[(mm * 2 + sx) * 2 + h] = H.v;
+                    }
+                blkp[8 + h * 2 + 0] = make_uint4(p8h[0], p8h[1], p8h[2], p8h[3]);
+                blkp[8 + h * 2 + 1] = make_uint4(p8h[4], p8h[5], p8h[6], p8h[7]);
+                blkp[12 + h * 2 + 0] = make_uint4(p8l[0], p8l[1], p8l[2], p8l[3]);
+                blkp[12 + h * 2 + 1] = make_uint4(p8l[4], p8l[5], p8l[6], p8l[7]);
+            }
+        }
+    }
+}
+
+// ===============================================================================================
+// OMOK_NET_F16X3: fc0 with block-scaled fp8 correction terms
+// ===============================================================================================
+// x*w = hi*hi (f16 MFMA) + lo*hi + hi*lo, the two correction terms on v_mfma_scale_f32_32x32x64_f8f6f4 with fp8
+// (e4m3) operands: they are 2^-11 of the product, so 3 mantissa bits keep the total at ~2^-15 relative
+// (tools/precision_study.py: max|dp| 4e-5), and per K=64 the matrix pipe executes 4 f16 + 2 fp8 MFMAs
+// instead of 12 f16 MFMAs (2.1x less pipe time, tools/probe/mx_rate.hip).  Operand layout probed on the device
+// (tools/probe/mx_probe.hip): lane = row/col, 32 bytes per lane, k-slots pair by (lane-half, byte); the E8M0
+// scale byte multiplies the result by 2^(byte-127).
+//
+// Tile = 512 features x 128 samples per workgroup, 8 waves.  A K=64 super-step is consumed in 4 stages, one per
+// group of 4 m-tiles: weights (32 KiB per stage) flow through a 3-slot LDS ring, the sample operands of a
+// super-step (32 KiB) are double-buffered and shared by its 4 stages.  Wave (wm, ws) owns m-tile 4g+wm of every
+// group g and sample tiles {2ws, 2ws+1}.
+typedef int v8i __attribute__((ext_vector_type(8)));
+constexpr int MXS_W_U4 = 32 * 64;   // uint4 per weight stage (32 fragments)
+constexpr int MXS_A_U4 = 32 * 64;   // uint4 per sample-operand buffer (4 tiles x 8 fragments)
+
+struct MxScales { int wa_hi, wa_lo, ab_hi, ab_lo; }; // E8M0 bytes: weights (A operand) hi/lo, activations (B operand) hi/lo
+
+template <int EPI>
+__global__ __launch_bounds__(512) void k_fc0_mx(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksup,
+                                                size_t act_row_u4, int full_tiles, int last_cnt, MxScales sc,
+                                                const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
+                                                float* __restrict__ out_part, const int32_t* __restrict__ d_count, int max_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* ldsA = (uint4*)smem;               // [2][4 ct][8 frag][64]
+    uint4* ldsW = ldsA + 2 * MXS_A_U4;        // [3][4 i][8 frag][64]
+    int count = d_count[0];
+    if (count > max_count) count = max_count;
+    const int b0 = blockIdx.x * GT_BS;
+    if (b0 >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, ws = wave & 1;
+    const int h = lane >> 5;
+    const int ubeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksup : 0;
+
+    // uint4 offset of super-step u inside a sample row: blocks (tile, q) of [pxl 32][16 uint4]
+    auto uoff = [&](int u) {
+        const int full = full_tiles * 64;
+        int tile, q, pl;
+        if (u < full) { tile = u >> 6; q = (u >> 5) & 1; pl = u & 31; }
+        else { const int r = u - full; tile = full_tiles; q = r / last_cnt; pl = r % last_cnt; }
+        return ((tile * 2 + q) * 32 + pl) * 16;
+    };
+    const uint4* wsrc = wp + (size_t)ubeg * 4 * MXS_W_U4 + (size_t)wave * 64 + lane; // + stage*MXS_W_U4 + k*8*64
+    auto issue_w = [&](int stage_local, int slot) { // 4 of the 32 weight fragments of a stage
+        const uint4* g = wsrc + (size_t)stage_local * MXS_W_U4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 8 * 64),
+                                             (__attribute__((address_space(3))) void*)(ldsW + slot * MXS_W_U4 + (wave + 8 * k) * 64),
+                                             16, 0, 0);
+    };
+    // sample-operand fragments: f < 4: f16 piece j = f at +f*2 + h;  f = 4,5: fp8 hi halves at +8 + h*2 + (f-4);
+    // f = 6,7: fp8 lo halves at +12 + h*2 + (f-6).  Lane (c = lane&31, h) reads sample row b0 + 32*ct + c.
+    auto frag_off = [&](int f) { return f < 4 ? f * 2 + h : (f < 6 ? 8 + h * 2 + (f - 4) : 12 + h * 2 + (f - 6)); };
+    auto issue_a = [&](int u, int buf, int ct0) { // the 16 fragments of sample tiles ct0, ct0+1: 2 per wave
+        const int uo = uoff(u);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int fi = wave + 8 * k; // 0..15
+            const int ct = ct0 + (fi >> 3), f = fi & 7;
+            const uint4* g = act + (size_t)(b0 + 32 * ct + (lane & 31)) * act_row_u4 + uo + frag_off(f);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(ldsA + buf * MXS_A_U4 + (ct * 8 + f) * 64),
+                                             16, 0, 0);
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
+
+    // prologue: sample operands of the first super-step, weight stages 0 and 1
+    issue_a(ubeg, 0, 0);
+    issue_a(ubeg, 0, 2);
+    issue_w(0, 0);
+    issue_w(1, 1);
+    int slot = 0, nslot = 2;
+    for (int ul = 0; ul < ksup; ++ul) {
+        const int ub = ul & 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // in-order retirement: everything except what the PREVIOUS stage issued must have landed
+            if (g == 0 || g == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_w(ul * 4 + g + 2, nslot);                      // ring slot last read one stage ago (padded past the end)
+            if (g == 0) issue_a(ubeg + ul + 1, ub ^ 1, 0);          // next super-step's operands: buffer last read one
+            if (g == 1) issue_a(ubeg + ul + 1, ub ^ 1, 2);          // super-step ago (rows are padded past the end)
+            const uint4* LW = ldsW + slot * MXS_W_U4 + (wm * 8) * 64 + lane;
+            half8 ah[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ah[j] = *(const half8*)(LW + j * 64);
+            union { uint4 q[2]; v8i v; } w8h, w8l;
+            w8h.q[0] = LW[4 * 64]; w8h.q[1] = LW[5 * 64];
+            w8l.q[0] = LW[6 * 64]; w8l.q[1] = LW[7 * 64];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint4* LA = ldsA + ub * MXS_A_U4 + ((2 * ws + c) * 8) * 64 + lane;
+                union { uint4 q[2]; v8i v; } a8h, a8l;
+                a8h.q[0] = LA[4 * 64]; a8h.q[1] = LA[5 * 64];
+                a8l.q[0] = LA[6 * 64]; a8l.q[1] = LA[7 * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[g][c] = MFMA16(ah[j], *(const half8*)(LA + j * 64), acc[g][c]);
+                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8h.v, a8l.v, acc[g][c], 0, 0, 0, sc.wa_hi, 0, sc.ab_lo);
+                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8l.v, a8h.v, acc[g][c], 0, 0, 0, sc.wa_lo, 0, sc.ab_hi);
+            }
+            slot = slot == 2 ? 0 : slot + 1;
+            nslot = nslot == 2 ? 0 : nslot + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue (m-tile of accumulator g is 4g + wm) ----
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int sample = b0 + 32 * (2 * ws + c) + (lane & 31);
+        if (sample >= count) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int mt = 4 * g + wm;
+            if (EPI == EPI_PARTIAL) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = acc[g][c][4 * q4 + q];
+                    *(f32x4*)(out_part + ((size_t)blockIdx.y * out_row_u4 + sample) * NF + 32 * mt + 8 * q4 + 4 * h) = o;
+                }
+            } else {
+                float y[16];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 bv = *(const f32x4*)(bias + 32 * mt + 8 * q4 + 4 * h);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) y[4 * q4 + q] = acc[g][c][4 * q4 + q] + bv[q];
+                }
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = x[m][8 * s + j];
+                    for (int j = 0; j < 8; ++j) v[j] = lrelu(y[8 * sx + j]);
                     half8 hi, lo;
                     split8(v, hi, lo);
-                    uint4* blkp = row + ((tile * 4 + m) * 2 + s) * 128 + pxl * 4 + h;
-                    blkp[0] = *(const uint4*)&hi;
-                    blkp[2] = *(const uint4*)&lo;
+                    uint4* row = out_split + (size_t)sample * out_row_u4 + (size_t)(2 * mt + sx) * 4;
+                    row[h] = *(const uint4*)&hi;
+                    row[2 + h] = *(const uint4*)&lo;
                 }
+            }
         }
     }
 }
@@ -488,9 +677,6 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
 // ===============================================================================================
 // Wp : [ksteps][MT][hi|lo][lane][8] f16 (1 KiB fragments), Act: rows of [ksteps][hi h0|hi h1|lo h0|lo h1]
 // 8 waves: wm = wave>>1 owns MT/4 m-tiles, ws = wave&1 owns 2 of the 4 sample tiles.
-enum { EPI_SPLIT = 0, EPI_LOGITS = 1, EPI_PARTIAL = 2 };
-constexpr int GT_BS = 128;
-constexpr int GT_STAGES = 3;
 
 template <int MT, int EPI, int TAG, int NST, int PRIO>
 __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksteps,
@@ -729,6 +915,31 @@ static void pack_A(std::vector<_Float16>& out, int ksteps, int MT, GetW getw, KI
                 }
 }
 
+// float -> OCP fp8 e4m3fn, round to nearest even, saturating at +-448
+static uint8_t to_e4m3(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80);
+    float a = fabsf(x);
+    if (!(a == a)) return 0x7f;
+    if (a >= 448.0f) return sign | 0x7e;
+    if (a < 0.0009765625f) return sign; // below half of the smallest subnormal (2^-9): rounds to 0
+    int e;
+    const float m = frexpf(a, &e); // a = m * 2^e, m in [0.5, 1)
+    int E = e - 1;                 // a = (2m) * 2^E, 2m in [1,2)
+    if (E < -6) { // subnormal: units of 2^-9
+        const float q = a * 512.0f;
+        int r = (int)lrintf(q);
+        if (r >= 8) return sign | 0x08; // rounds up to the smallest normal
+        return sign | (uint8_t)r;
+    }
+    const float frac = (2.0f * m - 1.0f) * 8.0f; // [0,8)
+    int r = (int)lrintf(frac);
+    if (r == 8) { r = 0; E += 1; }
+    if (E > 8 || (E == 8 && r > 6)) return sign | 0x7e;
+    return sign | (uint8_t)(((E + 7) << 3) | r);
+}
+
 static int heads_mt(int hw) { return ((hw + 1 + 31) / 32 + 3) / 4 * 4; }
 
 size_t net_alloc(Net& net) {
@@ -757,11 +968,11 @@ size_t net_alloc(Net& net) {
         ok = ok && A((void**)&net.s1, sizeof(float) * c * NF);
     } else {
         const size_t ks0 = hw * 8;
-        net.row_u4 = (size_t)((hw + 31) / 32) * 8 * 128 + (getenv("OMOK_ROWPAD_U4") ? atoi(getenv("OMOK_ROWPAD_U4")) : 80);
+        net.row_u4 = (size_t)((hw + 31) / 32) * 2 * 32 * 16 + (getenv("OMOK_ROWPAD_U4") ? atoi(getenv("OMOK_ROWPAD_U4")) : 80);
         const size_t row_u4 = net.row_u4;
         ok = ok && A(&net.wt_trunk, TR_WBYTES + TR_CONV_FRAGS * 1024);
         ok = ok && A((void**)&net.wt_first, sizeof(float) * (TR_SIDE_FLOATS + 2 * NF + heads_mt(net.hw) * 32));
-        ok = ok && A(&net.wt_fc0, ks0 * 16 * 2 * 1024);
+        ok = ok && A(&net.wt_fc0, ks0 * 16 * 2 * 1024 + 2 * 32 * 1024); // + 2 stages of padding (k_fc0_mx prefetches past the end)
         ok = ok && A(&net.wt_fc1, (size_t)32 * 16 * 2 * 1024);
         ok = ok && A(&net.wt_heads, (size_t)32 * heads_mt(net.hw) * 2 * 1024);
         ok = ok && A(&net.a_fc0, mb * row_u4 * 16);
@@ -833,22 +1044,49 @@ int net_commit(Net& net, hipStream_t st) {
     memcpy(bias_fc1, T[26].data(), sizeof(float) * NF);
     memcpy(bias_heads, T[30].data(), sizeof(float) * hw);
     bias_heads[hw] = T[28][0];
-    // ---- fc0: k-steps enumerate (tile, m, s, pixel-in-tile) over the valid pixels, matching the trunk's
-    //      operand row; source row of fc0_w = px*128 + kperm(m, s, h, j) (flatten index (y*N+x)*128 + c) ----
+    // ---- fc0 (k_fc0_mx): super-steps (K = 64 = one pixel x 64 channels) enumerate (tile, q, pixel-in-tile) over
+    //      the valid pixels; stage (u, g) = 32 fragments: [i: m-tile 4g+i][hi j0..j3 | w_hi8 half0, half1 | w_lo8
+    //      half0, half1].  Source row of fc0_w = px*128 + 32*m + kperm-order channel (flatten index (y*N+x)*128+c). ----
     std::vector<_Float16> pk;
     {
         const float* w = T[23].data();
         const int tiles = (hw + 31) / 32;
-        std::vector<int> kpx, km, ks_;
+        float wmax = 0.0f;
+        for (size_t i = 0; i < T[23].size(); ++i) wmax = fmaxf(wmax, fabsf(w[i]));
+        int SW = wmax > 0.0f ? (int)floorf(log2f(240.0f / wmax)) : 0;
+        if (SW < -20) SW = -20;
+        if (SW > 40) SW = 40;
+        net.mx_sw = SW;
+        std::vector<uint8_t> buf;
+        std::vector<int> upx, uq;
         for (int tile = 0; tile < tiles; ++tile)
-            for (int m = 0; m < 4; ++m)
-                for (int s2 = 0; s2 < 2; ++s2)
-                    for (int pl = 0; pl < 32 && tile * 32 + pl < hw; ++pl) {
-                        kpx.push_back(tile * 32 + pl); km.push_back(m); ks_.push_back(s2);
+            for (int q = 0; q < 2; ++q)
+                for (int pl = 0; pl < 32 && tile * 32 + pl < hw; ++pl) { upx.push_back(tile * 32 + pl); uq.push_back(q); }
+        const size_t nsup = upx.size();
+        buf.assign((nsup * 4 + 2) * 32 * 1024, 0);
+        const float s_hi = ldexpf(1.0f, SW), s_lo = ldexpf(1.0f, SW + 11);
+        for (size_t u = 0; u < nsup; ++u)
+            for (int g = 0; g < 4; ++g)
+                for (int i = 0; i < 4; ++i) {
+                    uint8_t* st = buf.data() + ((u * 4 + g) * 32 + (size_t)i * 8) * 1024;
+                    const int mt = 4 * g + i;
+                    for (int l = 0; l < 64; ++l) {
+                        const int r = l & 31, hh = l >> 5, n = 32 * mt + r;
+                        for (int slot = 0; slot < 32; ++slot) { // byte slot = 16*(m&1) + reg, reg = 8*s + jj
+                            const int mm = slot >> 4, reg = slot & 15;
+                            const int m = 2 * uq[u] + mm;
+                            const size_t k = (size_t)upx[u] * NC + kperm(m, reg >> 3, hh, reg & 7);
+                            const float wv = w[k * NF + n];
+                            const _Float16 wh = (_Float16)wv;
+                            const float wl = wv - (float)wh;
+                            const int j = 2 * mm + (reg >> 3), jj = reg & 7; // f16 piece j, element jj
+                            memcpy(st + (size_t)j * 1024 + (size_t)l * 16 + jj * 2, &wh, 2);
+                            st[(size_t)(4 + (slot >> 4)) * 1024 + (size_t)l * 16 + (slot & 15)] = to_e4m3((float)wh * s_hi);
+                            st[(size_t)(6 + (slot >> 4)) * 1024 + (size_t)l * 16 + (slot & 15)] = to_e4m3(wl * s_lo);
+                        }
                     }
-        pack_A(pk, hw * 8, 16, [&](int k, int m) { return w[(size_t)k * NF + m]; },
-               [&](int ks, int h, int j) { return kpx[ks] * NC + kperm(km[ks], ks_[ks], h, j); });
-        if (hipMemcpyAsync(net.wt_fc0, pk.data(), pk.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+                }
+        if (hipMemcpyAsync(net.wt_fc0, buf.data(), buf.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
         hipStreamSynchronize(st);
     }
     {
@@ -924,18 +1162,36 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     uint4* h1 = h0 + mb * 128; // 32 k-steps * 4 uint4 per row
     // fc0.  Small batches (late plies of an episode) cannot fill 256 CUs with 128-sample tiles: split K over
     // blockIdx.y into fp32 partials and finish (sum in split order + bias + LeakyReLU + hi|lo) in a second kernel.
-    const int nsplit = max_count > 16384 ? 1 : (max_count > 8192 ? 2 : (max_count > 4096 ? 4 : 8));
-    if (nsplit == 1) {
-        launch_gemm<16, EPI_SPLIT, 0, 4, 0>(net.wt_fc0, net.a_fc0, ks0, net.row_u4, (hw / 32) * 256, (hw % 32) ? (hw % 32) : 1, 2,
-                                             bias_fc0, h0, 128, nullptr, S, max_count, st);
-    } else {
-        const size_t cap_rows = 16384 / nsplit * 2; // rows per split slab (>= padded max_count)
-        launch_gemm<16, EPI_PARTIAL, 3, 4, 0>(net.wt_fc0, net.a_fc0, ks0 / nsplit, net.row_u4, (hw / 32) * 256,
-                                               (hw % 32) ? (hw % 32) : 1, 2, bias_fc0, nullptr, cap_rows, net.part, S, max_count, st,
-                                               nsplit);
-        const size_t threads = (size_t)max_count * 64;
-        k_splitk_finish<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(net.part, nsplit, cap_rows, bias_fc0, h0, 128, S.d_count,
-                                                                            max_count);
+    {
+        const int nsup = hw * 2;
+        const int tiles128 = (max_count + GT_BS - 1) / GT_BS;
+        int nsplit = 1;
+        if (max_count <= 16384) { // largest divisor of nsup that keeps <= ~256 workgroups and fits the partial slab
+            const int want = 256 / (tiles128 > 0 ? tiles128 : 1);
+            for (int d = 2; d <= 16 && d <= want; ++d)
+                if (nsup % d == 0 && (size_t)d * (size_t)(tiles128 * GT_BS) <= (size_t)2 * 16384) nsplit = d;
+        }
+        const MxScales sc{127 - net.mx_sw, 127 - (net.mx_sw + 11), 127 - MX_SA, 127 - (MX_SA + 11)};
+        constexpr int LDS = (2 * MXS_A_U4 + 3 * MXS_W_U4) * 16;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute((const void*)k_fc0_mx<EPI_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            hipFuncSetAttribute((const void*)k_fc0_mx<EPI_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            attr_done = true;
+        }
+        if (nsplit == 1) {
+            k_fc0_mx<EPI_SPLIT><<<dim3(tiles128, 1), 512, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4,
+                                                                      hw / 32, (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr,
+                                                                      S.d_count, max_count);
+        } else {
+            const size_t cap_rows = (size_t)tiles128 * GT_BS;
+            k_fc0_mx<EPI_PARTIAL><<<dim3(tiles128, nsplit), 512, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0,
+                                                                            nsup / nsplit, net.row_u4, hw / 32, (hw % 32) ? (hw % 32) : 1, sc,
+                                                                            bias_fc0, nullptr, cap_rows, net.part, S.d_count, max_count);
+            const size_t threads = (size_t)max_count * 64;
+            k_splitk_finish<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(net.part, nsplit, cap_rows, bias_fc0, h0, 128, S.d_count,
+                                                                                max_count);
+        }
     }
     if (prof) { prof->end(st); prof->begin(PC_TAIL, st); }
     launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st);
