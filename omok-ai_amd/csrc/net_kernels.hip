@@ -467,15 +467,15 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
         }
         in = load_in(has_next ? b_next : b, ref_n, aux_n); // next sample's inputs first (see load_in)
         // ---- fc0 operand row (k_fc0_mx): block (tile, q) = [pxl 32][256 B], one K=64 super-step per pixel and
-        //      channel half q:  [0,128) f16 hi pieces of k-steps j = 2*(m&1)+s as [h0|h1];  [128,192) fp8 x*2^SA
-        //      as [h0 32 B | h1 32 B];  [192,256) fp8 (x - hi)*2^(SA+11).  Byte slot of a lane = 16*(m&1) + reg. ----
+        //      channel half q:  [0,128) f16 hi pieces of k-steps j = 2*(m&1)+s as [h0|h1];  [128,192) unused (the fp8 copy of x
+        //      is derived from the f16 pieces inside k_fc0_mx);  [192,256) fp8 (x - hi)*2^(SA+11) as [h0 32 B | h1 32 B].  Byte slot of a lane = 16*(m&1) + reg. ----
         if (valid && !(ABL & 2)) {
             uint4* row = a_out + (size_t)b * row_u4;
-            const float sc_hi = __uint_as_float((uint32_t)(127 + MX_SA) << 23), sc_lo = __uint_as_float((uint32_t)(127 + MX_SA + 11) << 23);
+            const float sc_lo = __uint_as_float((uint32_t)(127 + MX_SA + 11) << 23);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 uint4* blkp = row + ((size_t)((tile * 2 + q) * 32 + pxl)) * 16;
-                uint32_t p8h[8], p8l[8];
+                uint32_t p8l[8];
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
@@ -489,22 +489,17 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                             const _Float16 r0 = (_Float16)v0, r1 = (_Float16)v1;
                             const float h0 = (float)r0, h1 = (float)r1;
                             H.u[jj] = (uint32_t)__builtin_bit_cast(unsigned short, r0) | ((uint32_t)__builtin_bit_cast(unsigned short, r1) << 16);
-                            const float a0 = __builtin_amdgcn_fmed3f(v0 * sc_hi, -448.0f, 448.0f), a1 = __builtin_amdgcn_fmed3f(v1 * sc_hi, -448.0f, 448.0f);
                             const float l0 = __builtin_amdgcn_fmed3f((v0 - h0) * sc_lo, -448.0f, 448.0f), l1 = __builtin_amdgcn_fmed3f((v1 - h1) * sc_lo, -448.0f, 448.0f);
                             const int slot = 16 * mm + 8 * sx + 2 * jj; // byte slot of v0
                             const int w = slot >> 2;
                             if ((slot & 3) == 0) {
-                                p8h[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false);
                                 p8l[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, 0, false);
                             } else {
-                                p8h[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, (int)p8h[w], true);
                                 p8l[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, (int)p8l[w], true);
                             }
                         }
                         blkp[(mm * 2 + sx) * 2 + h] = H.v;
                     }
-                blkp[8 + h * 2 + 0] = make_uint4(p8h[0], p8h[1], p8h[2], p8h[3]);
-                blkp[8 + h * 2 + 1] = make_uint4(p8h[4], p8h[5], p8h[6], p8h[7]);
                 blkp[12 + h * 2 + 0] = make_uint4(p8l[0], p8l[1], p8l[2], p8l[3]);
                 blkp[12 + h * 2 + 1] = make_uint4(p8l[4], p8l[5], p8l[6], p8l[7]);
             }
@@ -527,19 +522,34 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
 // super-step (32 KiB) are double-buffered and shared by its 4 stages.  Wave (wm, ws) owns m-tile 4g+wm of every
 // group g and sample tiles {2ws, 2ws+1}.
 typedef int v8i __attribute__((ext_vector_type(8)));
-constexpr int MXS_W_U4 = 32 * 64;   // uint4 per weight stage (32 fragments)
-constexpr int MXS_A_U4 = 32 * 64;   // uint4 per sample-operand buffer (4 tiles x 8 fragments)
+constexpr int MXS_FR = 24;              // fragments per weight stage (4 m-tiles x {hi j0..j3, lo8 half0, half1}) and per
+constexpr int MXS_U4 = MXS_FR * 64;     // sample-operand buffer (4 sample tiles x the same 6); uint4 units
+constexpr int MXS_SLOTS = 4;            // weight ring depth: three stages stay in flight behind the one being read
 
-struct MxScales { int wa_hi, wa_lo, ab_hi, ab_lo; }; // E8M0 bytes: weights (A operand) hi/lo, activations (B operand) hi/lo
+struct MxScales { int wa_hi, wa_lo, ab_hi, ab_lo; float w_mul, a_mul; }; // E8M0 bytes (A = weights, B = samples) + 2^SW, 2^SA
 
-template <int EPI>
+// fp8 (e4m3) copy of 8 f16 values * mul, as 2 dwords (the k-slots 8j..8j+7 of a lane).  The hi*lo / lo*hi correction
+// terms only need ~3 bits, so the fp8 "hi" operands are derived from the f16 fragments on the otherwise idle VALU
+// instead of being streamed (25 % fewer bytes through the LDS-DMA path, which bounds this kernel).
+__device__ inline void f16x8_to_fp8(const half8& v, float mul, bool clamp, uint32_t& d0, uint32_t& d1) {
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f[j] = (float)v[j] * mul;
+        if (clamp) f[j] = __builtin_amdgcn_fmed3f(f[j], -448.0f, 448.0f);
+    }
+    d0 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false), true);
+    d1 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false), true);
+}
+
+template <int EPI, int DBG = 0> // DBG: timing-only ablations (1 no fp8 derivation, 2 no sample DMA, 4 no weight DMA, 8 no barrier, 16 no MFMA)
 __global__ __launch_bounds__(512) void k_fc0_mx(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksup,
                                                 size_t act_row_u4, int full_tiles, int last_cnt, MxScales sc,
                                                 const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
                                                 float* __restrict__ out_part, const int32_t* __restrict__ d_count, int max_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* ldsA = (uint4*)smem;               // [2][4 ct][8 frag][64]
-    uint4* ldsW = ldsA + 2 * MXS_A_U4;        // [3][4 i][8 frag][64]
+    uint4* ldsA = (uint4*)smem;               // [2][4 ct][6 frag][64]
+    uint4* ldsW = ldsA + 2 * MXS_U4;          // [MXS_SLOTS][4 i][6 frag][64]
     int count = d_count[0];
     if (count > max_count) count = max_count;
     const int b0 = blockIdx.x * GT_BS;
@@ -558,27 +568,27 @@ __global__ __launch_bounds__(512) void k_fc0_mx(const uint4* __restrict__ wp, co
         else { const int r = u - full; tile = full_tiles; q = r / last_cnt; pl = r % last_cnt; }
         return ((tile * 2 + q) * 32 + pl) * 16;
     };
-    const uint4* wsrc = wp + (size_t)ubeg * 4 * MXS_W_U4 + (size_t)wave * 64 + lane; // + stage*MXS_W_U4 + k*8*64
-    auto issue_w = [&](int stage_local, int slot) { // 4 of the 32 weight fragments of a stage
-        const uint4* g = wsrc + (size_t)stage_local * MXS_W_U4;
+    const uint4* wsrc = wp + (size_t)ubeg * 4 * MXS_U4 + (size_t)wave * 64 + lane;
+    auto issue_w = [&](int stage_local, int slot) { // 3 of the 24 weight fragments of a stage
+        const uint4* g = wsrc + (size_t)stage_local * MXS_U4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 3; ++k)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 8 * 64),
-                                             (__attribute__((address_space(3))) void*)(ldsW + slot * MXS_W_U4 + (wave + 8 * k) * 64),
+                                             (__attribute__((address_space(3))) void*)(ldsW + slot * MXS_U4 + (wave + 8 * k) * 64),
                                              16, 0, 0);
     };
-    // sample-operand fragments: f < 4: f16 piece j = f at +f*2 + h;  f = 4,5: fp8 hi halves at +8 + h*2 + (f-4);
-    // f = 6,7: fp8 lo halves at +12 + h*2 + (f-6).  Lane (c = lane&31, h) reads sample row b0 + 32*ct + c.
-    auto frag_off = [&](int f) { return f < 4 ? f * 2 + h : (f < 6 ? 8 + h * 2 + (f - 4) : 12 + h * 2 + (f - 6)); };
-    auto issue_a = [&](int u, int buf, int ct0) { // the 16 fragments of sample tiles ct0, ct0+1: 2 per wave
+    // sample-operand fragments: f < 4: f16 piece j = f at +f*2 + h;  f = 4,5: fp8 residual halves at +12 + h*2 + (f-4).
+    // Lane (c = lane&31, h) reads sample row b0 + 32*ct + c.
+    auto issue_a = [&](int u, int buf) { // the 24 fragments of a super-step: 3 per wave
         const int uo = uoff(u);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int fi = wave + 8 * k; // 0..15
-            const int ct = ct0 + (fi >> 3), f = fi & 7;
-            const uint4* g = act + (size_t)(b0 + 32 * ct + (lane & 31)) * act_row_u4 + uo + frag_off(f);
+        for (int k = 0; k < 3; ++k) {
+            const int fi = wave + 8 * k; // 0..23
+            const int ct = fi / 6, f = fi % 6;
+            const int fo = f < 4 ? f * 2 + h : 12 + h * 2 + (f - 4);
+            const uint4* g = act + (size_t)(b0 + 32 * ct + (lane & 31)) * act_row_u4 + uo + fo;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(ldsA + buf * MXS_A_U4 + (ct * 8 + f) * 64),
+                                             (__attribute__((address_space(3))) void*)(ldsA + buf * MXS_U4 + fi * 64),
                                              16, 0, 0);
         }
     };
@@ -590,44 +600,68 @@ __global__ __launch_bounds__(512) void k_fc0_mx(const uint4* __restrict__ wp, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
 
-    // prologue: sample operands of the first super-step, weight stages 0 and 1
-    issue_a(ubeg, 0, 0);
-    issue_a(ubeg, 0, 2);
+    // prologue: sample operands of the first super-step, weight stages 0..2
+    issue_a(ubeg, 0);
     issue_w(0, 0);
     issue_w(1, 1);
-    int slot = 0, nslot = 2;
+    issue_w(2, 2);
+    int slot = 0, nslot = 3;
     for (int ul = 0; ul < ksup; ++ul) {
         const int ub = ul & 1;
+        v8i a8h[2]; // fp8 copies of this wave's two sample tiles, derived once per super-step
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            // in-order retirement: everything except what the PREVIOUS stage issued must have landed
-            if (g == 0 || g == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            // vmcnt retires in order: everything except what the previous TWO stages issued must have landed
+            // (per-wave issue counts per stage: g = 0: 3 W + 3 A, else 3 W)
+            if (DBG & 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (g == 0 || g == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            issue_w(ul * 4 + g + 2, nslot);                      // ring slot last read one stage ago (padded past the end)
-            if (g == 0) issue_a(ubeg + ul + 1, ub ^ 1, 0);          // next super-step's operands: buffer last read one
-            if (g == 1) issue_a(ubeg + ul + 1, ub ^ 1, 2);          // super-step ago (rows are padded past the end)
-            const uint4* LW = ldsW + slot * MXS_W_U4 + (wm * 8) * 64 + lane;
+            if (!(DBG & 4)) issue_w(ul * 4 + g + 3, nslot);  // ring slot last read one stage ago (stream padded past the end)
+            else { asm volatile("s_nop 0" ::: "memory"); }
+            if (g == 0 && !(DBG & 2)) issue_a(ubeg + ul + 1, ub ^ 1); // buffer last read one super-step ago (rows padded past the end)
+            const uint4* LW = ldsW + slot * MXS_U4 + (wm * 6) * 64 + lane;
             half8 ah[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) ah[j] = *(const half8*)(LW + j * 64);
-            union { uint4 q[2]; v8i v; } w8h, w8l;
-            w8h.q[0] = LW[4 * 64]; w8h.q[1] = LW[5 * 64];
-            w8l.q[0] = LW[6 * 64]; w8l.q[1] = LW[7 * 64];
+            union { uint4 q[2]; v8i v; } w8l;
+            w8l.q[0] = LW[4 * 64]; w8l.q[1] = LW[5 * 64];
+            v8i w8h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t d0, d1;
+                if (DBG & 1) { d0 = w8l.q[0].x + j; d1 = w8l.q[1].y; } else f16x8_to_fp8(ah[j], sc.w_mul, false, d0, d1);
+                w8h[2 * j] = (int)d0; w8h[2 * j + 1] = (int)d1;
+            }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const uint4* LA = ldsA + ub * MXS_A_U4 + ((2 * ws + c) * 8) * 64 + lane;
-                union { uint4 q[2]; v8i v; } a8h, a8l;
-                a8h.q[0] = LA[4 * 64]; a8h.q[1] = LA[5 * 64];
-                a8l.q[0] = LA[6 * 64]; a8l.q[1] = LA[7 * 64];
+                const uint4* LA = ldsA + ub * MXS_U4 + ((2 * ws + c) * 6) * 64 + lane;
+                half8 bh[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g][c] = MFMA16(ah[j], *(const half8*)(LA + j * 64), acc[g][c]);
-                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8h.v, a8l.v, acc[g][c], 0, 0, 0, sc.wa_hi, 0, sc.ab_lo);
-                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8l.v, a8h.v, acc[g][c], 0, 0, 0, sc.wa_lo, 0, sc.ab_hi);
+                for (int j = 0; j < 4; ++j) bh[j] = *(const half8*)(LA + j * 64);
+                union { uint4 q[2]; v8i v; } a8l;
+                a8l.q[0] = LA[4 * 64]; a8l.q[1] = LA[5 * 64];
+                if (g == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        uint32_t d0, d1;
+                        if (DBG & 1) { d0 = a8l.q[0].x + j; d1 = a8l.q[1].y; } else f16x8_to_fp8(bh[j], sc.a_mul, true, d0, d1);
+                        a8h[c][2 * j] = (int)d0; a8h[c][2 * j + 1] = (int)d1;
+                    }
+                }
+                if (DBG & 16) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[g][c][r] += (float)ah[r & 3][r & 7] * (float)bh[r & 3][0] + (float)(w8h[r & 7] ^ a8l.v[r & 7]) + (float)(w8l.v[r & 7] ^ a8h[c][r & 7]);
+                } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[g][c] = MFMA16(ah[j], bh[j], acc[g][c]);
+                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8h, a8l.v, acc[g][c], 0, 0, 0, sc.wa_hi, 0, sc.ab_lo);
+                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8l.v, a8h[c], acc[g][c], 0, 0, 0, sc.wa_lo, 0, sc.ab_hi);
+                }
             }
-            slot = slot == 2 ? 0 : slot + 1;
-            nslot = nslot == 2 ? 0 : nslot + 1;
+            slot = slot == MXS_SLOTS - 1 ? 0 : slot + 1;
+            nslot = nslot == MXS_SLOTS - 1 ? 0 : nslot + 1;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -972,7 +1006,7 @@ size_t net_alloc(Net& net) {
         const size_t row_u4 = net.row_u4;
         ok = ok && A(&net.wt_trunk, TR_WBYTES + TR_CONV_FRAGS * 1024);
         ok = ok && A((void**)&net.wt_first, sizeof(float) * (TR_SIDE_FLOATS + 2 * NF + heads_mt(net.hw) * 32));
-        ok = ok && A(&net.wt_fc0, ks0 * 16 * 2 * 1024 + 2 * 32 * 1024); // + 2 stages of padding (k_fc0_mx prefetches past the end)
+        ok = ok && A(&net.wt_fc0, (ks0 + 3) * (size_t)MXS_FR * 1024); // hw*2 super-steps x 4 stages (= ks0) + 3 stages of padding
         ok = ok && A(&net.wt_fc1, (size_t)32 * 16 * 2 * 1024);
         ok = ok && A(&net.wt_heads, (size_t)32 * heads_mt(net.hw) * 2 * 1024);
         ok = ok && A(&net.a_fc0, mb * row_u4 * 16);
@@ -1063,12 +1097,12 @@ int net_commit(Net& net, hipStream_t st) {
             for (int q = 0; q < 2; ++q)
                 for (int pl = 0; pl < 32 && tile * 32 + pl < hw; ++pl) { upx.push_back(tile * 32 + pl); uq.push_back(q); }
         const size_t nsup = upx.size();
-        buf.assign((nsup * 4 + 2) * 32 * 1024, 0);
-        const float s_hi = ldexpf(1.0f, SW), s_lo = ldexpf(1.0f, SW + 11);
+        buf.assign((nsup * 4 + 3) * MXS_FR * 1024, 0);
+        const float s_lo = ldexpf(1.0f, SW + 11);
         for (size_t u = 0; u < nsup; ++u)
             for (int g = 0; g < 4; ++g)
                 for (int i = 0; i < 4; ++i) {
-                    uint8_t* st = buf.data() + ((u * 4 + g) * 32 + (size_t)i * 8) * 1024;
+                    uint8_t* st = buf.data() + ((u * 4 + g) * MXS_FR + (size_t)i * 6) * 1024;
                     const int mt = 4 * g + i;
                     for (int l = 0; l < 64; ++l) {
                         const int r = l & 31, hh = l >> 5, n = 32 * mt + r;
@@ -1081,8 +1115,7 @@ int net_commit(Net& net, hipStream_t st) {
                             const float wl = wv - (float)wh;
                             const int j = 2 * mm + (reg >> 3), jj = reg & 7; // f16 piece j, element jj
                             memcpy(st + (size_t)j * 1024 + (size_t)l * 16 + jj * 2, &wh, 2);
-                            st[(size_t)(4 + (slot >> 4)) * 1024 + (size_t)l * 16 + (slot & 15)] = to_e4m3((float)wh * s_hi);
-                            st[(size_t)(6 + (slot >> 4)) * 1024 + (size_t)l * 16 + (slot & 15)] = to_e4m3(wl * s_lo);
+                            st[(size_t)(4 + (slot >> 4)) * 1024 + (size_t)l * 16 + (slot & 15)] = to_e4m3(wl * s_lo);
                         }
                     }
                 }
@@ -1171,8 +1204,8 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
             for (int d = 2; d <= 16 && d <= want; ++d)
                 if (nsup % d == 0 && (size_t)d * (size_t)(tiles128 * GT_BS) <= (size_t)2 * 16384) nsplit = d;
         }
-        const MxScales sc{127 - net.mx_sw, 127 - (net.mx_sw + 11), 127 - MX_SA, 127 - (MX_SA + 11)};
-        constexpr int LDS = (2 * MXS_A_U4 + 3 * MXS_W_U4) * 16;
+        const MxScales sc{127 - net.mx_sw, 127 - (net.mx_sw + 11), 127 - MX_SA, 127 - (MX_SA + 11), ldexpf(1.0f, net.mx_sw), ldexpf(1.0f, MX_SA)};
+        constexpr int LDS = (2 + MXS_SLOTS) * MXS_U4 * 16;
         static bool attr_done = false;
         if (!attr_done) {
             hipFuncSetAttribute((const void*)k_fc0_mx<EPI_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1180,6 +1213,11 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
             attr_done = true;
         }
         if (nsplit == 1) {
+            static const int dbg = getenv("OMOK_DBG_FC0") ? atoi(getenv("OMOK_DBG_FC0")) : 0; // timing experiments only
+#define FC0_DBG_CASE(D) else if (dbg == D) { hipFuncSetAttribute((const void*)k_fc0_mx<EPI_SPLIT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); k_fc0_mx<EPI_SPLIT, D><<<dim3(tiles128, 1), 512, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32, (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr, S.d_count, max_count); }
+            if (false) {}
+            FC0_DBG_CASE(1) FC0_DBG_CASE(2) FC0_DBG_CASE(4) FC0_DBG_CASE(6) FC0_DBG_CASE(8) FC0_DBG_CASE(16) FC0_DBG_CASE(14) FC0_DBG_CASE(17)
+            else
             k_fc0_mx<EPI_SPLIT><<<dim3(tiles128, 1), 512, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4,
                                                                       hw / 32, (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr,
                                                                       S.d_count, max_count);
