@@ -542,8 +542,13 @@ __device__ inline void f16x8_to_fp8(const half8& v, float mul, bool clamp, uint3
     d1 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false), true);
 }
 
-template <int EPI, int DBG = 0> // DBG: timing-only ablations (1 no fp8 derivation, 2 no sample DMA, 4 no weight DMA, 8 no barrier, 16 no MFMA)
-__global__ __launch_bounds__(512) void k_fc0_mx(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksup,
+// Workgroup = 4 waves (one per SIMD, each with the full 512-register file): wave w owns m-tile 4g+w of every
+// group g for ALL four sample tiles, i.e. 16 accumulator tiles (256 registers).  The sample operands of a
+// super-step are read from LDS once and stay in registers for its 4 stages; a weight fragment is read from LDS by
+// exactly one wave.  LDS traffic per stage drops from 144 KiB (8-wave form) to ~48 KiB and the matrix pipe is fed
+// by one wave with 4 independent accumulator chains.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksup,
                                                 size_t act_row_u4, int full_tiles, int last_cnt, MxScales sc,
                                                 const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
                                                 float* __restrict__ out_part, const int32_t* __restrict__ d_count, int max_count) {
@@ -555,13 +560,11 @@ __global__ __launch_bounds__(512) void k_fc0_mx(const uint4* __restrict__ wp, co
     const int b0 = blockIdx.x * GT_BS;
     if (b0 >= count) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, ws = wave & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // 0..3 = m-tile inside a group
     const int h = lane >> 5;
     const int ubeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksup : 0;
 
-    // uint4 offset of super-step u inside a sample row: blocks (tile, q) of [pxl 32][16 uint4]
-    auto uoff = [&](int u) {
+    auto uoff = [&](int u) { // uint4 offset of super-step u inside a sample row: blocks (tile, q) of [pxl 32][16 uint4]
         const int full = full_tiles * 64;
         int tile, q, pl;
         if (u < full) { tile = u >> 6; q = (u >> 5) & 1; pl = u & 31; }
@@ -569,111 +572,117 @@ __global__ __launch_bounds__(512) void k_fc0_mx(const uint4* __restrict__ wp, co
         return ((tile * 2 + q) * 32 + pl) * 16;
     };
     const uint4* wsrc = wp + (size_t)ubeg * 4 * MXS_U4 + (size_t)wave * 64 + lane;
-    auto issue_w = [&](int stage_local, int slot) { // 3 of the 24 weight fragments of a stage
-        const uint4* g = wsrc + (size_t)stage_local * MXS_U4;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + k * 8 * 64),
-                                             (__attribute__((address_space(3))) void*)(ldsW + slot * MXS_U4 + (wave + 8 * k) * 64),
-                                             16, 0, 0);
+    auto issue_w1 = [&](int stage_local, int slot, int k) { // fragment wave + 4k of the stage's 24 (k = 0..5)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)stage_local * MXS_U4 + k * 4 * 64),
+                                         (__attribute__((address_space(3))) void*)(ldsW + slot * MXS_U4 + (wave + 4 * k) * 64), 16, 0, 0);
     };
-    // sample-operand fragments: f < 4: f16 piece j = f at +f*2 + h;  f = 4,5: fp8 residual halves at +12 + h*2 + (f-4).
-    // Lane (c = lane&31, h) reads sample row b0 + 32*ct + c.
-    auto issue_a = [&](int u, int buf) { // the 24 fragments of a super-step: 3 per wave
-        const int uo = uoff(u);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int fi = wave + 8 * k; // 0..23
-            const int ct = fi / 6, f = fi % 6;
-            const int fo = f < 4 ? f * 2 + h : 12 + h * 2 + (f - 4);
-            const uint4* g = act + (size_t)(b0 + 32 * ct + (lane & 31)) * act_row_u4 + uo + fo;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(ldsA + buf * MXS_U4 + fi * 64),
-                                             16, 0, 0);
-        }
+    // sample-operand fragments: f < 4: f16 piece j = f at +f*2 + h;  f = 4,5: fp8 residual halves at +12 + h*2 + (f-4)
+    auto issue_a1 = [&](int uo, int buf, int k) { // fragment wave + 4k of the super-step's 24 (k = 0..5)
+        const int fi = wave + 4 * k, ct = fi / 6, f = fi % 6;
+        const int fo = f < 4 ? f * 2 + h : 12 + h * 2 + (f - 4);
+        const uint4* g = act + (size_t)(b0 + 32 * ct + (lane & 31)) * act_row_u4 + uo + fo;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(ldsA + buf * MXS_U4 + fi * 64), 16, 0, 0);
     };
-    f32x16 acc[4][2];
+    f32x16 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
 
-    // prologue: sample operands of the first super-step, weight stages 0..2
-    issue_a(ubeg, 0);
-    issue_w(0, 0);
-    issue_w(1, 1);
-    issue_w(2, 2);
+    { // prologue: sample operands of the first super-step, weight stages 0..2  (per wave: 6 + 18 DMA instructions)
+        const int uo = uoff(ubeg);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) issue_a1(uo, 0, k);
+#pragma unroll
+        for (int st = 0; st < 3; ++st)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) issue_w1(st, st, k);
+    }
+    half8 bh[4][4];  // sample operands of the current super-step (f16 pieces)
+    v8i a8l[4], a8h[4];
     int slot = 0, nslot = 3;
     for (int ul = 0; ul < ksup; ++ul) {
         const int ub = ul & 1;
-        v8i a8h[2]; // fp8 copies of this wave's two sample tiles, derived once per super-step
+        const int uo_next = uoff(ubeg + ul + 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             // vmcnt retires in order: everything except what the previous TWO stages issued must have landed
-            // (per-wave issue counts per stage: g = 0: 3 W + 3 A, else 3 W)
-            if (DBG & 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (g == 0 || g == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
+            // (per-wave issue counts per stage: g = 0: 6 W + 6 A, else 6 W)
+            if (g == 0 || g == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (!(DBG & 4)) issue_w(ul * 4 + g + 3, nslot);  // ring slot last read one stage ago (stream padded past the end)
-            else { asm volatile("s_nop 0" ::: "memory"); }
-            if (g == 0 && !(DBG & 2)) issue_a(ubeg + ul + 1, ub ^ 1); // buffer last read one super-step ago (rows padded past the end)
-            const uint4* LW = ldsW + slot * MXS_U4 + (wm * 6) * 64 + lane;
+            const uint4* LW = ldsW + slot * MXS_U4 + (wave * 6) * 64 + lane;
             half8 ah[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) ah[j] = *(const half8*)(LW + j * 64);
             union { uint4 q[2]; v8i v; } w8l;
             w8l.q[0] = LW[4 * 64]; w8l.q[1] = LW[5 * 64];
+            if (g == 0) { // this super-step's sample operands: LDS -> registers, once
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint4* LA = ldsA + ub * MXS_U4 + (c * 6) * 64 + lane;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bh[c][j] = *(const half8*)(LA + j * 64);
+                    union { uint4 q[2]; v8i v; } t;
+                    t.q[0] = LA[4 * 64]; t.q[1] = LA[5 * 64];
+                    a8l[c] = t.v;
+                }
+            }
+            // f16 main products first: they only need the LDS reads; the fp8 derivations run on the VALU underneath
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[g][c] = MFMA16(ah[j], bh[c][j], acc[g][c]);
+                // staging of stage q+3 (its ring slot was last read one stage ago) and, at g = 0, of the next
+                // super-step's sample operands (buffer last read one super-step ago), spread between the MFMAs
+                issue_w1(ul * 4 + g + 3, nslot, j);
+                if (j < 2) issue_w1(ul * 4 + g + 3, nslot, 4 + j);
+                if (g == 0) {
+                    issue_a1(uo_next, ub ^ 1, j);
+                    if (j < 2) issue_a1(uo_next, ub ^ 1, 4 + j);
+                }
+            }
             v8i w8h;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 uint32_t d0, d1;
-                if (DBG & 1) { d0 = w8l.q[0].x + j; d1 = w8l.q[1].y; } else f16x8_to_fp8(ah[j], sc.w_mul, false, d0, d1);
+                f16x8_to_fp8(ah[j], sc.w_mul, false, d0, d1);
                 w8h[2 * j] = (int)d0; w8h[2 * j + 1] = (int)d1;
             }
+            if (g == 0) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const uint4* LA = ldsA + ub * MXS_U4 + ((2 * ws + c) * 6) * 64 + lane;
-                half8 bh[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bh[j] = *(const half8*)(LA + j * 64);
-                union { uint4 q[2]; v8i v; } a8l;
-                a8l.q[0] = LA[4 * 64]; a8l.q[1] = LA[5 * 64];
-                if (g == 0) {
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         uint32_t d0, d1;
-                        if (DBG & 1) { d0 = a8l.q[0].x + j; d1 = a8l.q[1].y; } else f16x8_to_fp8(bh[j], sc.a_mul, true, d0, d1);
+                        f16x8_to_fp8(bh[c][j], sc.a_mul, true, d0, d1);
                         a8h[c][2 * j] = (int)d0; a8h[c][2 * j + 1] = (int)d1;
                     }
-                }
-                if (DBG & 16) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[g][c][r] += (float)ah[r & 3][r & 7] * (float)bh[r & 3][0] + (float)(w8h[r & 7] ^ a8l.v[r & 7]) + (float)(w8l.v[r & 7] ^ a8h[c][r & 7]);
-                } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[g][c] = MFMA16(ah[j], bh[j], acc[g][c]);
-                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8h, a8l.v, acc[g][c], 0, 0, 0, sc.wa_hi, 0, sc.ab_lo);
-                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8l.v, a8h[c], acc[g][c], 0, 0, 0, sc.wa_lo, 0, sc.ab_hi);
-                }
             }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8h, a8l[c], acc[g][c], 0, 0, 0, sc.wa_hi, 0, sc.ab_lo);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8l.v, a8h[c], acc[g][c], 0, 0, 0, sc.wa_lo, 0, sc.ab_hi);
             slot = slot == MXS_SLOTS - 1 ? 0 : slot + 1;
             nslot = nslot == MXS_SLOTS - 1 ? 0 : nslot + 1;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue (m-tile of accumulator g is 4g + wm) ----
+    // ---- epilogue (accumulator g = m-tile 4g + wave) ----
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int sample = b0 + 32 * (2 * ws + c) + (lane & 31);
+    for (int c = 0; c < 4; ++c) {
+        const int sample = b0 + 32 * c + (lane & 31);
         if (sample >= count) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int mt = 4 * g + wm;
+            const int mt = 4 * g + wave;
             if (EPI == EPI_PARTIAL) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
@@ -1213,17 +1222,12 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
             attr_done = true;
         }
         if (nsplit == 1) {
-            static const int dbg = getenv("OMOK_DBG_FC0") ? atoi(getenv("OMOK_DBG_FC0")) : 0; // timing experiments only
-#define FC0_DBG_CASE(D) else if (dbg == D) { hipFuncSetAttribute((const void*)k_fc0_mx<EPI_SPLIT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); k_fc0_mx<EPI_SPLIT, D><<<dim3(tiles128, 1), 512, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32, (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr, S.d_count, max_count); }
-            if (false) {}
-            FC0_DBG_CASE(1) FC0_DBG_CASE(2) FC0_DBG_CASE(4) FC0_DBG_CASE(6) FC0_DBG_CASE(8) FC0_DBG_CASE(16) FC0_DBG_CASE(14) FC0_DBG_CASE(17)
-            else
-            k_fc0_mx<EPI_SPLIT><<<dim3(tiles128, 1), 512, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4,
+            k_fc0_mx<EPI_SPLIT><<<dim3(tiles128, 1), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4,
                                                                       hw / 32, (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr,
                                                                       S.d_count, max_count);
         } else {
             const size_t cap_rows = (size_t)tiles128 * GT_BS;
-            k_fc0_mx<EPI_PARTIAL><<<dim3(tiles128, nsplit), 512, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0,
+            k_fc0_mx<EPI_PARTIAL><<<dim3(tiles128, nsplit), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0,
                                                                             nsup / nsplit, net.row_u4, hw / 32, (hw % 32) ? (hw % 32) : 1, sc,
                                                                             bias_fc0, nullptr, cap_rows, net.part, S.d_count, max_count);
             const size_t threads = (size_t)max_count * 64;
