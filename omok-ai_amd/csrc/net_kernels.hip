@@ -522,6 +522,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
 // super-step (32 KiB) are double-buffered and shared by its 4 stages.  Wave (wm, ws) owns m-tile 4g+wm of every
 // group g and sample tiles {2ws, 2ws+1}.
 typedef int v8i __attribute__((ext_vector_type(8)));
+#define VMCNT(n) ((((n) & 15) | (((n) >> 4) << 14)) | (7 << 4) | (15 << 8)) // s_waitcnt immediate: vmcnt(n) only
 constexpr int MXS_FR = 24;              // fragments per weight stage (4 m-tiles x {hi j0..j3, lo8 half0, half1}) and per
 constexpr int MXS_U4 = MXS_FR * 64;     // sample-operand buffer (4 sample tiles x the same 6); uint4 units
 constexpr int MXS_SLOTS = 4;            // weight ring depth: three stages stay in flight behind the one being read
@@ -531,15 +532,27 @@ struct MxScales { int wa_hi, wa_lo, ab_hi, ab_lo; float w_mul, a_mul; }; // E8M0
 // fp8 (e4m3) copy of 8 f16 values * mul, as 2 dwords (the k-slots 8j..8j+7 of a lane).  The hi*lo / lo*hi correction
 // terms only need ~3 bits, so the fp8 "hi" operands are derived from the f16 fragments on the otherwise idle VALU
 // instead of being streamed (25 % fewer bytes through the LDS-DMA path, which bounds this kernel).
-__device__ inline void f16x8_to_fp8(const half8& v, float mul, bool clamp, uint32_t& d0, uint32_t& d1) {
-    float f[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        f[j] = (float)v[j] * mul;
-        if (clamp) f[j] = __builtin_amdgcn_fmed3f(f[j], -448.0f, 448.0f);
-    }
-    d0 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false), true);
-    d1 = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false), true);
+__device__ inline v8i v8_from(const uint4& a, const uint4& b) {
+    return v8i{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, (int)b.z, (int)b.w};
+}
+// LDS-DMA as inline asm: hipcc's waitcnt pass orders every later ds_read against builtin LDS-DMA with vmcnt(0),
+// which drains the whole prefetch ring once per stage; issued from asm the pass does not see it and the counted
+// waits below (also asm) are the only ordering.  m0 = LDS byte address of lane 0's 16 bytes.
+__device__ inline void dma16(const uint4* g, const uint4* lds) {
+    const uint32_t a = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(a) : "memory", "m0");
+}
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ inline void f16x8_to_fp8(const half8& v, float inv_mul, uint32_t& d0, uint32_t& d1) {
+    // v_cvt_scalef32_pk_fp8_f16: fp8(x / scale), RNE, two values per instruction (tools/probe/cvt_probe.hip)
+    short2v r0 = {0, 0}, r1 = {0, 0};
+    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, half2v{v[0], v[1]}, inv_mul, false);
+    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, half2v{v[2], v[3]}, inv_mul, true);
+    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, half2v{v[4], v[5]}, inv_mul, false);
+    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, half2v{v[6], v[7]}, inv_mul, true);
+    d0 = __builtin_bit_cast(uint32_t, r0);
+    d1 = __builtin_bit_cast(uint32_t, r1);
 }
 
 // Workgroup = 4 waves (one per SIMD, each with the full 512-register file): wave w owns m-tile 4g+w of every
@@ -552,9 +565,12 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
                                                 size_t act_row_u4, int full_tiles, int last_cnt, MxScales sc,
                                                 const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
                                                 float* __restrict__ out_part, const int32_t* __restrict__ d_count, int max_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* ldsA = (uint4*)smem;               // [2][4 ct][6 frag][64]
-    uint4* ldsW = ldsA + 2 * MXS_U4;          // [MXS_SLOTS][4 i][6 frag][64]
+    // Static LDS objects, one per weight-ring slot: hipcc orders a ds_read after an LDS-DMA write by object (alias
+    // scopes of distinct LDS variables), and with one dynamic array it drains ALL outstanding DMA (vmcnt(0)) before
+    // the first LDS read of every stage.  With separate objects it waits exactly for the last DMA into the slot read.
+    __shared__ uint4 ldsA[2 * MXS_U4];        // [2][4 ct][6 frag][64]
+    __shared__ uint4 ldsW0[MXS_U4], ldsW1[MXS_U4], ldsW2[MXS_U4], ldsW3[MXS_U4]; // [4 i][6 frag][64] each
+    auto ring = [&](int slot) -> uint4* { return slot == 0 ? ldsW0 : slot == 1 ? ldsW1 : slot == 2 ? ldsW2 : ldsW3; };
     int count = d_count[0];
     if (count > max_count) count = max_count;
     const int b0 = blockIdx.x * GT_BS;
@@ -571,19 +587,28 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
         else { const int r = u - full; tile = full_tiles; q = r / last_cnt; pl = r % last_cnt; }
         return ((tile * 2 + q) * 32 + pl) * 16;
     };
-    const uint4* wsrc = wp + (size_t)ubeg * 4 * MXS_U4 + (size_t)wave * 64 + lane;
-    auto issue_w1 = [&](int stage_local, int slot, int k) { // fragment wave + 4k of the stage's 24 (k = 0..5)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)stage_local * MXS_U4 + k * 4 * 64),
-                                         (__attribute__((address_space(3))) void*)(ldsW + slot * MXS_U4 + (wave + 4 * k) * 64), 16, 0, 0);
+    // a wave stages exactly the 6 weight fragments it consumes (m-tile `wave` of the stage's group): the weight ring is
+    // wave-private, ordered by this wave's own vmcnt, and needs no workgroup barrier
+    const uint4* wsrc = wp + (size_t)ubeg * 4 * MXS_U4 + (size_t)(wave * 6) * 64 + lane;
+    // LDS offsets of this wave's fragments, as opaque values: the LDS-DMA store is modelled as 4 bytes at the M0
+    // address, and when the compiler can prove that a ds_read does not overlap THAT it stops ordering the read
+    // against the slot's DMA and falls back to "wait for every DMA" (vmcnt(0))
+    int w_dma_off = wave * 6 * 64, w_rd_off = wave * 6 * 64 + lane;
+    asm volatile("" : "+s"(w_dma_off));
+    asm volatile("" : "+v"(w_rd_off));
+    auto issue_w1 = [&](int stage_local, int slot, int k) { // fragment k of this wave's 6
+        dma16(wsrc + (size_t)stage_local * MXS_U4 + k * 64, ring(slot) + w_dma_off + k * 64);
     };
     // sample-operand fragments: f < 4: f16 piece j = f at +f*2 + h;  f = 4,5: fp8 residual halves at +12 + h*2 + (f-4)
     auto issue_a1 = [&](int uo, int buf, int k) { // fragment wave + 4k of the super-step's 24 (k = 0..5)
         const int fi = wave + 4 * k, ct = fi / 6, f = fi % 6;
         const int fo = f < 4 ? f * 2 + h : 12 + h * 2 + (f - 4);
         const uint4* g = act + (size_t)(b0 + 32 * ct + (lane & 31)) * act_row_u4 + uo + fo;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(ldsA + buf * MXS_U4 + fi * 64), 16, 0, 0);
+        dma16(g, ldsA + buf * MXS_U4 + fi * 64);
     };
+    // fp8 conversions saturate to +-448 instead of producing NaN (MODE.FP16_OVFL, probed: tools/probe/cvt_probe.hip)
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+    const float w_inv = 1.0f / sc.w_mul, a_inv = 1.0f / sc.a_mul; // powers of two
     f32x16 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -592,6 +617,9 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
 
+    half8 bh[4][4];  // sample operands of the current super-step (f16 pieces)
+    v8i a8l[4], a8h[4];
+    uint4 wc[6];     // this wave's weight fragments of the current stage
     { // prologue: sample operands of the first super-step, weight stages 0..2  (per wave: 6 + 18 DMA instructions)
         const int uo = uoff(ubeg);
 #pragma unroll
@@ -600,80 +628,94 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
         for (int st = 0; st < 3; ++st)
 #pragma unroll
             for (int k = 0; k < 6; ++k) issue_w1(st, st, k);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); // A(0) and W(0) landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bh[c][j] = *(const half8*)(ldsA + (c * 6 + j) * 64 + lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a8l[c] = v8_from(ldsA[(c * 6 + 4) * 64 + lane], ldsA[(c * 6 + 5) * 64 + lane]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wc[k] = ldsW0[w_rd_off + k * 64];
     }
-    half8 bh[4][4];  // sample operands of the current super-step (f16 pieces)
-    v8i a8l[4], a8h[4];
-    int slot = 0, nslot = 3;
+    // Stage q = (ul, g) lives in ring slot g.  During stage q: the matrix pipe works on wc; the DMA of stage q+3 is
+    // issued into slot (g+3)&3 (read during stage q-2, consumed by the MFMAs of stage q-1); the fragments of stage q+1
+    // are read from LDS into registers behind the block-scaled MFMAs.  One workgroup barrier per super-step (top of
+    // g = 3): behind it the NEXT super-step's sample operands replace the current ones in registers piece by piece,
+    // each right after its last MFMA.
     for (int ul = 0; ul < ksup; ++ul) {
         const int ub = ul & 1;
         const int uo_next = uoff(ubeg + ul + 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            // vmcnt retires in order: everything except what the previous TWO stages issued must have landed
-            // (per-wave issue counts per stage: g = 0: 6 W + 6 A, else 6 W)
-            if (g == 0 || g == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const uint4* LW = ldsW + slot * MXS_U4 + (wave * 6) * 64 + lane;
             half8 ah[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ah[j] = *(const half8*)(LW + j * 64);
-            union { uint4 q[2]; v8i v; } w8l;
-            w8l.q[0] = LW[4 * 64]; w8l.q[1] = LW[5 * 64];
-            if (g == 0) { // this super-step's sample operands: LDS -> registers, once
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint4* LA = ldsA + ub * MXS_U4 + (c * 6) * 64 + lane;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bh[c][j] = *(const half8*)(LA + j * 64);
-                    union { uint4 q[2]; v8i v; } t;
-                    t.q[0] = LA[4 * 64]; t.q[1] = LA[5 * 64];
-                    a8l[c] = t.v;
-                }
+            for (int j = 0; j < 4; ++j) ah[j] = __builtin_bit_cast(half8, wc[j]);
+            const v8i w8l = v8_from(wc[4], wc[5]);
+            v8i w8h;
+            if (g == 3) { // every wave's share of A(ul+1) must have landed before anyone reads it: issued during stage
+                          // g = 0 with A before W in each slot, so 1 + 6 + 6 later loads may still be in flight
+                asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
             }
-            // f16 main products first: they only need the LDS reads; the fp8 derivations run on the VALU underneath
+            const uint4* LAn = ldsA + (ub ^ 1) * MXS_U4 + lane;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[g][c] = MFMA16(ah[j], bh[c][j], acc[g][c]);
-                // staging of stage q+3 (its ring slot was last read one stage ago) and, at g = 0, of the next
-                // super-step's sample operands (buffer last read one super-step ago), spread between the MFMAs
-                issue_w1(ul * 4 + g + 3, nslot, j);
-                if (j < 2) issue_w1(ul * 4 + g + 3, nslot, 4 + j);
-                if (g == 0) {
+                if (g == 0) { // next super-step's sample operands (buffer last read during stage (ul-1, 3))
                     issue_a1(uo_next, ub ^ 1, j);
                     if (j < 2) issue_a1(uo_next, ub ^ 1, 4 + j);
                 }
-            }
-            v8i w8h;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
+                issue_w1(ul * 4 + g + 3, (g + 3) & 3, j);
+                if (j < 2) issue_w1(ul * 4 + g + 3, (g + 3) & 3, 4 + j);
                 uint32_t d0, d1;
-                f16x8_to_fp8(ah[j], sc.w_mul, false, d0, d1);
+                f16x8_to_fp8(ah[j], w_inv, d0, d1);
                 w8h[2 * j] = (int)d0; w8h[2 * j + 1] = (int)d1;
-            }
-            if (g == 0) {
+                if (g == 0) { // fp8 copies of this super-step's f16 pieces
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        uint32_t d0, d1;
-                        f16x8_to_fp8(bh[c][j], sc.a_mul, true, d0, d1);
+                    for (int c = 0; c < 4; ++c) {
+                        f16x8_to_fp8(bh[c][j], a_inv, d0, d1);
                         a8h[c][2 * j] = (int)d0; a8h[c][2 * j + 1] = (int)d1;
                     }
+                }
+                if (g == 3) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bh[c][j] = *(const half8*)(LAn + (c * 6 + j) * 64);
+                }
+                // the machine scheduler otherwise sinks the DMA issues and the register prefetches to their first
+                // use, which serialises the whole pipeline: pin every j-step
+                __builtin_amdgcn_sched_barrier(0);
             }
+            // stage q+1's weights (issued during stage q-2): everything but the loads of stages q-1 and q has landed.
+            // The wait goes through the builtin so that hipcc's own LDS-DMA tracking sees it; with an opaque asm wait
+            // it adds a vmcnt(0) in front of the ds_reads and drains the whole ring every stage.
+            if (g < 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            uint4 wn[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wn[k] = ring((g + 1) & 3)[w_rd_off + k * 64];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8h, a8l[c], acc[g][c], 0, 0, 0, sc.wa_hi, 0, sc.ab_lo);
+            if (g == 3) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a8l[c] = v8_from(LAn[(c * 6 + 4) * 64], LAn[(c * 6 + 5) * 64]);
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8l.v, a8h[c], acc[g][c], 0, 0, 0, sc.wa_lo, 0, sc.ab_hi);
-            slot = slot == MXS_SLOTS - 1 ? 0 : slot + 1;
-            nslot = nslot == MXS_SLOTS - 1 ? 0 : nslot + 1;
+                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8l, a8h[c], acc[g][c], 0, 0, 0, sc.wa_lo, 0, sc.ab_hi);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wc[k] = wn[k];
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0");
 
     // ---- epilogue (accumulator g = m-tile 4g + wave) ----
 #pragma unroll
@@ -1214,13 +1256,7 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
                 if (nsup % d == 0 && (size_t)d * (size_t)(tiles128 * GT_BS) <= (size_t)2 * 16384) nsplit = d;
         }
         const MxScales sc{127 - net.mx_sw, 127 - (net.mx_sw + 11), 127 - MX_SA, 127 - (MX_SA + 11), ldexpf(1.0f, net.mx_sw), ldexpf(1.0f, MX_SA)};
-        constexpr int LDS = (2 + MXS_SLOTS) * MXS_U4 * 16;
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipFuncSetAttribute((const void*)k_fc0_mx<EPI_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            hipFuncSetAttribute((const void*)k_fc0_mx<EPI_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            attr_done = true;
-        }
+        constexpr int LDS = 0; // static LDS objects: (2 + MXS_SLOTS) x 24 KiB
         if (nsplit == 1) {
             k_fc0_mx<EPI_SPLIT><<<dim3(tiles128, 1), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4,
                                                                       hw / 32, (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr,
