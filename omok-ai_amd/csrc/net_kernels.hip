@@ -46,24 +46,43 @@ __device__ inline float lrelu(float x) {
     return r;
 }
 
-typedef __fp16 half2r __attribute__((ext_vector_type(2)));
-// x = hi + lo with hi = x truncated to 11 significant bits (exactly an f16 in the normal range)
-// and lo = f16(x - hi): 3 VALU per value (and, sub, half a packed convert each for hi and lo).
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// x = hi + lo with hi = f16(x) (v_cvt_pk_f16_f32, round to nearest: two values per instruction) and
+// lo = f16(x - hi) computed by ONE mixed-precision fma per value (v_fma_mix{lo,hi}_f16 reads hi as f16 and x as
+// f32 and writes the f16 half directly): 1.5 VALU per value.  The trunk is VALU-bound, not MFMA-bound.
 __device__ inline void split8(const float* v, half8& hi, half8& lo) {
     union { uint32_t u[4]; half8 h; } H, L;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float a = v[2 * j], b = v[2 * j + 1];
-        const float ah = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u);
-        const float bh = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
-        const half2r ph = __builtin_amdgcn_cvt_pkrtz(ah, bh);
-        const half2r pl = __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh);
-        H.u[j] = *(const uint32_t*)&ph;
-        L.u[j] = *(const uint32_t*)&pl;
+        const uint32_t ph = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, half2v));
+        uint32_t pl;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(pl) : "v"(ph), "v"(a));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(pl) : "v"(ph), "v"(b));
+        H.u[j] = ph;
+        L.u[j] = pl;
     }
     hi = H.h;
     lo = L.h;
 }
+// LeakyRelu on a pair: one packed multiply + two v_max
+__device__ inline f32x2 lrelu2(float a, float b) {
+    const f32x2 y = (f32x2){a, b} * 0.2f;
+    f32x2 r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r[0]) : "v"(a), "v"(y[0]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(r[1]) : "v"(b), "v"(y[1]));
+    return r;
+}
+#define LRELU16(X)                                           \
+    do {                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; i_ += 2) { \
+            const f32x2 r_ = lrelu2((X)[i_], (X)[i_ + 1]);   \
+            (X)[i_] = r_[0];                                 \
+            (X)[i_ + 1] = r_[1];                             \
+        }                                                    \
+    } while (0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define MFMA3(ah, al, bh, bl, c)   \
     do {                           \
@@ -208,6 +227,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
     const float* lside = (const float*)(smem + TR_WBYTES + TG::GRID_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, tile = tid >> 6;
     const int h = lane >> 5;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); // fp8 / f16 conversions saturate (MODE.FP16_OVFL)
     // ---- one-time: weights, side table, zero halo grid ----
     for (int i = tid; i < TR_WBYTES / 16; i += blockDim.x) ((uint4*)smem)[i] = wt[i];
     for (int i = tid; i < TR_SIDE_FLOATS; i += blockDim.x) ((float*)lside)[i] = side[i];
@@ -332,8 +352,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
 #pragma unroll
                 for (int i = 0; i < 16; ++i) x[m][i] = 0.0f;
                 MFMA3(cwh[m], cwl[m], bh, bl, x[m]);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) x[m][i] = lrelu(x[m][i]);
+                LRELU16(x[m]);
             }
         }
         // ---- 3 bottleneck residual blocks ----
@@ -370,8 +389,8 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = lrelu(acc[4 * g + i]);
+                    const f32x2 r0 = lrelu2(acc[4 * g], acc[4 * g + 1]), r1 = lrelu2(acc[4 * g + 2], acc[4 * g + 3]);
+                    o[0] = r0[0]; o[1] = r0[1]; o[2] = r1[0]; o[3] = r1[1];
                     *(f32x4*)(grid + gi * GRID_STRIDE + 8 * g + 4 * h) = o;
                 }
             }
@@ -444,7 +463,8 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
             // L2: 1x1 32 -> 128 + bias + residual (accumulated onto x), lrelu
             float gv[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) gv[i] = lrelu(accg[i]);
+            for (int i = 0; i < 16; ++i) gv[i] = accg[i];
+            LRELU16(gv);
             half8 gh[2], gl[2];
             split8(gv, gh[0], gl[0]);
             split8(gv + 8, gh[1], gl[1]);
@@ -461,8 +481,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
                     const half8 ah = W[(20 + m * 2 + ks) * 64 + lane], al = W[(28 + m * 2 + ks) * 64 + lane];
                     MFMA3(ah, al, gh[ks], gl[ks], x[m]);
                 }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) x[m][i] = lrelu(x[m][i]);
+                LRELU16(x[m]);
             }
         }
         in = load_in(has_next ? b_next : b, ref_n, aux_n); // next sample's inputs first (see load_in)
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
         //      is derived from the f16 pieces inside k_fc0_mx);  [192,256) fp8 (x - hi)*2^(SA+11) as [h0 32 B | h1 32 B].  Byte slot of a lane = 16*(m&1) + reg. ----
         if (valid && !(ABL & 2)) {
             uint4* row = a_out + (size_t)b * row_u4;
-            const float sc_lo = __uint_as_float((uint32_t)(127 + MX_SA + 11) << 23);
+            const float sc_lo_inv = __uint_as_float((uint32_t)(127 - MX_SA - 11) << 23); // fp8 = (x - hi) / 2^-(SA+11)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 uint4* blkp = row + ((size_t)((tile * 2 + q) * 32 + pxl)) * 16;
@@ -484,19 +503,19 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
                             const float v0 = x[2 * q + mm][8 * sx + 2 * jj], v1 = x[2 * q + mm][8 * sx + 2 * jj + 1];
-                            // round-to-nearest hi (not the truncating split8): the fp8 residual term is then half as
-                            // large and unbiased
-                            const _Float16 r0 = (_Float16)v0, r1 = (_Float16)v1;
-                            const float h0 = (float)r0, h1 = (float)r1;
-                            H.u[jj] = (uint32_t)__builtin_bit_cast(unsigned short, r0) | ((uint32_t)__builtin_bit_cast(unsigned short, r1) << 16);
-                            const float l0 = __builtin_amdgcn_fmed3f((v0 - h0) * sc_lo, -448.0f, 448.0f), l1 = __builtin_amdgcn_fmed3f((v1 - h1) * sc_lo, -448.0f, 448.0f);
+                            // round-to-nearest hi; residual by one mixed-precision fma per value; scaled saturating
+                            // (MODE.FP16_OVFL) packed fp8 convert: 2 VALU per value
+                            const uint32_t ph = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v0, v1}, half2v));
+                            H.u[jj] = ph;
+                            float l0, l1;
+                            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ph), "v"(v0));
+                            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph), "v"(v1));
                             const int slot = 16 * mm + 8 * sx + 2 * jj; // byte slot of v0
                             const int w = slot >> 2;
-                            if ((slot & 3) == 0) {
-                                p8l[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, 0, false);
-                            } else {
-                                p8l[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, (int)p8l[w], true);
-                            }
+                            if ((slot & 3) == 0)
+                                p8l[w] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(short2v{0, 0}, l0, l1, sc_lo_inv, false));
+                            else
+                                p8l[w] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(short2v, p8l[w]), l0, l1, sc_lo_inv, true));
                         }
                         blkp[(mm * 2 + sx) * 2 + h] = H.v;
                     }
@@ -542,8 +561,6 @@ __device__ inline void dma16(const uint4* g, const uint4* lds) {
     const uint32_t a = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(a) : "memory", "m0");
 }
-typedef short short2v __attribute__((ext_vector_type(2)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 __device__ inline void f16x8_to_fp8(const half8& v, float inv_mul, uint32_t& d0, uint32_t& d1) {
     // v_cvt_scalef32_pk_fp8_f16: fp8(x / scale), RNE, two values per instruction (tools/probe/cvt_probe.hip)
     short2v r0 = {0, 0}, r1 = {0, 0};
@@ -560,7 +577,7 @@ __device__ inline void f16x8_to_fp8(const half8& v, float inv_mul, uint32_t& d0,
 // super-step are read from LDS once and stay in registers for its 4 stages; a weight fragment is read from LDS by
 // exactly one wave.  LDS traffic per stage drops from 144 KiB (8-wave form) to ~48 KiB and the matrix pipe is fed
 // by one wave with 4 independent accumulator chains.
-template <int EPI>
+template <int EPI, int DBG = 0> // DBG: timing-only ablations (1 = no weight DMA, 2 = no sample DMA, 4 = no fp8 derivation)
 __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksup,
                                                 size_t act_row_u4, int full_tiles, int last_cnt, MxScales sc,
                                                 const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
@@ -568,7 +585,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     // Static LDS objects, one per weight-ring slot: hipcc orders a ds_read after an LDS-DMA write by object (alias
     // scopes of distinct LDS variables), and with one dynamic array it drains ALL outstanding DMA (vmcnt(0)) before
     // the first LDS read of every stage.  With separate objects it waits exactly for the last DMA into the slot read.
-    __shared__ uint4 ldsA[2 * MXS_U4];        // [2][4 ct][6 frag][64]
+    __shared__ uint4 ldsA[2 * MXS_U4];        // [2]{ f16 [128 samples][8 pieces] | fp8 [128 samples][4 pieces] }
     __shared__ uint4 ldsW0[MXS_U4], ldsW1[MXS_U4], ldsW2[MXS_U4], ldsW3[MXS_U4]; // [4 i][6 frag][64] each
     auto ring = [&](int slot) -> uint4* { return slot == 0 ? ldsW0 : slot == 1 ? ldsW1 : slot == 2 ? ldsW2 : ldsW3; };
     int count = d_count[0];
@@ -597,15 +614,38 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     asm volatile("" : "+s"(w_dma_off));
     asm volatile("" : "+v"(w_rd_off));
     auto issue_w1 = [&](int stage_local, int slot, int k) { // fragment k of this wave's 6
-        dma16(wsrc + (size_t)stage_local * MXS_U4 + k * 64, ring(slot) + w_dma_off + k * 64);
+        if (!(DBG & 1)) dma16(wsrc + (size_t)stage_local * MXS_U4 + k * 64, ring(slot) + w_dma_off + k * 64);
     };
-    // sample-operand fragments: f < 4: f16 piece j = f at +f*2 + h;  f = 4,5: fp8 residual halves at +12 + h*2 + (f-4)
-    auto issue_a1 = [&](int uo, int buf, int k) { // fragment wave + 4k of the super-step's 24 (k = 0..5)
-        const int fi = wave + 4 * k, ct = fi / 6, f = fi % 6;
-        const int fo = f < 4 ? f * 2 + h : 12 + h * 2 + (f - 4);
-        const uint4* g = act + (size_t)(b0 + 32 * ct + (lane & 31)) * act_row_u4 + uo + fo;
-        dma16(g, ldsA + buf * MXS_U4 + fi * 64);
+    // Sample operands of a super-step: per sample one 256-B block = f16 pieces (2j+h) at [0,128) and fp8 residual
+    // pieces (2h+e) at [192,256).  The DMA reads them with ADJACENT LANES ON ADJACENT 16-B PIECES of one sample (8
+    // lanes = the 128-B f16 part, 4 lanes = the 64-B fp8 part): the texture path coalesces neighbouring lanes only,
+    // and the MFMA lane order (lane = sample) made every lane its own 16-B request -- 64 requests per instruction
+    // and as much address-path time for these 20 % of the bytes as for all the weights.  Wave w stages sample tile w:
+    // k = 0..3: f16 part of samples 8k..8k+7 of the tile, k = 4,5: fp8 part of samples 16(k-4)..+15.
+    // LDS image: f16 [128 samples][8 pieces], then fp8 [128 samples][4 pieces]; the piece index is XOR-swizzled with
+    // the sample index (on the global side, inside the contiguous segment) so that the ds_read_b128 of an MFMA
+    // fragment (lane = sample, 128-B / 64-B stride) is bank-conflict free for its four 16-lane groups.
+    const int a_hi_s = lane >> 3, a_hi_p = lane & 7;   // f16 part: sample within the group of 8, LDS piece slot
+    const int a_lo_s = lane >> 2, a_lo_p = lane & 3;   // fp8 part: sample within the group of 16, LDS piece slot
+    auto issue_a1 = [&](int uo, int buf, int k) {
+        const uint4* g;
+        if (k < 4) {
+            const int st = 8 * k + a_hi_s; // sample within the tile
+            g = act + (size_t)(b0 + 32 * wave + st) * act_row_u4 + uo + (a_hi_p ^ ((st >> 1) & 7));
+        } else {
+            const int st = 16 * (k - 4) + a_lo_s;
+            g = act + (size_t)(b0 + 32 * wave + st) * act_row_u4 + uo + 12 + (a_lo_p ^ ((st >> 2) & 3));
+        }
+        const int dst = k < 4 ? (wave * 4 + k) * 64 : 1024 + (wave * 2 + (k - 4)) * 64;
+        if (!(DBG & 2)) dma16(g, ldsA + buf * MXS_U4 + dst);
     };
+    // LDS read offsets (uint4 units) of this lane's pieces inside sample tile 0; tile c adds 256 / 128
+    const int sl = lane & 31;
+    int a_rd_hi[4], a_rd_lo[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_rd_hi[j] = sl * 8 + ((2 * j + h) ^ ((sl >> 1) & 7));
+#pragma unroll
+    for (int e = 0; e < 2; ++e) a_rd_lo[e] = 1024 + sl * 4 + ((2 * h + e) ^ ((sl >> 2) & 3));
     // fp8 conversions saturate to +-448 instead of producing NaN (MODE.FP16_OVFL, probed: tools/probe/cvt_probe.hip)
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
     const float w_inv = 1.0f / sc.w_mul, a_inv = 1.0f / sc.a_mul; // powers of two
@@ -634,9 +674,9 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) bh[c][j] = *(const half8*)(ldsA + (c * 6 + j) * 64 + lane);
+            for (int c = 0; c < 4; ++c) bh[c][j] = *(const half8*)(ldsA + c * 256 + a_rd_hi[j]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a8l[c] = v8_from(ldsA[(c * 6 + 4) * 64 + lane], ldsA[(c * 6 + 5) * 64 + lane]);
+        for (int c = 0; c < 4; ++c) a8l[c] = v8_from(ldsA[c * 128 + a_rd_lo[0]], ldsA[c * 128 + a_rd_lo[1]]);
 #pragma unroll
         for (int k = 0; k < 6; ++k) wc[k] = ldsW0[w_rd_off + k * 64];
     }
@@ -661,7 +701,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
-            const uint4* LAn = ldsA + (ub ^ 1) * MXS_U4 + lane;
+            const uint4* LAn = ldsA + (ub ^ 1) * MXS_U4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -673,18 +713,18 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
                 issue_w1(ul * 4 + g + 3, (g + 3) & 3, j);
                 if (j < 2) issue_w1(ul * 4 + g + 3, (g + 3) & 3, 4 + j);
                 uint32_t d0, d1;
-                f16x8_to_fp8(ah[j], w_inv, d0, d1);
+                if (DBG & 4) { d0 = (uint32_t)w8l[0] + j; d1 = (uint32_t)w8l[5]; } else f16x8_to_fp8(ah[j], w_inv, d0, d1);
                 w8h[2 * j] = (int)d0; w8h[2 * j + 1] = (int)d1;
                 if (g == 0) { // fp8 copies of this super-step's f16 pieces
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        f16x8_to_fp8(bh[c][j], a_inv, d0, d1);
+                        if (DBG & 4) { d0 = (uint32_t)w8l[2] + c; d1 = (uint32_t)w8l[7] + j; } else f16x8_to_fp8(bh[c][j], a_inv, d0, d1);
                         a8h[c][2 * j] = (int)d0; a8h[c][2 * j + 1] = (int)d1;
                     }
                 }
                 if (g == 3) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) bh[c][j] = *(const half8*)(LAn + (c * 6 + j) * 64);
+                    for (int c = 0; c < 4; ++c) bh[c][j] = *(const half8*)(LAn + c * 256 + a_rd_hi[j]);
                 }
                 // the machine scheduler otherwise sinks the DMA issues and the register prefetches to their first
                 // use, which serialises the whole pipeline: pin every j-step
@@ -704,7 +744,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
                 acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8h, a8l[c], acc[g][c], 0, 0, 0, sc.wa_hi, 0, sc.ab_lo);
             if (g == 3) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) a8l[c] = v8_from(LAn[(c * 6 + 4) * 64], LAn[(c * 6 + 5) * 64]);
+                for (int c = 0; c < 4; ++c) a8l[c] = v8_from(LAn[c * 128 + a_rd_lo[0]], LAn[c * 128 + a_rd_lo[1]]);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -1258,9 +1298,12 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
         const MxScales sc{127 - net.mx_sw, 127 - (net.mx_sw + 11), 127 - MX_SA, 127 - (MX_SA + 11), ldexpf(1.0f, net.mx_sw), ldexpf(1.0f, MX_SA)};
         constexpr int LDS = 0; // static LDS objects: (2 + MXS_SLOTS) x 24 KiB
         if (nsplit == 1) {
-            k_fc0_mx<EPI_SPLIT><<<dim3(tiles128, 1), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4,
-                                                                      hw / 32, (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr,
-                                                                      S.d_count, max_count);
+            static const int dbg = getenv("OMOK_DBG_FC0") ? atoi(getenv("OMOK_DBG_FC0")) : 0; // timing experiments only
+            auto kern = dbg == 1 ? k_fc0_mx<EPI_SPLIT, 1> : dbg == 2 ? k_fc0_mx<EPI_SPLIT, 2> : dbg == 3 ? k_fc0_mx<EPI_SPLIT, 3>
+                      : dbg == 4 ? k_fc0_mx<EPI_SPLIT, 4> : dbg == 7 ? k_fc0_mx<EPI_SPLIT, 7> : k_fc0_mx<EPI_SPLIT, 0>;
+            kern<<<dim3(tiles128, 1), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4,
+                                                      hw / 32, (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr,
+                                                      S.d_count, max_count);
         } else {
             const size_t cap_rows = (size_t)tiles128 * GT_BS;
             k_fc0_mx<EPI_PARTIAL><<<dim3(tiles128, nsplit), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0,
