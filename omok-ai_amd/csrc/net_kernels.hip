@@ -235,6 +235,11 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
     __syncthreads();
     int count = S.d_count[0];
     if (count > max_count) count = max_count;
+    // depthwise work items are dealt to lanes in the order of the ds_read_b128 lane groups ({0-3,12-15,20-27},
+    // {4-11,16-19,28-31} per half): each group then holds two strips 8 pixels apart = 16 distinct 16-B slots of the
+    // 256-B bank row (halo-grid row stride 36 floats); lane order gave a 2-way conflict on every window read
+    const int l31 = lane & 31;
+    const int dw_tid = (tid & ~31) | (l31 < 4 ? l31 : l31 < 12 ? l31 + 4 : l31 < 16 ? l31 - 8 : l31 < 20 ? l31 + 8 : l31 < 28 ? l31 - 4 : l31);
     const int pxl = lane & 31;
     const int px = tile * 32 + pxl;
     const bool valid = px < HW;
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
             f32x4 dout[TG::DW_ITER][4];
 #pragma unroll
             for (int it = 0; it < TG::DW_ITER; ++it) {
-                const int item = tid + it * TG::THREADS;
+                const int item = dw_tid + it * TG::THREADS;
                 const int itc = item < TG::DW_ITEMS ? item : 0;
                 const int cg = itc & 7, strip = itc >> 3;
                 const int y = strip / TG::SPR, x0 = (strip % TG::SPR) * 4;
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
             lds_barrier(); // B3: all windows are in registers; the grid can be overwritten in place
 #pragma unroll
             for (int it = 0; it < TG::DW_ITER; ++it) {
-                const int item = tid + it * TG::THREADS;
+                const int item = dw_tid + it * TG::THREADS;
                 if (item < TG::DW_ITEMS) {
                     const int cg = item & 7, strip = item >> 3;
                     const int y = strip / TG::SPR, x0 = (strip % TG::SPR) * 4;
