@@ -216,7 +216,9 @@ struct TrunkGeo {
 };
 
 template <int N, bool FROM_F32, int ABL = 0> // ABL: timing-only ablations (1 = no depthwise exchange, 2 = no output stores, 4 = no conv_in)
-__global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, const float* __restrict__ in_f32,
+__global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_t* __restrict__ req_ref, const uint32_t* __restrict__ req_aux,
+                                                                    const uint64_t* __restrict__ board, const NodeHdr* __restrict__ hdr,
+                                                                    const int32_t* __restrict__ d_count, int cap_nodes, const float* __restrict__ in_f32,
                                                                     const uint4* __restrict__ wt, const float* __restrict__ side,
                                                                     uint4* __restrict__ a_out, size_t row_u4, int max_count) {
     using TG = TrunkGeo<N>;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
     for (int i = tid; i < TR_SIDE_FLOATS; i += blockDim.x) ((float*)lside)[i] = side[i];
     for (int i = tid; i < TG::GRID_ROWS * GRID_STRIDE; i += blockDim.x) grid[i] = 0.0f;
     __syncthreads();
-    int count = S.d_count[0];
+    int count = d_count[0];
     if (count > max_count) count = max_count;
     // depthwise work items are dealt to lanes in the order of the ds_read_b128 lane groups ({0-3,12-15,20-27},
     // {4-11,16-19,28-31} per half): each group then holds two strips 8 pixels apart = 16 distinct 16-B slots of the
@@ -255,15 +257,9 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
         uint32_t aux;
         int turn;
         float f[3];
-        half8 cwh[4], cwl[4];
     };
     auto load_in = [&](int b, uint32_t ref, uint32_t aux) {
         SampleIn in;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) { // conv_in fragments (L2-resident)
-            in.cwh[m] = convW[m * 64 + lane];
-            in.cwl[m] = convW[(4 + m) * 64 + lane];
-        }
         in.aux = aux;
         in.turn = 0;
         in.f[0] = in.f[1] = in.f[2] = 0.0f;
@@ -273,23 +269,31 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
             const float* f = in_f32 + (size_t)b * 3 * HW + 3 * pxc;
             in.f[0] = f[0]; in.f[1] = f[1]; in.f[2] = f[2];
         } else {
-            const size_t tn = (size_t)(ref >> 16) * (size_t)S.cap_nodes + (size_t)(ref & 0xFFFFu);
+            const size_t tn = (size_t)(ref >> 16) * (size_t)cap_nodes + (size_t)(ref & 0xFFFFu);
 #pragma unroll
-            for (int i = 0; i < 2 * NW; ++i) in.bb[i] = S.board[tn * (2 * NW) + i];
-            in.turn = S.hdr[tn].turn;
+            for (int i = 0; i < 2 * NW; ++i) in.bb[i] = board[tn * (2 * NW) + i];
+            in.turn = (int)((((const uint32_t*)hdr)[tn * 4 + 2] >> 16) & 0xFFu); // NodeHdr::turn (byte 10) through a dword: scalar load
         }
         return in;
     };
+    // conv_in fragments stay in registers for the whole persistent loop (8 x 4 VGPRs): re-fetching them per sample
+    // put 8 loads in front of every sample's first MFMA, and their wait also drained the previous sample's stores
+    half8 cwh[4], cwl[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        cwh[m] = convW[m * 64 + lane];
+        cwl[m] = convW[(4 + m) * 64 + lane];
+    }
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     const int b_first = blockIdx.x;
     uint32_t ref_n = 0, aux_n = 0xFFFFFFFFu;
-    if (!FROM_F32 && b_first < count) { ref_n = S.req_ref[b_first]; aux_n = S.req_aux[b_first]; }
+    if (!FROM_F32 && b_first < count) { ref_n = req_ref[b_first]; aux_n = req_aux[b_first]; }
     SampleIn in = load_in(b_first < count ? b_first : 0, ref_n, aux_n);
 
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
         const int b_next = b + (int)gridDim.x;
         const bool has_next = b_next < count;
-        if (!FROM_F32 && has_next) { ref_n = S.req_ref[b_next]; aux_n = S.req_aux[b_next]; } // used at the end of this sample
+        if (!FROM_F32 && has_next) { ref_n = req_ref[b_next]; aux_n = req_aux[b_next]; } // used at the end of this sample
         // ---- the pixel's three input floats in the flat encoder.rs layout ----
         float f0, f1, f2;
         if (FROM_F32) {
@@ -336,9 +340,6 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
             }
             f0 = fv[0]; f1 = fv[1]; f2 = fv[2];
         }
-        half8 cwh[4], cwl[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) { cwh[m] = in.cwh[m]; cwl[m] = in.cwl[m]; }
         // ---- conv_in 1x1 3->128 + bias + lrelu as one 16-deep k-step: k = (f0, f1, f2, 1, 0...) on lane-half 0 ----
         f32x16 x[4];
         if (ABL & 4) {
@@ -493,7 +494,9 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(Store S, cons
         // ---- fc0 operand row (k_fc0_mx): block (tile, q) = [pxl 32][256 B], one K=64 super-step per pixel and
         //      channel half q:  [0,128) f16 hi pieces of k-steps j = 2*(m&1)+s as [h0|h1];  [128,192) unused (the fp8 copy of x
         //      is derived from the f16 pieces inside k_fc0_mx);  [192,256) fp8 (x - hi)*2^(SA+11) as [h0 32 B | h1 32 B].  Byte slot of a lane = 16*(m&1) + reg. ----
-        if (valid && !(ABL & 2)) {
+        // (lanes past the last pixel store into the pad slots of the row: without a branch around the stores the
+        //  compiler counts them exactly and the next sample's operand waits do not drain them)
+        if (!(ABL & 2)) {
             uint4* row = a_out + (size_t)b * row_u4;
             const float sc_lo_inv = __uint_as_float((uint32_t)(127 - MX_SA - 11) << 23); // fp8 = (x - hi) / 2^-(SA+11)
 #pragma unroll
@@ -566,15 +569,27 @@ __device__ inline void dma16(const uint4* g, const uint4* lds) {
     const uint32_t a = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(a) : "memory", "m0");
 }
+// same with a wave-uniform 64-bit base in SGPRs and a 32-bit byte offset per lane: no 64-bit vector add per DMA
+__device__ inline void dma16s(const uint4* sbase, uint32_t voff, const uint4* lds) {
+    const uint32_t a = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(a) : "memory", "m0");
+}
+// v_cvt_scalef32_pk_fp8_f16: fp8(x / scale), RNE, two f16 (one dword) per instruction into one half of the destination
+// (tools/probe/cvt_probe.hip).  From asm so that the first convert of a dword does not drag a zeroing v_mov along for
+// the half it leaves alone (the builtin's tied "old" operand).
+__device__ inline uint32_t cvt_fp8_lo(uint32_t src2, float scale) {
+    uint32_t d;
+    asm("v_cvt_scalef32_pk_fp8_f16 %0, %1, %2" : "=v"(d) : "v"(src2), "v"(scale));
+    return d;
+}
+__device__ inline uint32_t cvt_fp8_hi(uint32_t d, uint32_t src2, float scale) {
+    asm("v_cvt_scalef32_pk_fp8_f16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(d) : "v"(src2), "v"(scale));
+    return d;
+}
 __device__ inline void f16x8_to_fp8(const half8& v, float inv_mul, uint32_t& d0, uint32_t& d1) {
-    // v_cvt_scalef32_pk_fp8_f16: fp8(x / scale), RNE, two values per instruction (tools/probe/cvt_probe.hip)
-    short2v r0 = {0, 0}, r1 = {0, 0};
-    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, half2v{v[0], v[1]}, inv_mul, false);
-    r0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r0, half2v{v[2], v[3]}, inv_mul, true);
-    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, half2v{v[4], v[5]}, inv_mul, false);
-    r1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r1, half2v{v[6], v[7]}, inv_mul, true);
-    d0 = __builtin_bit_cast(uint32_t, r0);
-    d1 = __builtin_bit_cast(uint32_t, r1);
+    const uint4 q = __builtin_bit_cast(uint4, v);
+    d0 = cvt_fp8_hi(cvt_fp8_lo(q.x, inv_mul), q.y, inv_mul);
+    d1 = cvt_fp8_hi(cvt_fp8_lo(q.z, inv_mul), q.w, inv_mul);
 }
 
 // Workgroup = 4 waves (one per SIMD, each with the full 512-register file): wave w owns m-tile 4g+w of every
@@ -582,7 +597,8 @@ __device__ inline void f16x8_to_fp8(const half8& v, float inv_mul, uint32_t& d0,
 // super-step are read from LDS once and stay in registers for its 4 stages; a weight fragment is read from LDS by
 // exactly one wave.  LDS traffic per stage drops from 144 KiB (8-wave form) to ~48 KiB and the matrix pipe is fed
 // by one wave with 4 independent accumulator chains.
-template <int EPI, int DBG = 0> // DBG: timing-only ablations (1 = no weight DMA, 2 = no sample DMA, 4 = no fp8 derivation)
+constexpr bool STAGGER = false; // (skewing the waves by s_nops after the barrier: 3.52 -> 3.88 ms, the delay costs more than it saves)
+template <int EPI, int DBG = 0> // DBG: timing-only ablations (1 = no weight DMA, 2 = no sample DMA, 4 = no fp8 derivation, 8 = no vmcnt waits)
 __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksup,
                                                 size_t act_row_u4, int full_tiles, int last_cnt, MxScales sc,
                                                 const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
@@ -611,15 +627,13 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     };
     // a wave stages exactly the 6 weight fragments it consumes (m-tile `wave` of the stage's group): the weight ring is
     // wave-private, ordered by this wave's own vmcnt, and needs no workgroup barrier
-    const uint4* wsrc = wp + (size_t)ubeg * 4 * MXS_U4 + (size_t)(wave * 6) * 64 + lane;
-    // LDS offsets of this wave's fragments, as opaque values: the LDS-DMA store is modelled as 4 bytes at the M0
-    // address, and when the compiler can prove that a ds_read does not overlap THAT it stops ordering the read
-    // against the slot's DMA and falls back to "wait for every DMA" (vmcnt(0))
+    const uint4* wsrc = wp + (size_t)ubeg * 4 * MXS_U4 + (size_t)(wave * 6) * 64; // wave-uniform; lanes add lane * 16 B
+    const uint32_t w_voff = lane * 16;
     int w_dma_off = wave * 6 * 64, w_rd_off = wave * 6 * 64 + lane;
     asm volatile("" : "+s"(w_dma_off));
     asm volatile("" : "+v"(w_rd_off));
     auto issue_w1 = [&](int stage_local, int slot, int k) { // fragment k of this wave's 6
-        if (!(DBG & 1)) dma16(wsrc + (size_t)stage_local * MXS_U4 + k * 64, ring(slot) + w_dma_off + k * 64);
+        if (!(DBG & 1)) dma16s(wsrc + (size_t)stage_local * MXS_U4 + k * 64, w_voff, ring(slot) + w_dma_off + k * 64);
     };
     // Sample operands of a super-step: per sample one 256-B block = f16 pieces (2j+h) at [0,128) and fp8 residual
     // pieces (2h+e) at [192,256).  The DMA reads them with ADJACENT LANES ON ADJACENT 16-B PIECES of one sample (8
@@ -630,19 +644,21 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     // LDS image: f16 [128 samples][8 pieces], then fp8 [128 samples][4 pieces]; the piece index is XOR-swizzled with
     // the sample index (on the global side, inside the contiguous segment) so that the ds_read_b128 of an MFMA
     // fragment (lane = sample, 128-B / 64-B stride) is bank-conflict free for its four 16-lane groups.
-    const int a_hi_s = lane >> 3, a_hi_p = lane & 7;   // f16 part: sample within the group of 8, LDS piece slot
-    const int a_lo_s = lane >> 2, a_lo_p = lane & 3;   // fp8 part: sample within the group of 16, LDS piece slot
-    auto issue_a1 = [&](int uo, int buf, int k) {
-        const uint4* g;
+    const uint4* abase = act + (size_t)(b0 + 32 * wave) * act_row_u4; // wave-uniform
+    uint32_t a_voff[6];                                               // per-lane byte offsets of the 6 pieces
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
         if (k < 4) {
-            const int st = 8 * k + a_hi_s; // sample within the tile
-            g = act + (size_t)(b0 + 32 * wave + st) * act_row_u4 + uo + (a_hi_p ^ ((st >> 1) & 7));
+            const int st = 8 * k + (lane >> 3); // sample within the tile
+            a_voff[k] = (uint32_t)(((size_t)st * act_row_u4 + (size_t)((lane & 7) ^ ((st >> 1) & 7))) * 16);
         } else {
-            const int st = 16 * (k - 4) + a_lo_s;
-            g = act + (size_t)(b0 + 32 * wave + st) * act_row_u4 + uo + 12 + (a_lo_p ^ ((st >> 2) & 3));
+            const int st = 16 * (k - 4) + (lane >> 2);
+            a_voff[k] = (uint32_t)(((size_t)st * act_row_u4 + 12 + (size_t)((lane & 3) ^ ((st >> 2) & 3))) * 16);
         }
+    }
+    auto issue_a1 = [&](int uo, int buf, int k) {
         const int dst = k < 4 ? (wave * 4 + k) * 64 : 1024 + (wave * 2 + (k - 4)) * 64;
-        if (!(DBG & 2)) dma16(g, ldsA + buf * MXS_U4 + dst);
+        if (!(DBG & 2)) dma16s(abase + uo, a_voff[k], ldsA + buf * MXS_U4 + dst);
     };
     // LDS read offsets (uint4 units) of this lane's pieces inside sample tile 0; tile c adds 256 / 128
     const int sl = lane & 31;
@@ -685,11 +701,19 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
 #pragma unroll
         for (int k = 0; k < 6; ++k) wc[k] = ldsW0[w_rd_off + k * 64];
     }
-    // Stage q = (ul, g) lives in ring slot g.  During stage q: the matrix pipe works on wc; the DMA of stage q+3 is
-    // issued into slot (g+3)&3 (read during stage q-2, consumed by the MFMAs of stage q-1); the fragments of stage q+1
-    // are read from LDS into registers behind the block-scaled MFMAs.  One workgroup barrier per super-step (top of
-    // g = 3): behind it the NEXT super-step's sample operands replace the current ones in registers piece by piece,
-    // each right after its last MFMA.
+    // One wave per SIMD: nothing but this wave's own instruction stream hides anything, and an MFMA only covers what
+    // is issued in ITS gap (tools/probe/overlap_probe.hip: an 8-pass f16 MFMA hides ~4-5 single-issue instructions, a
+    // trailing block of VALU hides nothing; one LDS-DMA costs ~60 cycles of issue).  So every MFMA below is followed by
+    // its own small group of fillers and a scheduling barrier pins the group to the gap:
+    //   f16 MFMA gaps   : the fp8 derivations (one packed convert per weight pair; at g = 0 also the sample copies),
+    //                     at g = 3 the LDS read that replaces the piece just consumed, at the end the next stage's
+    //                     weight fragments LDS -> registers
+    //   scaled-fp8 gaps : one LDS-DMA each (16-pass MFMA = 64 cycles)
+    // Stage q = (ul, g) lives in ring slot g.  The DMA of stage q+3 goes to slot (g+3)&3 (read during stage q-2,
+    // consumed by the MFMAs of stage q-1).  Per block-scaled phase the DMA order is [2 sample pieces (g < 3)], 6 weights.
+    // One workgroup barrier per super-step (top of g = 3): behind it the NEXT super-step's sample operands replace the
+    // current ones in registers piece by piece, each right after its last MFMA.
+#define GAP() __builtin_amdgcn_sched_barrier(0)
     for (int ul = 0; ul < ksup; ++ul) {
         const int ub = ul & 1;
         const int uo_next = uoff(ubeg + ul + 1);
@@ -699,66 +723,80 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
 #pragma unroll
             for (int j = 0; j < 4; ++j) ah[j] = __builtin_bit_cast(half8, wc[j]);
             const v8i w8l = v8_from(wc[4], wc[5]);
-            v8i w8h;
-            if (g == 3) { // every wave's share of A(ul+1) must have landed before anyone reads it: issued during stage
-                          // g = 0 with A before W in each slot, so 1 + 6 + 6 later loads may still be in flight
-                asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            uint32_t w8[8]; // fp8 copy of ah[0..3]: dword 2j, 2j+1
+            if (g == 3) { // every wave's share of A(ul+1) must have landed before anyone reads it: its last pieces were
+                          // issued at the head of stage g = 2's block-scaled phase, 6 weight pieces behind them
+                if (!(DBG & 8)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                // the barrier releases the four waves in the same cycle and they would then reach every DMA gap together
+                // (one texture path per CU, 16 cycles per piece): skew them by 16 cycles each
+                if (STAGGER)
+                    for (int i = 0; i < wave; ++i) asm volatile("s_nop 15");
             }
             const uint4* LAn = ldsA + (ub ^ 1) * MXS_U4;
+            uint4 wn[6];
+            // DMA piece d = 0..7 of this stage: [2 sample pieces (g < 3)], 6 weight pieces; spread over the stage's 24
+            // MFMA gaps (the four waves share one texture path: 30 pieces x 16 cycles per stage and CU)
+            auto dma_piece = [&](int d) {
+                if (g < 3) {
+                    if (d < 2) issue_a1(uo_next, ub ^ 1, 2 * g + d);
+                    else issue_w1(ul * 4 + g + 3, (g + 3) & 3, d - 2);
+                } else if (d < 6) {
+                    issue_w1(ul * 4 + g + 3, (g + 3) & 3, d);
+                }
+            };
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[g][c] = MFMA16(ah[j], bh[c][j], acc[g][c]);
-                if (g == 0) { // next super-step's sample operands (buffer last read during stage (ul-1, 3))
-                    issue_a1(uo_next, ub ^ 1, j);
-                    if (j < 2) issue_a1(uo_next, ub ^ 1, 4 + j);
-                }
-                issue_w1(ul * 4 + g + 3, (g + 3) & 3, j);
-                if (j < 2) issue_w1(ul * 4 + g + 3, (g + 3) & 3, 4 + j);
-                uint32_t d0, d1;
-                if (DBG & 4) { d0 = (uint32_t)w8l[0] + j; d1 = (uint32_t)w8l[5]; } else f16x8_to_fp8(ah[j], w_inv, d0, d1);
-                w8h[2 * j] = (int)d0; w8h[2 * j + 1] = (int)d1;
-                if (g == 0) { // fp8 copies of this super-step's f16 pieces
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < 4; ++c) {
+                    acc[g][c] = MFMA16(ah[j], bh[c][j], acc[g][c]);
+                    if (!(DBG & 4)) { // weight pair c of piece j -> one half of dword 2j + (c >> 1)
+                        const uint4 aq = __builtin_bit_cast(uint4, ah[j]);
+                        const uint32_t src = c == 0 ? aq.x : c == 1 ? aq.y : c == 2 ? aq.z : aq.w;
+                        w8[2 * j + (c >> 1)] = (c & 1) ? cvt_fp8_hi(w8[2 * j + (c >> 1)], src, w_inv) : cvt_fp8_lo(src, w_inv);
+                    } else if (!(c & 1)) w8[2 * j + (c >> 1)] = (uint32_t)w8l[j] + c;
+                    if (g == 0) { // fp8 copy of this super-step's piece (c, j)
+                        uint32_t d0, d1;
                         if (DBG & 4) { d0 = (uint32_t)w8l[2] + c; d1 = (uint32_t)w8l[7] + j; } else f16x8_to_fp8(bh[c][j], a_inv, d0, d1);
                         a8h[c][2 * j] = (int)d0; a8h[c][2 * j + 1] = (int)d1;
                     }
+                    if (g == 3) bh[c][j] = *(const half8*)(LAn + c * 256 + a_rd_hi[j]); // next super-step's piece
+                    if (j == 3) { // stage q+1's weights (issued during stage q-2): everything but the pieces of stage q-1
+                                  // and the first 4 of this stage has landed
+                        if (c == 0 && !(DBG & 8)) {
+                            if (g == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                        }
+                        if (c >= 1) {
+                            wn[2 * (c - 1)] = ring((g + 1) & 3)[w_rd_off + (2 * (c - 1)) * 64];
+                            wn[2 * (c - 1) + 1] = ring((g + 1) & 3)[w_rd_off + (2 * (c - 1) + 1) * 64];
+                        }
+                    }
+                    if ((4 * j + c) % 3 == 1 && 4 * j + c <= 13) dma_piece((4 * j + c) / 3); // gaps 1, 4, 7, 10, 13 -> d = 0..4 (after the wait above)
+                    GAP();
                 }
-                if (g == 3) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) bh[c][j] = *(const half8*)(LAn + c * 256 + a_rd_hi[j]);
-                }
-                // the machine scheduler otherwise sinks the DMA issues and the register prefetches to their first
-                // use, which serialises the whole pipeline: pin every j-step
-                __builtin_amdgcn_sched_barrier(0);
             }
-            // stage q+1's weights (issued during stage q-2): everything but the loads of stages q-1 and q has landed.
-            // The wait goes through the builtin so that hipcc's own LDS-DMA tracking sees it; with an opaque asm wait
-            // it adds a vmcnt(0) in front of the ds_reads and drains the whole ring every stage.
-            if (g < 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            uint4 wn[6];
+            const v8i w8h = v8i{(int)w8[0], (int)w8[1], (int)w8[2], (int)w8[3], (int)w8[4], (int)w8[5], (int)w8[6], (int)w8[7]};
 #pragma unroll
-            for (int k = 0; k < 6; ++k) wn[k] = ring((g + 1) & 3)[w_rd_off + k * 64];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c) {
                 acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8h, a8l[c], acc[g][c], 0, 0, 0, sc.wa_hi, 0, sc.ab_lo);
-            if (g == 3) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) a8l[c] = v8_from(LAn[c * 128 + a_rd_lo[0]], LAn[c * 128 + a_rd_lo[1]]);
+                if (c == 0) dma_piece(5);
+                if (c == 3) dma_piece(6);
+                if (g == 3) a8l[c] = v8_from(LAn[c * 128 + a_rd_lo[0]], LAn[c * 128 + a_rd_lo[1]]);
+                GAP();
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c) {
                 acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8l, a8h[c], acc[g][c], 0, 0, 0, sc.wa_lo, 0, sc.ab_hi);
+                if (c == 2) dma_piece(7);
+                GAP();
+            }
 #pragma unroll
             for (int k = 0; k < 6; ++k) wc[k] = wn[k];
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#undef GAP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0");
 
@@ -1249,7 +1287,7 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
         attr_done = true;
     }
     const int grid = max_count < 256 ? max_count : 256;
-    kern<<<grid, TG::TILES * 64, TG::LDS_BYTES, st>>>(S, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4, max_count);
+    kern<<<grid, TG::TILES * 64, TG::LDS_BYTES, st>>>(S.req_ref, S.req_aux, S.board, S.hdr, S.d_count, S.cap_nodes, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4, max_count);
 }
 
 template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
@@ -1305,7 +1343,7 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
         if (nsplit == 1) {
             static const int dbg = getenv("OMOK_DBG_FC0") ? atoi(getenv("OMOK_DBG_FC0")) : 0; // timing experiments only
             auto kern = dbg == 1 ? k_fc0_mx<EPI_SPLIT, 1> : dbg == 2 ? k_fc0_mx<EPI_SPLIT, 2> : dbg == 3 ? k_fc0_mx<EPI_SPLIT, 3>
-                      : dbg == 4 ? k_fc0_mx<EPI_SPLIT, 4> : dbg == 7 ? k_fc0_mx<EPI_SPLIT, 7> : k_fc0_mx<EPI_SPLIT, 0>;
+                      : dbg == 4 ? k_fc0_mx<EPI_SPLIT, 4> : dbg == 7 ? k_fc0_mx<EPI_SPLIT, 7> : dbg == 8 ? k_fc0_mx<EPI_SPLIT, 8> : k_fc0_mx<EPI_SPLIT, 0>;
             kern<<<dim3(tiles128, 1), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4,
                                                       hw / 32, (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr,
                                                       S.d_count, max_count);
