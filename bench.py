@@ -26,6 +26,9 @@ import torch.distributed as dist  # noqa: E402
 
 F16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16/f16 MFMA dense
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
+# HBM bytes per fc0 row from the committed rocprofv3 --pmc passes (profiles/, B = 65536): FETCH_SIZE x 2 (gfx950
+# correction for 16-B/lane streaming reads) + WRITE_SIZE, divided by the rows of that launch.
+FC0_HBM_BYTES_PER_ROW = {15: 8.6e9 / 65536 + 134.7e6 / 65536}
 
 
 def parse():
@@ -174,7 +177,7 @@ def main():
         "metric": "self-play games/sec (15x15, 800 sims/move); MCTS nodes/sec",
         "value": games_per_s, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16x3 (split-fp16 MFMA operands, fp32 accumulate)" if args.net_mode == "f16x3" else "f32",
+        "dtype": "f16 (split hi+lo MFMA operands; fc0 correction terms in block-scaled fp8), fp32 accumulate" if args.net_mode == "f16x3" else "f32",
         "data": "synthetic (games from the empty board, random-init net seed 0)",
         "config": {"workload": f"{games} concurrent {n}x{n} games per GPU, {args.sims} sims/move, K={k}, two trees per game"
                                + ("" if complete else f", first {args.max_plies} plies only (games/s extrapolated)"),
@@ -182,10 +185,14 @@ def main():
                    "parallelism": f"games sharded x{world}, no hot-path collective" + (", RCCL replay gather" if args.gather else "")},
         "mcts_sims_per_s": sims / dt, "nn_evals_per_s": evals / dt, "plies_per_s": ply_games / dt,
         "mean_plies_per_game": mean_plies, "games_finished": finished,
-        "roofline": {"bound": "mfma", "kernel": "k_gemm_t<16,0> (fc0)", "achieved": fc0_tflops, "peak": F16_DENSE_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": fc0_tflops / F16_DENSE_PEAK_TFLOPS, "traffic": None,
-                     "note": "algorithmic flops (2*128*HW*512 per eval); the split-fp16 path issues 3 MFMAs per product, "
-                             "so frac <= 1/3 by construction"},
+        "roofline": {"bound": "mfma", "kernel": "k_fc0_mx (fc0)", "achieved": fc0_tflops, "peak": F16_DENSE_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": fc0_tflops / F16_DENSE_PEAK_TFLOPS,
+                     "traffic": FC0_HBM_BYTES_PER_ROW.get(n, 0) * st["fc0_rows"] / max(st["fc0_launches"], 1.0) or None,
+                     "traffic_unit": "HBM bytes per launch (rows per launch x per-row bytes of the committed PMC pass: "
+                                     "profiles/README.md; FETCH_SIZE x2 + WRITE_SIZE)",
+                     "algorithmic_bytes_per_launch": (128 * hw * 3 + 2048) * st["fc0_rows"] / max(st["fc0_launches"], 1.0) + 128 * hw * 512 * 3,
+                     "note": "algorithmic flops (2*128*HW*512 per eval); per K=64 the kernel issues 4 f16 + 2 block-scaled fp8 "
+                             "MFMAs (split operands) = 1.41x the pipe time of a plain-f16 product, so frac <= 0.71 by construction"},
         "roofline_net": {"bound": "mfma", "achieved": evals * flop_eval / net_s / 1e12 if net_s > 0 else 0.0,
                          "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (evals * flop_eval / net_s / 1e12 / F16_DENSE_PEAK_TFLOPS) if net_s > 0 else 0.0},

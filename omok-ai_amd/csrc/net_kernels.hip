@@ -1,10 +1,11 @@
 // net_kernels.hip — forward of the policy/value net (alpha-zero/src/network.rs:51-262, builders
 // network-utils/src/lib.rs:95-170,172-262,285-330,386-461) for gfx950.
 //
-// OMOK_NET_F16X3 (default): every contraction runs on v_mfma_f32_32x32x16_f16 with SPLIT fp16
-// operands: x = hi + lo (hi = f16(x), lo = f16(x - hi)), product = hi*hi + lo*hi + hi*lo in an
-// fp32 accumulator (3 MFMAs).  Plain fp16/bf16 inputs miss the 1e-3 parity bar on this net
-// (random-init logits have std ~9; tools/precision_study.py), split fp16 lands at ~1e-5.
+// OMOK_NET_F16X3 (default): every contraction uses SPLIT operands: x = hi + lo with hi = f16(x), product =
+// hi*hi + lo*hi + hi*lo in an fp32 accumulator.  Trunk, fc1 and heads run the three terms on
+// v_mfma_f32_32x32x16_f16 (lo = f16(x - hi)); fc0 runs hi*hi on the f16 MFMA and the two correction terms on the
+// block-scaled fp8 MFMA (k_fc0_mx).  Plain fp16/bf16 inputs miss the 1e-3 parity bar on this net (random-init
+// logits have std ~9; tools/precision_study.py); the split lands at 1e-5 (f16 terms) .. 1e-4 (fp8 terms).
 //
 // Everything is computed TRANSPOSED: D[out-feature, column] = W^T[out, in] * X[in, column] with the
 // column (pixel in the trunk, sample in the fc layers) on the MFMA lane.  A 32x32 accumulator
@@ -13,10 +14,11 @@
 //     kperm(T, s, h, j) = 32*T + 16*s + 8*(j>>2) + 4*h + (j&3)
 // and every weight matrix is packed on the host in exactly that k order (pack_A below).
 //
-//   k_trunk   one workgroup = one sample, one wave = one 32-pixel tile: conv_in (VALU, K=3) ->
+//   k_trunk   one workgroup = one sample, one wave = one 32-pixel tile: conv_in (one MFMA k-step) ->
 //             3 x { 1x1 128->32, depthwise 3x3 through an LDS halo grid, 1x1 32->32, 1x1 32->128 +
-//             residual } with all weights LDS-resident -> fc0 operand rows (hi|lo f16) in HBM
-//   k_gemm_t  D^T[M x samples] = Wp[M x K] * Act^T, 8 waves, LDS double buffer: fc0, fc1, heads
+//             residual } with all weights LDS-resident -> fc0 operand rows (f16 hi | fp8 residual) in HBM
+//   k_fc0_mx  fc0: 512 features x 128 samples per workgroup, one wave per SIMD, LDS-DMA rings
+//   k_gemm_t  D^T[M x samples] = Wp[M x K] * Act^T, 8 waves, LDS ring: fc1, heads
 //   k_softmax policy softmax + value tanh
 //
 // OMOK_NET_F32: naive fp32 VALU kernels (k-ascending sums), debug / A-B reference on the GPU.
