@@ -249,6 +249,13 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
     const bool valid = px < HW;
     const int pxc = valid ? px : HW - 1;
     const int gi = (pxc / N + 1) * (N + 2) + (pxc % N + 1);
+    int st_gi[4]; // halo-grid rows of the pixels this lane stores in the operand-row epilogue (pixel 8i + lane/8 of the tile)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = tile * 32 + 8 * i + (lane >> 3);
+        const int pc = p < HW ? p : HW - 1;
+        st_gi[i] = (pc / N + 1) * (N + 2) + (pc % N + 1);
+    }
     const half8* convW = (const half8*)(wt + TR_WBYTES / 16);
 
     // Inputs of a sample are fetched one sample ahead, BEFORE the output stores of the current sample are
@@ -496,15 +503,20 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
         // ---- fc0 operand row (k_fc0_mx): block (tile, q) = [pxl 32][256 B], one K=64 super-step per pixel and
         //      channel half q:  [0,128) f16 hi pieces of k-steps j = 2*(m&1)+s as [h0|h1];  [128,192) unused (the fp8 copy of x
         //      is derived from the f16 pieces inside k_fc0_mx);  [192,256) fp8 (x - hi)*2^(SA+11) as [h0 32 B | h1 32 B].  Byte slot of a lane = 16*(m&1) + reg. ----
-        // (lanes past the last pixel store into the pad slots of the row: without a branch around the stores the
-        //  compiler counts them exactly and the next sample's operand waits do not drain them)
+        //      Stores go through the sample's own halo-grid rows (free between the last depthwise read and the next
+        //      sample's first write; a wave touches only its own pixels' interior rows, so no barrier): a lane holds six
+        //      16-B pieces of ITS pixel, i.e. a direct store instruction touches 64 different cache lines with 16 B each
+        //      (one texture-path cycle per line).  Transposed through LDS, 8 adjacent lanes write one pixel's 128-B run:
+        //      8 full lines per instruction.  Three passes of 128 B per pixel: f16 part of q = 0, of q = 1, both fp8 parts.
+        //      (Lanes past the last pixel skip the LDS write; the read-back side then stores the clamped pixel's data into
+        //      the pad slots of the row: no branch around the global stores, so the compiler counts them exactly.)
         if (!(ABL & 2)) {
             uint4* row = a_out + (size_t)b * row_u4;
             const float sc_lo_inv = __uint_as_float((uint32_t)(127 - MX_SA - 11) << 23); // fp8 = (x - hi) / 2^-(SA+11)
+            uint4* stage_w = (uint4*)(grid + gi * GRID_STRIDE);          // this lane's pixel row (8 slots of 16 B)
+            uint32_t p8l[2][8];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                uint4* blkp = row + ((size_t)((tile * 2 + q) * 32 + pxl)) * 16;
-                uint32_t p8l[8];
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
@@ -523,14 +535,31 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
                             const int slot = 16 * mm + 8 * sx + 2 * jj; // byte slot of v0
                             const int w = slot >> 2;
                             if ((slot & 3) == 0)
-                                p8l[w] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(short2v{0, 0}, l0, l1, sc_lo_inv, false));
+                                p8l[q][w] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(short2v{0, 0}, l0, l1, sc_lo_inv, false));
                             else
-                                p8l[w] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(short2v, p8l[w]), l0, l1, sc_lo_inv, true));
+                                p8l[q][w] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(short2v, p8l[q][w]), l0, l1, sc_lo_inv, true));
                         }
-                        blkp[(mm * 2 + sx) * 2 + h] = H.v;
+                        if (valid) stage_w[(mm * 2 + sx) * 2 + h] = H.v;
                     }
-                blkp[12 + h * 2 + 0] = make_uint4(p8l[0], p8l[1], p8l[2], p8l[3]);
-                blkp[12 + h * 2 + 1] = make_uint4(p8l[4], p8l[5], p8l[6], p8l[7]);
+                // read back: lanes 8i'..8i'+7 hold the 8 pieces of pixel 8i + i' of the tile
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 v = *(const uint4*)(grid + st_gi[i] * GRID_STRIDE + 4 * (lane & 7));
+                    row[((size_t)((tile * 2 + q) * 32 + 8 * i + (lane >> 3))) * 16 + (lane & 7)] = v;
+                }
+            }
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    stage_w[q * 4 + h * 2 + 0] = make_uint4(p8l[q][0], p8l[q][1], p8l[q][2], p8l[q][3]);
+                    stage_w[q * 4 + h * 2 + 1] = make_uint4(p8l[q][4], p8l[q][5], p8l[q][6], p8l[q][7]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 v = *(const uint4*)(grid + st_gi[i] * GRID_STRIDE + 4 * (lane & 7));
+                const int q = (lane >> 2) & 1;
+                row[((size_t)((tile * 2 + q) * 32 + 8 * i + (lane >> 3))) * 16 + 12 + (lane & 3)] = v;
             }
         }
     }
@@ -900,9 +929,7 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
     };
     auto issue_one = [&](int i, int slot) { // one LDS-DMA instruction (1 KiB fragment) of k-step kt into ring slot `slot`
         const uint4* g = is_w[i] ? src[i] + (size_t)kt * (WFR * 64) : src[i] + ko_cur;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(lds + slot * STAGE_U4 + (wave + 8 * i) * 64),
-                                         16, 0, 0);
+        dma16(g, lds + slot * STAGE_U4 + (wave + 8 * i) * 64); // from asm: see dma16 (no compiler vmcnt(0) before the ds_reads)
     };
     auto issue = [&](int slot) {
         issue_begin();
