@@ -49,6 +49,8 @@ __device__ inline float lrelu(float x) {
 }
 
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline void nt_store(const uint4& v, uint4* p) { __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, (u32x4*)p); }
 typedef short short2v __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // x = hi + lo with hi = f16(x) (v_cvt_pk_f16_f32, round to nearest: two values per instruction) and
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const uint4 v = *(const uint4*)(grid + st_gi[i] * GRID_STRIDE + 4 * (lane & 7));
-                    if (!(ABL & 8)) { if (st_ok[i]) row[(size_t)(tile * 2 + q) * OP_BLK_U4 + (8 * i + (lane >> 3)) * 8 + (lane & 7)] = v; }
+                    if (!(ABL & 8)) { if (st_ok[i]) nt_store(v, &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + (8 * i + (lane >> 3)) * 8 + (lane & 7)]); }
                     else if (v.x == 0x12345678u && v.y == 0x9abcdef0u) row[lane] = v; // timing only: keep the staging alive
                 }
             }
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
             for (int i = 0; i < 4; ++i) {
                 const uint4 v = *(const uint4*)(grid + st_gi[i] * GRID_STRIDE + 4 * (lane & 7));
                 const int q = (lane >> 2) & 1;
-                if (!(ABL & 8)) { if (st_ok[i]) row[(size_t)(tile * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (8 * i + (lane >> 3)) * 4 + (lane & 3)] = v; }
+                if (!(ABL & 8)) { if (st_ok[i]) nt_store(v, &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (8 * i + (lane >> 3)) * 4 + (lane & 3)]); }
                 else if (v.x == 0x12345678u && v.y == 0x9abcdef0u) row[lane] = v;
             }
         }
@@ -608,9 +610,11 @@ __device__ inline void dma16(const uint4* g, const uint4* lds) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(a) : "memory", "m0");
 }
 // same with a wave-uniform 64-bit base in SGPRs and a 32-bit byte offset per lane: no 64-bit vector add per DMA
+template <bool NT = false>
 __device__ inline void dma16s(const uint4* sbase, uint32_t voff, const uint4* lds) {
     const uint32_t a = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(a) : "memory", "m0");
+    if (NT) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(a) : "memory", "m0");
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(a) : "memory", "m0");
 }
 // v_cvt_scalef32_pk_fp8_f16: fp8(x / scale), RNE, two f16 (one dword) per instruction into one half of the destination
 // (tools/probe/cvt_probe.hip).  From asm so that the first convert of a dword does not drag a zeroing v_mov along for
@@ -635,6 +639,7 @@ __device__ inline void f16x8_to_fp8(const half8& v, float inv_mul, uint32_t& d0,
 // super-step are read from LDS once and stay in registers for its 4 stages; a weight fragment is read from LDS by
 // exactly one wave.  LDS traffic per stage drops from 144 KiB (8-wave form) to ~48 KiB and the matrix pipe is fed
 // by one wave with 4 independent accumulator chains.
+constexpr bool A_NT = true;     // the sample-operand stream is read once: non-temporal, so it does not displace the weight stream in L2
 constexpr bool STAGGER = false; // (skewing the waves by s_nops after the barrier: 3.52 -> 3.88 ms, the delay costs more than it saves)
 template <int EPI, int DBG = 0> // DBG: timing-only ablations (1 = no weight DMA, 2 = no sample DMA, 4 = no fp8 derivation, 8 = no vmcnt waits)
 __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksup,
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     auto issue_a1 = [&](int uo, int buf, int k) {
         const int dst = k < 4 ? (wave * 4 + k) * 64 : 1024 + (wave * 2 + (k - 4)) * 64;
         const int blk = uo >> 5, pl = uo & 31; // f16 part: 8 uint4 per pixel; fp8 part: 4 per pixel behind the 32 x 8
-        if (!(DBG & 2)) dma16s(abase + blk * OP_BLK_U4 + (k < 4 ? pl * 8 : OP_LO_U4 + pl * 4), a_voff[k], ldsA + buf * MXS_U4 + dst);
+        if (!(DBG & 2)) dma16s<A_NT>(abase + blk * OP_BLK_U4 + (k < 4 ? pl * 8 : OP_LO_U4 + pl * 4), a_voff[k], ldsA + buf * MXS_U4 + dst);
     };
     // LDS read offsets (uint4 units) of this lane's pieces inside sample tile 0; tile c adds 256 / 128
     const int sl = lane & 31;
