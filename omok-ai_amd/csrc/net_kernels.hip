@@ -373,7 +373,9 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
             for (int m = 0; m < 4; ++m) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) x[m][i] = 0.0f;
-                MFMA3(cwh[m], cwl[m], bh, bl, x[m]);
+                x[m] = MFMA16(cwh[m], bh, x[m]);
+                x[m] = MFMA16(cwl[m], bh, x[m]);
+                if (FROM_F32) x[m] = MFMA16(cwh[m], bl, x[m]); // (board inputs are 0 / 1 and the bias 1: exact in f16, bl = 0)
                 LRELU16(x[m]);
             }
         }
@@ -406,7 +408,9 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
 #pragma unroll
                 for (int i = 0; i < 16; ++i) d[i] = lrelu(acc[i]);
             } else {
-            lds_barrier(); // B1: every wave has read its depthwise result of the previous block
+            // (no barrier here: a pixel's grid row is written below and was last read -- as depthwise output of the
+            //  previous block, or as staging row of the previous sample's operand stores -- by this same lane; the other
+            //  waves' window reads of it ended before B3 and their write-backs before B4 of the previous block)
             if (valid) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
