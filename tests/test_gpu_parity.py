@@ -118,6 +118,55 @@ def test_net_parity(n, mode):
     eng.close()
 
 
+def _random_positions(n, count, seed):
+    rng = np.random.default_rng(seed)
+    out = np.zeros((count, 3 * n * n), dtype=np.float32)
+    for i in range(count):
+        env = O.Environment(n)
+        for c in rng.permutation(n * n)[: int(rng.integers(0, n * n - 1))]:
+            env.place_stone(int(c))
+        out[i] = env.encode_nn_input(int(rng.integers(0, 2)))
+    return out
+
+
+def test_net_ragged_batches_are_row_independent():
+    """A row's result must not depend on what else is in the batch (empty, 1, tile-1, tile+1 rows): bit-identical."""
+    n = 15
+    eng = oa.Engine(board_size=n, games=32, max_nodes=16, max_tables=8, max_batch_k=16)
+    eng.load_random_weights(0)
+    x = _random_positions(n, 300, 11)
+    p, v = eng.evaluate_pv(x)
+    for b in (1, 31, 127, 128, 129, 257):
+        pb, vb = eng.evaluate_pv(x[:b])
+        assert np.array_equal(pb.view(np.uint32), p[:b].view(np.uint32)) and np.array_equal(vb.view(np.uint32), v[:b].view(np.uint32)), b
+    eng.close()
+
+
+def test_net_full_batch_kernel_path():
+    """Engines above 16384 rows run fc0 without split-K (k_fc0_mx<EPI_SPLIT>, the bench configuration): same results
+    as the split-K path of a small engine (different fp32 summation order in front of saturated softmaxes: 2e-4 allowed,
+    4e-5 seen), and within TOL of the oracle."""
+    n = 15
+    small = oa.Engine(board_size=n, games=32, max_nodes=16, max_tables=8, max_batch_k=16)
+    big = oa.Engine(board_size=n, games=1100, max_nodes=8, max_tables=4, max_batch_k=16)  # 17600 rows = 137.5 tiles
+    tensors = oa.weights.init_random(n, seed=0)
+    small.load_weights(tensors)
+    big.load_weights(tensors)
+    base = _random_positions(n, 400, 5)
+    x = np.tile(base, (44, 1))[:17600]  # full capacity in one launch, last tile half full
+    pb, vb = big.evaluate_pv(x)
+    ps, vs = small.evaluate_pv(base)
+    pb, ps = pb.reshape(len(x), -1), ps.reshape(len(base), -1)
+    vb, vs = vb.reshape(-1), vs.reshape(-1)
+    for r in (0, 1, 43):  # every copy of the base positions gives the same rows
+        assert np.array_equal(pb[r * 400:(r + 1) * 400].view(np.uint32), pb[:400].view(np.uint32))
+    assert np.abs(pb[:400] - ps).max() < 2e-4 and np.abs(vb[:400] - vs).max() < 2e-4
+    pc, vc = O.Net(n, tensors).forward(base[:96], threads=8)
+    assert np.abs(pb[:96] - pc).max() < TOL and np.abs(vb[:96] - vc).max() < TOL
+    small.close()
+    big.close()
+
+
 # ---- self-play: tree arithmetic bit-exact ---------------------------------------------------------
 def _compare_trees(sp, osp, games, tag):
     for g in range(games):
