@@ -68,6 +68,15 @@ int omok_net_num_tensors(void);
 int64_t omok_net_tensor_size(const omok_engine* e, int index);
 int omok_net_load(omok_engine* e, int index, const float* data, int64_t count);
 int omok_net_commit(omok_engine* e); /* pack into MFMA operand layouts; required before any eval */
+/* ModelIO::load (alpha-zero/src/model_io.rs:92-120): reads the reference's weights file = bincode 1.3.3 default
+ * encoding (little-endian, fixed-width u64 lengths) of SavedData{variable_names: Vec<String>, parameters: Vec<Vec<f32>>}
+ * (model_io.rs:20-24).  Loading is POSITIONAL like the reference's zip over `parameters` (:98): names are ignored,
+ * parameters beyond the 31st are ignored, fewer than 31 or a length that differs from the variable's element count is an
+ * error (the reference fails in session.run / copy_from_slice).  Commits the net on success. */
+int omok_net_load_file(omok_engine* e, const char* path);
+/* ModelIO::save (model_io.rs:59-90): writes the same format from the tensors currently loaded (canonical names
+ * conv_w, conv_b, residual_{i}_..., fc0_w, ...; the reference stores TF-uniquified names and never reads them back). */
+int omok_net_save_file(omok_engine* e, const char* path);
 /* AgentModel::evaluate_pv (agent_model.rs:116-134): in [B][N][N][3] f32 (encoder.rs layout),
  * p [B][N*N] softmax probabilities, v [B] tanh.  evaluate_p (:105-114) = same with v NULL. */
 int omok_evaluate_pv(omok_engine* e, const float* in, int32_t batch, float* p, float* v);

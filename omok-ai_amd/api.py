@@ -11,6 +11,8 @@ All compute happens in the HIP library; nothing here has a CPU path.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import binding as B
@@ -57,6 +59,14 @@ class Engine:
             t = np.ascontiguousarray(t, dtype=np.float32).ravel()
             self._chk(B.lib().omok_net_load(self.h, i, B.fptr(t), t.size))
         self._chk(B.lib().omok_net_commit(self.h))
+
+    def load(self, path):
+        """ModelIO::load (alpha-zero/src/model_io.rs:92-120): the reference's bincode weights file, positional."""
+        self._chk(B.lib().omok_net_load_file(self.h, os.fsencode(path)))
+
+    def save(self, path):
+        """ModelIO::save (alpha-zero/src/model_io.rs:59-90)."""
+        self._chk(B.lib().omok_net_save_file(self.h, os.fsencode(path)))
 
     def load_random_weights(self, seed=0):
         self.load_weights(W.init_random(self.n, seed))

@@ -18,7 +18,7 @@ STAT_NAMES = ["sims", "evals", "ply_games", "finished", "ms_tree", "ms_trunk", "
 # every symbol include/omok_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "omok_create", "omok_destroy", "omok_last_error", "omok_net_num_tensors", "omok_net_tensor_size", "omok_net_load",
-    "omok_net_commit", "omok_evaluate_pv", "omok_env_play", "omok_encode_nn_input", "omok_selfplay_reset", "omok_execute",
+    "omok_net_commit", "omok_net_load_file", "omok_net_save_file", "omok_evaluate_pv", "omok_env_play", "omok_encode_nn_input", "omok_selfplay_reset", "omok_execute",
     "omok_sample_actions", "omok_advance", "omok_selfplay_run", "omok_round_generate", "omok_round_inputs",
     "omok_round_eval", "omok_round_outputs", "omok_round_inject", "omok_round_scatter", "omok_mirror_generate",
     "omok_mirror_inputs", "omok_mirror_eval", "omok_mirror_outputs", "omok_mirror_inject", "omok_mirror_apply",
@@ -66,6 +66,8 @@ def lib():
     L.omok_net_tensor_size.restype = C.c_int64
     L.omok_net_load.argtypes = [H, C.c_int, fp, C.c_int64]
     L.omok_net_commit.argtypes = [H]
+    L.omok_net_load_file.argtypes = [H, C.c_char_p]
+    L.omok_net_save_file.argtypes = [H, C.c_char_p]
     L.omok_evaluate_pv.argtypes = [H, fp, C.c_int32, fp, fp]
     L.omok_env_play.argtypes = [H, ip, C.c_int32, C.c_int32, ip, u8p, u8p, C.POINTER(C.c_uint16)]
     L.omok_encode_nn_input.argtypes = [H, u8p, u8p, C.c_int32, C.c_int32, fp]

@@ -293,6 +293,93 @@ extern "C" int omok_net_commit(omok_engine* e) {
     return OMOK_OK;
 }
 
+// ---- weights file: ModelIO::save / ModelIO::load (alpha-zero/src/model_io.rs:20-24,59-120) ---------------------
+// bincode 1.3.3 default options: little-endian, fixed-width integers; Vec<T> = u64 length + elements; String = u64
+// byte length + UTF-8 bytes.  SavedData = { variable_names: Vec<String>, parameters: Vec<Vec<f32>> }.
+static const char* net_tensor_name(int i, char* buf, size_t cap) {
+    static const char* head[2] = {"conv_w", "conv_b"};
+    static const char* blk[7] = {"conv0_w", "conv0_b", "conv1_w(depthwise)", "conv1_w(pointwise)", "conv1_b", "conv2_w", "conv2_b"};
+    static const char* tail[8] = {"fc0_w", "fc0_b", "fc1_w", "fc1_b", "v_fc0_w", "v_fc0_b", "p_fc0_w", "p_fc0_b"};
+    if (i < 2) snprintf(buf, cap, "%s", head[i]);
+    else if (i < 23) snprintf(buf, cap, "residual_%d_%s", (i - 2) / 7, blk[(i - 2) % 7]);
+    else snprintf(buf, cap, "%s", tail[i - 23]);
+    return buf;
+}
+
+static bool rd_u64(FILE* f, uint64_t* v) {
+    unsigned char b[8];
+    if (fread(b, 1, 8, f) != 8) return false;
+    uint64_t x = 0;
+    for (int i = 7; i >= 0; --i) x = (x << 8) | b[i];
+    *v = x;
+    return true;
+}
+static bool wr_u64(FILE* f, uint64_t v) {
+    unsigned char b[8];
+    for (int i = 0; i < 8; ++i) b[i] = (unsigned char)(v >> (8 * i));
+    return fwrite(b, 1, 8, f) == 8;
+}
+
+extern "C" int omok_net_load_file(omok_engine* e, const char* path) {
+    if (!e || !path) return OMOK_ERR_INVALID;
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(e, OMOK_ERR_INVALID, "cannot open weights file %s", path);
+    fseek(f, 0, SEEK_END);
+    const long long fsize = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    int rc = OMOK_OK;
+    uint64_t n_names = 0, n_params = 0;
+    std::vector<std::vector<float>> params(NET_TENSORS); // validated completely before the engine is touched
+    if (!rd_u64(f, &n_names) || (long long)n_names > fsize / 8) rc = fail(e, OMOK_ERR_INVALID, "weights file %s: bad name count", path);
+    for (uint64_t i = 0; rc == OMOK_OK && i < n_names; ++i) { // names are skipped: the load is positional (model_io.rs:98)
+        uint64_t len = 0;
+        if (!rd_u64(f, &len) || (long long)len > fsize || fseek(f, (long)len, SEEK_CUR) != 0) rc = fail(e, OMOK_ERR_INVALID, "weights file %s: truncated in variable_names", path);
+    }
+    if (rc == OMOK_OK && (!rd_u64(f, &n_params) || (long long)n_params > fsize / 8)) rc = fail(e, OMOK_ERR_INVALID, "weights file %s: bad parameter count", path);
+    if (rc == OMOK_OK && n_params < (uint64_t)NET_TENSORS)
+        rc = fail(e, OMOK_ERR_INVALID, "weights file %s holds %llu parameter vectors, the net has %d variables", path, (unsigned long long)n_params, NET_TENSORS);
+    for (int i = 0; rc == OMOK_OK && i < NET_TENSORS; ++i) {
+        uint64_t len = 0;
+        if (!rd_u64(f, &len)) { rc = fail(e, OMOK_ERR_INVALID, "weights file %s: truncated at parameter %d", path, i); break; }
+        if ((int64_t)len != e->net.wsize[i]) { // Tensor::copy_from_slice panics on a length mismatch (model_io.rs:106)
+            rc = fail(e, OMOK_ERR_INVALID, "weights file %s: parameter %d has %llu values, variable has %lld", path, i, (unsigned long long)len, (long long)e->net.wsize[i]);
+            break;
+        }
+        params[i].resize((size_t)len); // (host is little-endian like the file)
+        if (fread(params[i].data(), sizeof(float), (size_t)len, f) != (size_t)len) { rc = fail(e, OMOK_ERR_INVALID, "weights file %s: truncated inside parameter %d", path, i); break; }
+    }
+    fclose(f);
+    for (int i = 0; rc == OMOK_OK && i < NET_TENSORS; ++i) rc = omok_net_load(e, i, params[i].data(), (int64_t)params[i].size());
+    if (rc != OMOK_OK) return rc;
+    return omok_net_commit(e);
+}
+
+extern "C" int omok_net_save_file(omok_engine* e, const char* path) {
+    if (!e || !path) return OMOK_ERR_INVALID;
+    for (int i = 0; i < NET_TENSORS; ++i)
+        if (!e->net.loaded[i]) return fail(e, OMOK_ERR_STATE, "tensor %d was never loaded", i);
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(e, OMOK_ERR_INVALID, "cannot create weights file %s", path);
+    bool ok = wr_u64(f, NET_TENSORS);
+    char name[64];
+    for (int i = 0; ok && i < NET_TENSORS; ++i) {
+        net_tensor_name(i, name, sizeof(name));
+        const size_t len = strlen(name);
+        ok = wr_u64(f, len) && fwrite(name, 1, len, f) == len;
+    }
+    ok = ok && wr_u64(f, NET_TENSORS);
+    std::vector<float> buf;
+    for (int i = 0; ok && i < NET_TENSORS; ++i) {
+        const size_t len = (size_t)e->net.wsize[i];
+        buf.resize(len);
+        if (hipMemcpy(buf.data(), e->net.w[i], sizeof(float) * len, hipMemcpyDeviceToHost) != hipSuccess) { fclose(f); return fail(e, OMOK_ERR_HIP, "weight read-back failed"); }
+        ok = wr_u64(f, len) && fwrite(buf.data(), sizeof(float), len, f) == len;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? OMOK_OK : fail(e, OMOK_ERR_INVALID, "short write to %s", path);
+}
+
 static int need_net(omok_engine* e) {
     if (!e->net.committed) return fail(e, OMOK_ERR_STATE, "net not loaded/committed (omok_net_load x31 + omok_net_commit)");
     return 0;
