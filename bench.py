@@ -203,6 +203,21 @@ def main():
         "game_length_percentiles": {str(q): float(np.percentile(plies, q)) for q in (0, 10, 25, 50, 75, 90, 99, 100)},
         "arena": {"max_nodes": max_nodes, "max_tables": max_tables, "peak_nodes": st["peak_nodes"], "peak_tables": st["peak_tables"]},
     }
+    if complete:  # outside the timed region: the episode-end replay post-processing row on the device
+        rec = sp.replay_record_bytes()
+        n_rec = 6 * int(plies.sum())
+        buf = torch.empty(max(n_rec, 1) * rec, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        sp.replay_augment_into(buf.data_ptr(), n_rec)  # warm-up
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        got = sp.replay_augment_into(buf.data_ptr(), n_rec)
+        dt_pp = time.perf_counter() - t1
+        nw = (hw + 63) // 64
+        alg = (n_rec // 6) * (16 * nw + 1 + 4 * hw + 4) + n_rec * rec  # transitions read once + records written
+        out["replay_postprocess"] = {"records": got, "ms": 1e3 * dt_pp, "bound": "hbm", "achieved": alg / dt_pp / 1e9, "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": alg / dt_pp / 1e9 / HBM_PEAK_GBS,
+                                     "note": "z back-fill + 5 augmentations per transition (trainer.rs:207-324), rank 0, host-timed call"}
+        del buf
     if args.cpu_seconds > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, max(mean_plies, 1.0))
     print(json.dumps(out))

@@ -150,6 +150,15 @@ int omok_replay_game(omok_engine* e, int32_t game, uint8_t* boards, uint8_t* tur
  * pointer the caller owns, e.g. a torch tensor) and returns the record count. */
 int64_t omok_replay_pack_dev(omok_engine* e, void* dst_dev, int64_t cap_records);
 int32_t omok_replay_record_bytes(const omok_engine* e);
+/* Replay post-processing of Trainer::train (src/trainer.rs:207-324) on the device.  Per game, in game-id order (the
+ * reference appends games in completion order): the game's L transitions with z back-filled (walking backwards from the
+ * last transition z alternates sign, :209-214), then 5L augmented copies, transition-major, in the reference's order
+ * rotate_90, rotate_180, rotate_270, flip_horizontal, flip_vertical of board and policy (src/utils.rs:1-64), turn and z
+ * unchanged.  Records as in omok_replay_pack_dev.  Returns the record count 6 * sum(L) (records beyond cap are dropped). */
+int64_t omok_replay_augment_dev(omok_engine* e, void* dst_dev, int64_t cap_records);
+/* the same for one game into host arrays ([6L][N*N] boards / pi, [6L] turns / z); returns 6L */
+int omok_replay_augmented_game(omok_engine* e, int32_t game, uint8_t* boards, uint8_t* turns, float* pi, float* z,
+                               int32_t cap_records);
 
 #define OMOK_STAT_SIMS 0        /* simulations run (incl. terminal hits / no-action sims) */
 #define OMOK_STAT_EVALS 1       /* net evaluations (search requests + mirror evals + root) */

@@ -268,6 +268,23 @@ class SelfPlay:
         n = self._chk(B.lib().omok_replay_game(self.h, game, B.u8ptr(boards), B.u8ptr(turns), B.fptr(pi), B.fptr(z), cap))
         return boards[:n], turns[:n], pi[:n], z[:n]
 
+    def replay_augmented(self, game):
+        """Trainer::train replay post-processing for one game (src/trainer.rs:207-324): z back-fill, then the game's
+        transitions followed by their 5 augmentations each (rot90, rot180, rot270, flipH, flipV)."""
+        cap = 6 * self.hw
+        boards = np.zeros((cap, self.hw), dtype=np.uint8)
+        turns = np.zeros(cap, dtype=np.uint8)
+        pi = np.zeros((cap, self.hw), dtype=np.float32)
+        z = np.zeros(cap, dtype=np.float32)
+        n = self._chk(B.lib().omok_replay_augmented_game(self.h, game, B.u8ptr(boards), B.u8ptr(turns), B.fptr(pi), B.fptr(z), cap))
+        return boards[:n], turns[:n], pi[:n], z[:n]
+
+    def replay_augment_into(self, dev_ptr, cap_records):
+        n = B.lib().omok_replay_augment_dev(self.h, C.c_void_p(dev_ptr), cap_records)
+        if n < 0:
+            raise B.OmokError(int(n), B.lib().omok_last_error(self.h).decode())
+        return int(n)
+
     def replay_record_bytes(self):
         return self._chk(B.lib().omok_replay_record_bytes(self.h))
 

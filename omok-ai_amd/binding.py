@@ -23,7 +23,7 @@ SYMBOLS = [
     "omok_round_eval", "omok_round_outputs", "omok_round_inject", "omok_round_scatter", "omok_mirror_generate",
     "omok_mirror_inputs", "omok_mirror_eval", "omok_mirror_outputs", "omok_mirror_inject", "omok_mirror_apply",
     "omok_alive_count", "omok_current_ply", "omok_game_info", "omok_tree_dump", "omok_tree_root", "omok_replay_game",
-    "omok_replay_pack_dev", "omok_replay_record_bytes", "omok_get_stats", "omok_reset_stats", "omok_set_profiling",
+    "omok_replay_pack_dev", "omok_replay_record_bytes", "omok_replay_augment_dev", "omok_replay_augmented_game", "omok_get_stats", "omok_reset_stats", "omok_set_profiling",
 ]
 
 
@@ -97,6 +97,9 @@ def lib():
     L.omok_replay_game.argtypes = [H, C.c_int32, u8p, u8p, fp, fp, C.c_int32]
     L.omok_replay_pack_dev.argtypes = [H, C.c_void_p, C.c_int64]
     L.omok_replay_pack_dev.restype = C.c_int64
+    L.omok_replay_augment_dev.argtypes = [H, C.c_void_p, C.c_int64]
+    L.omok_replay_augment_dev.restype = C.c_int64
+    L.omok_replay_augmented_game.argtypes = [H, C.c_int32, u8p, u8p, fp, fp, C.c_int32]
     L.omok_replay_record_bytes.argtypes = [H]
     L.omok_get_stats.argtypes = [H, C.POINTER(C.c_double)]
     L.omok_reset_stats.argtypes = [H]

@@ -112,6 +112,9 @@ void launch_encode_boards(int n, const uint8_t* boards_dev, const uint8_t* turns
                           float* out_dev, hipStream_t st);
 void launch_replay_pack(int n, const Store& S, uint8_t* dst_dev, long long cap_records, long long* d_total,
                         hipStream_t st);
+void launch_replay_offsets(int n, const Store& S, long long* offsets_dev /*[games + 1]*/, hipStream_t st);
+void launch_replay_augment(int n, const Store& S, const long long* offsets_dev, int game_first, int game_count, long long base_sub,
+                           uint8_t* dst_dev, long long cap_records, hipStream_t st);
 size_t advance_lds_bytes(int cap_nodes, int cap_tables);
 
 // ---- net_kernels.hip --------------------------------------------------------------------------

@@ -89,6 +89,8 @@ struct omok_engine {
     uint32_t* d_error = nullptr; // [0] error bits, [1] alive count
     unsigned long long* d_evals = nullptr;
     long long* d_pack_total = nullptr;
+    long long* d_aug_offsets = nullptr; // [games + 1] first augmented-replay record of every game
+    uint8_t* d_aug_scratch = nullptr;   // one game's 6 * HW records (omok_replay_augmented_game)
     // host-side stats
     double sims = 0, evals = 0, ply_games = 0, finished = 0;
     uint32_t peak_nodes = 0, peak_tables = 0;
@@ -235,6 +237,7 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     rc |= dalloc(e, &e->d_error, 4);
     rc |= dalloc(e, &e->d_evals, 2);
     rc |= dalloc(e, &e->d_pack_total, 2);
+    rc |= dalloc(e, &e->d_aug_offsets, G + 1);
     if (rc) {
         g_create_error = e->err;
         omok_destroy(e);
@@ -888,6 +891,44 @@ extern "C" int64_t omok_replay_pack_dev(omok_engine* e, void* dst_dev, int64_t c
     long long total = 0;
     if (hipMemcpyAsync(&total, e->d_pack_total, 8, hipMemcpyDeviceToHost, e->st) != hipSuccess) return OMOK_ERR_HIP;
     if (sync_and_check(e, "replay_pack")) return OMOK_ERR_HIP;
+    return total;
+}
+
+// ---- replay post-processing (src/trainer.rs:207-324) ----------------------------------------------------------------
+extern "C" int64_t omok_replay_augment_dev(omok_engine* e, void* dst_dev, int64_t cap_records) {
+    if (!e || !dst_dev || cap_records < 0) return OMOK_ERR_INVALID;
+    if (hipSetDevice(e->cfg.device) != hipSuccess) return OMOK_ERR_HIP;
+    launch_replay_offsets(e->n, e->S, e->d_aug_offsets, e->st);
+    launch_replay_augment(e->n, e->S, e->d_aug_offsets, 0, e->cfg.games, 0, (uint8_t*)dst_dev, cap_records, e->st);
+    long long total = 0;
+    if (hipMemcpyAsync(&total, e->d_aug_offsets + e->cfg.games, 8, hipMemcpyDeviceToHost, e->st) != hipSuccess) return OMOK_ERR_HIP;
+    if (sync_and_check(e, "replay_augment")) return OMOK_ERR_HIP;
+    return total;
+}
+
+extern "C" int omok_replay_augmented_game(omok_engine* e, int32_t game, uint8_t* boards, uint8_t* turns, float* pi, float* z, int32_t cap_records) {
+    if (!e || game < 0 || game >= e->cfg.games || cap_records < 0) return OMOK_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    const size_t hw = (size_t)e->hw, brd = (hw + 1 + 3) / 4 * 4, rec = brd + 4 * hw + 4, max_rec = 6 * hw;
+    if (!e->d_aug_scratch && dalloc(e, &e->d_aug_scratch, max_rec * rec)) return OMOK_ERR_HIP;
+    long long off[2] = {0, 0};
+    launch_replay_offsets(e->n, e->S, e->d_aug_offsets, e->st);
+    HIPCHK(e, hipMemcpyAsync(off, e->d_aug_offsets + game, 16, hipMemcpyDeviceToHost, e->st));
+    if (sync_and_check(e, "replay_augmented_game")) return OMOK_ERR_HIP;
+    const int total = (int)(off[1] - off[0]);
+    const int n = total < cap_records ? total : cap_records;
+    if (n <= 0) return total;
+    launch_replay_augment(e->n, e->S, e->d_aug_offsets, game, 1, off[0], e->d_aug_scratch, (long long)max_rec, e->st);
+    std::vector<uint8_t> host((size_t)total * rec);
+    HIPCHK(e, hipMemcpyAsync(host.data(), e->d_aug_scratch, host.size(), hipMemcpyDeviceToHost, e->st));
+    if (sync_and_check(e, "replay_augmented_game")) return OMOK_ERR_HIP;
+    for (int i = 0; i < n; ++i) {
+        const uint8_t* r = host.data() + (size_t)i * rec;
+        if (boards) memcpy(boards + (size_t)i * hw, r, hw);
+        if (turns) turns[i] = r[hw];
+        if (pi) memcpy(pi + (size_t)i * hw, r + brd, 4 * hw);
+        if (z) memcpy(z + i, r + brd + 4 * hw, 4);
+    }
     return total;
 }
 

@@ -1119,6 +1119,82 @@ __global__ __launch_bounds__(64) void k_replay_pack(Store S, uint8_t* __restrict
     }
 }
 
+// Replay post-processing of Trainer::train (src/trainer.rs:207-324) on the device, one wave per transition:
+//   z back-fill: walking the game backwards from its last transition, z alternates sign (:209-214);
+//   five augmented copies per transition, in the reference's order rotate_90, rotate_180, rotate_270, flip_horizontal,
+//   flip_vertical of board and policy (:222-318, src/utils.rs:1-64), same z.
+// Output per game (game-id order; the reference appends games in completion order): the L back-filled transitions
+// (replay_memory.extend(transitions), :320), then the 5L augmented ones, transition-major (:321).  Record layout as in
+// k_replay_pack.  offsets[g] = first record of game g (exclusive scan of 6 * plies).
+template <int N>
+__global__ void k_replay_offsets(Store S, long long* __restrict__ offsets) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    long long acc = 0;
+    for (int g = 0; g < S.games; ++g) {
+        offsets[g] = acc;
+        const int plies = S.gs[g].plies < Geo<N>::HW ? S.gs[g].plies : Geo<N>::HW;
+        acc += 6LL * plies;
+    }
+    offsets[S.games] = acc;
+}
+
+template <int N>
+__device__ inline int aug_src(int k, int a) { // source cell of destination cell a under transform k (src/utils.rs)
+    const int i = a / N, j = a % N;
+    switch (k) {
+        case 1: return (N - j - 1) * N + i;           // rotate_90   :7-11
+        case 2: return (N - i - 1) * N + (N - j - 1); // rotate_180  :20-24
+        case 3: return j * N + (N - i - 1);           // rotate_270  :33-37
+        case 4: return i * N + (N - j - 1);           // flip_horizontal :46-50
+        case 5: return (N - i - 1) * N + j;           // flip_vertical   :59-63
+        default: return a;
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_replay_augment(Store S, const long long* __restrict__ offsets, int game_first, long long base_sub,
+                                                       uint8_t* __restrict__ dst, long long cap) {
+    using G = Geo<N>;
+    constexpr int NW = G::NW, ROWP = G::ROWP;
+    constexpr int BRD = (G::HW + 1 + 3) / 4 * 4, REC = BRD + 4 * G::HW + 4;
+    const int g = game_first + blockIdx.y; // one wave per transition: grid = (HW plies, games)
+    const int lane = LANE;
+    const int L = S.gs[g].plies < G::HW ? S.gs[g].plies : G::HW;
+    const int p = blockIdx.x;
+    if (p >= L) return;
+    const long long base = offsets[g] - base_sub;
+    const float z_last = S.rp_z[(size_t)g * G::HW + (L - 1)];
+    {
+        const size_t rec = (size_t)g * G::HW + p;
+        const float z = ((L - 1 - p) & 1) ? -z_last : z_last; // transition.z = z; z = -z; (:211-214), incl. the sign of zero
+        uint64_t bw[NW], ww[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { bw[i] = S.rp_board[rec * (2 * NW) + i]; ww[i] = S.rp_board[rec * (2 * NW) + NW + i]; }
+        const uint8_t turn = S.rp_turn[rec];
+        for (int k = 0; k < 6; ++k) {
+            const long long idx = k == 0 ? base + p : base + L + 5LL * p + (k - 1);
+            if (idx >= cap) continue;
+            uint8_t* r = dst + (size_t)idx * REC;
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) {
+                const int a = j * 64 + lane;
+                if (a < G::HW) {
+                    const int s = aug_src<N>(k, a);
+                    uint64_t b = bw[0], w = ww[0];
+#pragma unroll
+                    for (int i = 1; i < NW; ++i) { b = (s >> 6) == i ? bw[i] : b; w = (s >> 6) == i ? ww[i] : w; }
+                    r[a] = (uint8_t)(((b >> (s & 63)) & 1ULL) ? 1 : (((w >> (s & 63)) & 1ULL) ? 2 : 0));
+                    ((float*)(r + BRD))[a] = S.rp_pi[rec * ROWP + s];
+                }
+            }
+            if (lane == 0) {
+                r[G::HW] = turn; // env.turn is cloned unchanged (:224)
+                ((float*)(r + BRD))[G::HW] = z;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -1166,6 +1242,15 @@ void launch_env_play(int n, const int32_t* moves, int batch, int len, int32_t* s
 void launch_encode_boards(int n, const uint8_t* boards, const uint8_t* turns, int batch, int mode, float* out, hipStream_t st) {
     DISPATCH_N(n, (k_encode_boards<9><<<batch, 256, 0, st>>>(boards, turns, mode, out)),
                (k_encode_boards<15><<<batch, 256, 0, st>>>(boards, turns, mode, out)));
+}
+void launch_replay_offsets(int n, const Store& S, long long* offsets, hipStream_t st) {
+    DISPATCH_N(n, (k_replay_offsets<9><<<1, 64, 0, st>>>(S, offsets)), (k_replay_offsets<15><<<1, 64, 0, st>>>(S, offsets)));
+}
+void launch_replay_augment(int n, const Store& S, const long long* offsets, int game_first, int game_count, long long base_sub,
+                           uint8_t* dst, long long cap, hipStream_t st) {
+    if (game_count <= 0) return;
+    DISPATCH_N(n, (k_replay_augment<9><<<dim3(81, game_count), 64, 0, st>>>(S, offsets, game_first, base_sub, dst, cap)),
+               (k_replay_augment<15><<<dim3(225, game_count), 64, 0, st>>>(S, offsets, game_first, base_sub, dst, cap)));
 }
 void launch_replay_pack(int n, const Store& S, uint8_t* dst, long long cap, long long* d_total, hipStream_t st) {
     DISPATCH_N(n, (k_replay_pack<9><<<S.games, 64, 0, st>>>(S, dst, cap, d_total)),

@@ -87,3 +87,53 @@ void orc_flip_vertical(const float* src, float* dst, int size) {
     for (int i = 0; i < size; ++i)
         for (int j = 0; j < size; ++j) dst[i * size + j] = src[(size - i - 1) * size + j];
 }
+
+/* Replay post-processing of Trainer::train, src/trainer.rs:207-324, for ONE game of `len` transitions.
+ * in : boards [len][hw] Stone bytes, turns [len], pi [len][hw], z [len] (z as recorded at play time, :156-173)
+ * out: 6*len records: first the transitions with z back-filled (:209-214: z = last.z; walking backwards
+ *      transition.z = z; z = -z), then per transition (:222-318) rotate_90, rotate_180, rotate_270, flip_horizontal,
+ *      flip_vertical of env.board and policy (env.turn cloned, z copied); replay_memory.extend(transitions) then
+ *      .extend(augmented) (:320-321). */
+static void orc_xform_u8(int k, const uint8_t* src, uint8_t* dst, int n) {
+    float a[ORC_MAX_HW], b[ORC_MAX_HW];
+    for (int i = 0; i < n * n; ++i) a[i] = (float)src[i];
+    switch (k) {
+        case 0: orc_rotate_90(a, b, n); break;
+        case 1: orc_rotate_180(a, b, n); break;
+        case 2: orc_rotate_270(a, b, n); break;
+        case 3: orc_flip_horizontal(a, b, n); break;
+        default: orc_flip_vertical(a, b, n); break;
+    }
+    for (int i = 0; i < n * n; ++i) dst[i] = (uint8_t)b[i];
+}
+static void orc_xform_f32(int k, const float* src, float* dst, int n) {
+    switch (k) {
+        case 0: orc_rotate_90(src, dst, n); break;
+        case 1: orc_rotate_180(src, dst, n); break;
+        case 2: orc_rotate_270(src, dst, n); break;
+        case 3: orc_flip_horizontal(src, dst, n); break;
+        default: orc_flip_vertical(src, dst, n); break;
+    }
+}
+void orc_replay_postprocess(int n, int len, const uint8_t* boards, const uint8_t* turns, const float* pi, const float* z_in,
+                            uint8_t* boards_out, uint8_t* turns_out, float* pi_out, float* z_out) {
+    const int hw = n * n;
+    if (len <= 0) return;
+    float z = z_in[len - 1];
+    for (int t = len - 1; t >= 0; --t) { /* :211-214 */
+        z_out[t] = z;
+        z = -z;
+    }
+    for (int t = 0; t < len; ++t) { /* :320 */
+        for (int i = 0; i < hw; ++i) { boards_out[(size_t)t * hw + i] = boards[(size_t)t * hw + i]; pi_out[(size_t)t * hw + i] = pi[(size_t)t * hw + i]; }
+        turns_out[t] = turns[t];
+    }
+    for (int t = 0; t < len; ++t)
+        for (int k = 0; k < 5; ++k) { /* :222-318, :321 */
+            const size_t o = (size_t)len + 5 * (size_t)t + k;
+            orc_xform_u8(k, boards + (size_t)t * hw, boards_out + o * hw, n);
+            orc_xform_f32(k, pi + (size_t)t * hw, pi_out + o * hw, n);
+            turns_out[o] = turns[t];
+            z_out[o] = z_out[t];
+        }
+}

@@ -61,6 +61,9 @@ void orc_rotate_180(const float* src, float* dst, int size);
 void orc_rotate_270(const float* src, float* dst, int size);
 void orc_flip_horizontal(const float* src, float* dst, int size);
 void orc_flip_vertical(const float* src, float* dst, int size);
+/* replay post-processing of one game (src/trainer.rs:207-324): z back-fill + 5 augmentations per transition */
+void orc_replay_postprocess(int n, int len, const uint8_t* boards, const uint8_t* turns, const float* pi, const float* z_in,
+                            uint8_t* boards_out, uint8_t* turns_out, float* pi_out, float* z_out);
 
 /* ---- RNG contract ---- */
 enum { ORC_RNG_EXPAND = 1, ORC_RNG_NOISE = 2, ORC_RNG_SAMPLE = 3 };

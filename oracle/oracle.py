@@ -45,6 +45,9 @@ def lib():
     L.orc_encode_nn_input.argtypes = [C.POINTER(Env), C.c_int, fp]
     for name in ("orc_rotate_90", "orc_rotate_180", "orc_rotate_270", "orc_flip_horizontal", "orc_flip_vertical"):
         getattr(L, name).argtypes = [fp, fp, C.c_int]
+    u8 = C.POINTER(C.c_uint8)
+    L.orc_replay_postprocess.argtypes = [C.c_int, C.c_int, u8, u8, fp, fp, u8, u8, fp, fp]
+    L.orc_replay_postprocess.restype = None
     L.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.orc_det_log.argtypes = [C.c_double]
     L.orc_det_log.restype = C.c_double
@@ -251,3 +254,22 @@ class SelfPlay:
                                      max_plies, threads, stats)
         keys = ("sims", "evals", "ply_games", "finished", "t_net", "t_total")
         return err, dict(zip(keys, list(stats)))
+
+
+def replay_postprocess(n, boards, turns, pi, z):
+    """Trainer::train replay post-processing of one game (src/trainer.rs:207-324): returns 6*len records."""
+    hw = n * n
+    ln = len(turns)
+    boards = np.ascontiguousarray(boards, dtype=np.uint8).reshape(ln, hw)
+    turns = np.ascontiguousarray(turns, dtype=np.uint8)
+    pi = np.ascontiguousarray(pi, dtype=np.float32).reshape(ln, hw)
+    z = np.ascontiguousarray(z, dtype=np.float32)
+    bo = np.zeros((6 * ln, hw), dtype=np.uint8)
+    to = np.zeros(6 * ln, dtype=np.uint8)
+    po = np.zeros((6 * ln, hw), dtype=np.float32)
+    zo = np.zeros(6 * ln, dtype=np.float32)
+    u8 = C.POINTER(C.c_uint8)
+    fp = C.POINTER(C.c_float)
+    lib().orc_replay_postprocess(n, ln, boards.ctypes.data_as(u8), turns.ctypes.data_as(u8), pi.ctypes.data_as(fp), z.ctypes.data_as(fp),
+                                 bo.ctypes.data_as(u8), to.ctypes.data_as(u8), po.ctypes.data_as(fp), zo.ctypes.data_as(fp))
+    return bo, to, po, zo
