@@ -215,15 +215,20 @@ struct TrunkGeo {
     static constexpr int ROW_U4 = TILES * 2 * OP_BLK_U4;
     static constexpr int GRID_ROWS = (N + 2) * (N + 2) + 1; // +1: the 3x6 window of the last strip may touch one row more
     static constexpr int GRID_BYTES = GRID_ROWS * GRID_STRIDE * 4;
-    static constexpr int LDS_BYTES = TR_WBYTES + GRID_BYTES + TR_SIDE_FLOATS * 4;
-    static constexpr int SPR = (N + 3) / 4;        // depthwise strips (4 pixels) per board row
+    // samples per workgroup: at N = 9 a sample is only 3 waves and the LDS-resident weights allow one workgroup per CU,
+    // so two samples (each with its own halo grid) share a workgroup and its barriers; at N = 15 two grids do not fit
+    static constexpr int SPW = N == 9 ? 2 : 1;
+    static constexpr int LDS_BYTES = TR_WBYTES + SPW * GRID_BYTES + TR_SIDE_FLOATS * 4;
+    static constexpr int SW = N == 9 ? 5 : 4;      // depthwise strip width in pixels (N = 9: 2 strips of 5 = 144 items <= 192 threads)
+    static constexpr int SPR = (N + SW - 1) / SW;  // strips per board row
     static constexpr int DW_ITEMS = N * SPR * 8;   // (row, strip, 4-channel group)
     static constexpr int THREADS = TILES * 64;
     static constexpr int DW_ITER = (DW_ITEMS + THREADS - 1) / THREADS;
+    static constexpr int WG_THREADS = SPW * THREADS;
 };
 
 template <int N, bool FROM_F32, int ABL = 0> // ABL: timing-only ablations (1 = no depthwise exchange, 2 = no operand epilogue, 4 = no conv_in, 8 = epilogue without the global stores)
-__global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_t* __restrict__ req_ref, const uint32_t* __restrict__ req_aux,
+__global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_t* __restrict__ req_ref, const uint32_t* __restrict__ req_aux,
                                                                     const uint64_t* __restrict__ board, const NodeHdr* __restrict__ hdr,
                                                                     const int32_t* __restrict__ d_count, int cap_nodes, const float* __restrict__ in_f32,
                                                                     const uint4* __restrict__ wt, const float* __restrict__ side,
@@ -232,15 +237,17 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
     constexpr int HW = TG::HW, NW = Geo<N>::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const half8* ldsW = (const half8*)smem;
-    float* grid = (float*)(smem + TR_WBYTES);
-    const float* lside = (const float*)(smem + TR_WBYTES + TG::GRID_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, tile = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int slot = (tid >> 6) / TG::TILES, tile = (tid >> 6) % TG::TILES; // sample slot of the workgroup, pixel tile
+    const int stid = tid - slot * TG::THREADS;                              // thread index inside the sample
+    float* grid = (float*)(smem + TR_WBYTES) + slot * (TG::GRID_BYTES / 4);
+    const float* lside = (const float*)(smem + TR_WBYTES + TG::SPW * TG::GRID_BYTES);
     const int h = lane >> 5;
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); // fp8 / f16 conversions saturate (MODE.FP16_OVFL)
     // ---- one-time: weights, side table, zero halo grid ----
     for (int i = tid; i < TR_WBYTES / 16; i += blockDim.x) ((uint4*)smem)[i] = wt[i];
     for (int i = tid; i < TR_SIDE_FLOATS; i += blockDim.x) ((float*)lside)[i] = side[i];
-    for (int i = tid; i < TG::GRID_ROWS * GRID_STRIDE; i += blockDim.x) grid[i] = 0.0f;
+    for (int i = tid; i < TG::SPW * (TG::GRID_BYTES / 4); i += blockDim.x) ((float*)(smem + TR_WBYTES))[i] = 0.0f;
     __syncthreads();
     int count = d_count[0];
     if (count > max_count) count = max_count;
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
     // {4-11,16-19,28-31} per half): each group then holds two strips 8 pixels apart = 16 distinct 16-B slots of the
     // 256-B bank row (halo-grid row stride 36 floats); lane order gave a 2-way conflict on every window read
     const int l31 = lane & 31;
-    const int dw_tid = (tid & ~31) | (l31 < 4 ? l31 : l31 < 12 ? l31 + 4 : l31 < 16 ? l31 - 8 : l31 < 20 ? l31 + 8 : l31 < 28 ? l31 - 4 : l31);
+    const int dw_tid = (stid & ~31) | (l31 < 4 ? l31 : l31 < 12 ? l31 + 4 : l31 < 16 ? l31 - 8 : l31 < 20 ? l31 + 8 : l31 < 28 ? l31 - 4 : l31);
     const int pxl = lane & 31;
     const int px = tile * 32 + pxl;
     const bool valid = px < HW;
@@ -301,13 +308,16 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
         cwl[m] = convW[(4 + m) * 64 + lane];
     }
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    const int b_first = blockIdx.x;
+    const int b_first = (int)blockIdx.x * TG::SPW + slot;
+    const int b_stride = (int)gridDim.x * TG::SPW;
     uint32_t ref_n = 0, aux_n = 0xFFFFFFFFu;
     if (!FROM_F32 && b_first < count) { ref_n = req_ref[b_first]; aux_n = req_aux[b_first]; }
     SampleIn in = load_in(b_first < count ? b_first : 0, ref_n, aux_n);
 
-    for (int b = blockIdx.x; b < count; b += gridDim.x) {
-        const int b_next = b + (int)gridDim.x;
+    for (int b0 = (int)blockIdx.x * TG::SPW; b0 < count; b0 += b_stride) { // uniform trip count over the workgroup (barriers inside)
+        const int b = b0 + slot;
+        const bool active = b < count; // a slot without a sample in the last pass runs along (for the barriers) and stores nothing
+        const int b_next = b + b_stride;
         const bool has_next = b_next < count;
         if (!FROM_F32 && has_next) { ref_n = req_ref[b_next]; aux_n = req_aux[b_next]; } // used at the end of this sample
         // ---- the pixel's three input floats in the flat encoder.rs layout ----
@@ -423,24 +433,24 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
             lds_barrier(); // B2: h of the whole sample is in the halo grid
             // depthwise 3x3 SAME (zero halo), no bias.  Work item = (board row, 4-pixel strip, 4-channel
             // group): one 3x6 window of b128 loads serves 4 output pixels; taps in (dy,dx) order.
-            f32x4 dout[TG::DW_ITER][4];
+            f32x4 dout[TG::DW_ITER][TG::SW];
 #pragma unroll
             for (int it = 0; it < TG::DW_ITER; ++it) {
                 const int item = dw_tid + it * TG::THREADS;
                 const int itc = item < TG::DW_ITEMS ? item : 0;
                 const int cg = itc & 7, strip = itc >> 3;
-                const int y = strip / TG::SPR, x0 = (strip % TG::SPR) * 4;
+                const int y = strip / TG::SPR, x0 = (strip % TG::SPR) * TG::SW;
                 const float* gp = grid + (y * (N + 2) + x0) * GRID_STRIDE + 4 * cg;
-                f32x4 win[3][6];
+                f32x4 win[3][TG::SW + 2];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 6; ++dx) win[dy][dx] = *(const f32x4*)(gp + (dy * (N + 2) + dx) * GRID_STRIDE);
+                    for (int dx = 0; dx < TG::SW + 2; ++dx) win[dy][dx] = *(const f32x4*)(gp + (dy * (N + 2) + dx) * GRID_STRIDE);
                 f32x4 w9[9];
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) w9[tap] = *(const f32x4*)(dwt + tap * NM + 4 * cg);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
+                for (int p = 0; p < TG::SW; ++p) {
                     f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                     for (int tap = 0; tap < 9; ++tap) {
@@ -457,9 +467,9 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
                 const int item = dw_tid + it * TG::THREADS;
                 if (item < TG::DW_ITEMS) {
                     const int cg = item & 7, strip = item >> 3;
-                    const int y = strip / TG::SPR, x0 = (strip % TG::SPR) * 4;
+                    const int y = strip / TG::SPR, x0 = (strip % TG::SPR) * TG::SW;
 #pragma unroll
-                    for (int p = 0; p < 4; ++p)
+                    for (int p = 0; p < TG::SW; ++p)
                         if (x0 + p < N) *(f32x4*)(grid + ((y + 1) * (N + 2) + x0 + p + 1) * GRID_STRIDE + 4 * cg) = dout[it][p];
                 }
             }
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
                 LRELU16(x[m]);
             }
         }
-        in = load_in(has_next ? b_next : b, ref_n, aux_n); // next sample's inputs first (see load_in)
+        in = load_in(has_next ? b_next : (active ? b : 0), ref_n, aux_n); // next sample's inputs first (see load_in)
         // ---- fc0 operand row (k_fc0_mx): per (tile, channel half q) one 6-KiB block: f16 hi pieces [pxl 32][piece
         //      (2j+h) 8][16 B] with j = 2*(m&1)+s, then fp8 residual (x - hi)*2^(SA+11) pieces [pxl 32][piece (2h+e) 4][16 B]
         //      (the fp8 copy of hi is derived inside k_fc0_mx).  One K=64 super-step of fc0 = one pixel of one block. ----
@@ -556,7 +566,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const uint4 v = *(const uint4*)(grid + st_gi[i] * GRID_STRIDE + 4 * (lane & 7));
-                    if (!(ABL & 8)) { if (st_ok[i]) nt_store(v, &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + (8 * i + (lane >> 3)) * 8 + (lane & 7)]); }
+                    if (!(ABL & 8)) { if (st_ok[i] && active) nt_store(v, &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + (8 * i + (lane >> 3)) * 8 + (lane & 7)]); }
                     else if (v.x == 0x12345678u && v.y == 0x9abcdef0u) row[lane] = v; // timing only: keep the staging alive
                 }
             }
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::TILES * 64) void k_trunk(const uint32_
             for (int i = 0; i < 4; ++i) {
                 const uint4 v = *(const uint4*)(grid + st_gi[i] * GRID_STRIDE + 4 * (lane & 7));
                 const int q = (lane >> 2) & 1;
-                if (!(ABL & 8)) { if (st_ok[i]) nt_store(v, &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (8 * i + (lane >> 3)) * 4 + (lane & 3)]); }
+                if (!(ABL & 8)) { if (st_ok[i] && active) nt_store(v, &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (8 * i + (lane >> 3)) * 4 + (lane & 3)]); }
                 else if (v.x == 0x12345678u && v.y == 0x9abcdef0u) row[lane] = v;
             }
         }
@@ -1332,8 +1342,9 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TG::LDS_BYTES);
         attr_done = true;
     }
-    const int grid = max_count < 256 ? max_count : 256;
-    kern<<<grid, TG::TILES * 64, TG::LDS_BYTES, st>>>(S.req_ref, S.req_aux, S.board, S.hdr, S.d_count, S.cap_nodes, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4, max_count);
+    const int wgs = (max_count + TG::SPW - 1) / TG::SPW;
+    const int grid = wgs < 256 ? wgs : 256;
+    kern<<<grid, TG::WG_THREADS, TG::LDS_BYTES, st>>>(S.req_ref, S.req_aux, S.board, S.hdr, S.d_count, S.cap_nodes, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4, max_count);
 }
 
 template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
