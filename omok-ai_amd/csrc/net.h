@@ -33,6 +33,7 @@ struct Net {
     void* a_fc0 = nullptr;    // [max_b][KSTEPS][hi 16 | lo 16] f16 : trunk output = fc0 A operand
     void* h0 = nullptr;       // [max_b][512] hi|lo f16 : fc0 output = fc1 A operand
     size_t row_u4 = 0;        // a_fc0 row stride in uint4
+    size_t part_rows = 0;     // capacity of the split-K partial slab `part` in rows (x 512 floats)
     float* part = nullptr;    // split-K fp32 partials of fc0 for small batches
     int mx_sw = 0;            // fc0 weights: fp8 copies are w * 2^mx_sw (hi) and (w - f16(w)) * 2^(mx_sw + 11) (lo)
     size_t bytes = 0;         // device bytes held

@@ -1202,7 +1202,8 @@ size_t net_alloc(Net& net) {
         ok = ok && A(&net.a_fc0, mb * row_u4 * 16 + 2 * OP_BLK_U4 * 16); // + slack: the prefetch of the super-step past the last one reads one block beyond the row
         ok = ok && A(&net.h0, mb * 32 * 64 * 2);       // h0 and h1 rows (2 KiB each)
         ok = ok && A((void**)&net.s0, sizeof(float) * mb * heads_mt(net.hw) * 32); // logits
-        ok = ok && A((void**)&net.part, sizeof(float) * (size_t)2 * 16384 * NF);       // split-K partials (<= 64 MiB)
+        net.part_rows = mb * 3 > 32768 ? mb * 3 : 32768;                                // split-K partials: rows x split ways (2 KiB each)
+        ok = ok && A((void**)&net.part, sizeof(float) * net.part_rows * NF);
     }
     if (!ok) { net_free(net); return 0; }
     net.bytes = bytes;
@@ -1390,11 +1391,26 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     {
         const int nsup = hw * 2;
         const int tiles128 = (max_count + GT_BS - 1) / GT_BS;
+        // Split K over blockIdx.y so that the workgroups fill whole waves of CUs (one workgroup per CU at a time: 144 KiB of
+        // LDS): with T tiles of 128 samples and d-way split-K the launch takes ceil(T*d / CUs) / d units of time.  T = 300
+        // (59 % of the games alive at 4096 x K = 16) costs 2 units unsplit and 1.2 with d = 5; late plies (T << CUs) get
+        // their parallelism from d alone.  d must divide the super-step count and its fp32 partials must fit the slab.
         int nsplit = 1;
-        if (max_count <= 16384) { // largest divisor of nsup that keeps <= ~256 workgroups and fits the partial slab
-            const int want = 256 / (tiles128 > 0 ? tiles128 : 1);
-            for (int d = 2; d <= 16 && d <= want; ++d)
-                if (nsup % d == 0 && (size_t)d * (size_t)(tiles128 * GT_BS) <= (size_t)2 * 16384) nsplit = d;
+        {
+            static int n_cu = 0;
+            if (!n_cu) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            }
+            double best = 1e30;
+            for (int d = 1; d <= 16; ++d) {
+                if (nsup % d) continue;
+                if (d > 1 && (size_t)d * (size_t)(tiles128 * GT_BS) > net.part_rows) continue;
+                const double waves = (double)(((size_t)tiles128 * d + n_cu - 1) / n_cu);
+                const double cost = waves / d * (d > 1 ? 1.04 : 1.0); // (partials round trip + shorter K loops)
+                if (cost < best - 1e-9) { best = cost; nsplit = d; }
+            }
         }
         const MxScales sc{127 - net.mx_sw, 127 - (net.mx_sw + 11), 127 - MX_SA, 127 - (MX_SA + 11), ldexpf(1.0f, net.mx_sw), ldexpf(1.0f, MX_SA)};
         constexpr int LDS = 0; // static LDS objects: (2 + MXS_SLOTS) x 24 KiB

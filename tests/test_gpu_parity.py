@@ -142,23 +142,25 @@ def test_net_ragged_batches_are_row_independent():
     eng.close()
 
 
-def test_net_full_batch_kernel_path():
-    """Engines above 16384 rows run fc0 without split-K (k_fc0_mx<EPI_SPLIT>, the bench configuration): same results
-    as the split-K path of a small engine (different fp32 summation order in front of saturated softmaxes: 2e-4 allowed,
-    4e-5 seen), and within TOL of the oracle."""
+@pytest.mark.parametrize("games,rows", [(2048, 32768), (1100, 17600)])
+def test_net_large_batch_kernel_paths(games, rows):
+    """fc0 picks its split-K factor from the launch size: 32768 rows = 256 tiles run unsplit (k_fc0_mx<EPI_SPLIT>, the path
+    of full self-play rounds), 17600 rows = 137.5 tiles run 3-way split with a half-full last tile.  Same results as the
+    15-way split of a small engine (different fp32 summation order in front of saturated softmaxes: 2e-4 allowed, 4e-5
+    seen), and within TOL of the oracle."""
     n = 15
     small = oa.Engine(board_size=n, games=32, max_nodes=16, max_tables=8, max_batch_k=16)
-    big = oa.Engine(board_size=n, games=1100, max_nodes=8, max_tables=4, max_batch_k=16)  # 17600 rows = 137.5 tiles
+    big = oa.Engine(board_size=n, games=games, max_nodes=8, max_tables=4, max_batch_k=16)
     tensors = oa.weights.init_random(n, seed=0)
     small.load_weights(tensors)
     big.load_weights(tensors)
     base = _random_positions(n, 400, 5)
-    x = np.tile(base, (44, 1))[:17600]  # full capacity in one launch, last tile half full
+    x = np.tile(base, (rows // 400 + 1, 1))[:rows]  # full capacity in one launch
     pb, vb = big.evaluate_pv(x)
     ps, vs = small.evaluate_pv(base)
     pb, ps = pb.reshape(len(x), -1), ps.reshape(len(base), -1)
     vb, vs = vb.reshape(-1), vs.reshape(-1)
-    for r in (0, 1, 43):  # every copy of the base positions gives the same rows
+    for r in (1, rows // 400 - 1):  # every copy of the base positions gives the same rows
         assert np.array_equal(pb[r * 400:(r + 1) * 400].view(np.uint32), pb[:400].view(np.uint32))
     assert np.abs(pb[:400] - ps).max() < 2e-4 and np.abs(vb[:400] - vs).max() < 2e-4
     pc, vc = O.Net(n, tensors).forward(base[:96], threads=8)
