@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libomok_mi355x.so")
+# OMOK_MI355X_LIB: another build of the same library (A/B timing of kernel variants inside one GPU session)
+LIB_PATH = os.environ.get("OMOK_MI355X_LIB") or os.path.join(_HERE, "libomok_mi355x.so")
 
 OK = 0
 NET_F16X3, NET_F32 = 0, 1

@@ -35,6 +35,7 @@ struct Net {
     size_t row_u4 = 0;        // a_fc0 row stride in uint4
     size_t part_rows = 0;     // capacity of the split-K partial slab `part` in rows (x 512 floats)
     float* part = nullptr;    // split-K fp32 partials of fc0 for small batches
+    int32_t* d_chunk = nullptr; // [64][4] live row count of every row chunk of a forward (see forward_chunked)
     int mx_sw = 0;            // fc0 weights: fp8 copies are w * 2^mx_sw (hi) and (w - f16(w)) * 2^(mx_sw + 11) (lo)
     size_t bytes = 0;         // device bytes held
 };

@@ -227,6 +227,9 @@ struct TrunkGeo {
     static constexpr int WG_THREADS = SPW * THREADS;
 };
 
+#ifndef TRUNK_PRIO
+#define TRUNK_PRIO 0
+#endif
 template <int N, bool FROM_F32, int ABL = 0> // ABL: timing-only ablations (1 = no depthwise exchange, 2 = no operand epilogue, 4 = no conv_in, 8 = epilogue without the global stores)
 __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_t* __restrict__ req_ref, const uint32_t* __restrict__ req_aux,
                                                                     const uint64_t* __restrict__ board, const NodeHdr* __restrict__ hdr,
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
     const float* lside = (const float*)(smem + TR_WBYTES + TG::SPW * TG::GRID_BYTES);
     const int h = lane >> 5;
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); // fp8 / f16 conversions saturate (MODE.FP16_OVFL)
+    if (TRUNK_PRIO && ((tid >> 6) & 4)) __builtin_amdgcn_s_setprio(TRUNK_PRIO); // the two waves of a SIMD (w, w+4) run the same phases: let one lead
     // ---- one-time: weights, side table, zero halo grid ----
     for (int i = tid; i < TR_WBYTES / 16; i += blockDim.x) ((uint4*)smem)[i] = wt[i];
     for (int i = tid; i < TR_SIDE_FLOATS; i += blockDim.x) ((float*)lside)[i] = side[i];
@@ -653,6 +657,7 @@ __device__ inline void f16x8_to_fp8(const half8& v, float inv_mul, uint32_t& d0,
 // super-step are read from LDS once and stay in registers for its 4 stages; a weight fragment is read from LDS by
 // exactly one wave.  LDS traffic per stage drops from 144 KiB (8-wave form) to ~48 KiB and the matrix pipe is fed
 // by one wave with 4 independent accumulator chains.
+constexpr int NET_CHUNK_DEFAULT = 0; // rows per forward launch (0 = unchunked); OMOK_NET_CHUNK overrides
 constexpr bool A_NT = true;     // the sample-operand stream is read once: non-temporal, so it does not displace the weight stream in L2
 constexpr bool STAGGER = false; // (skewing the waves by s_nops after the barrier: 3.52 -> 3.88 ms, the delay costs more than it saves)
 template <int EPI, int DBG = 0> // DBG: timing-only ablations (1 = no weight DMA, 2 = no sample DMA, 4 = no fp8 derivation, 8 = no vmcnt waits)
@@ -1178,6 +1183,7 @@ size_t net_alloc(Net& net) {
     };
     bool ok = true;
     for (int i = 0; i < NET_TENSORS && ok; ++i) ok = A((void**)&net.w[i], sizeof(float) * (size_t)net.wsize[i]);
+    ok = ok && A((void**)&net.d_chunk, sizeof(int32_t) * 64 * 4);
     ok = ok && A((void**)&net.p, sizeof(float) * mb * rp);
     ok = ok && A((void**)&net.v, sizeof(float) * mb);
     ok = ok && A((void**)&net.in_f32, sizeof(float) * mb * 3 * hw);
@@ -1441,6 +1447,47 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     if (prof) prof->end(st);
 }
 
+// Optional (OMOK_NET_CHUNK, default off): a forward over more rows than the chunk size runs as consecutive launches over
+// row chunks (same kernels, offset request / output pointers, chunk-local scratch rows).  Isolated launches of 16-32 K
+// rows take 10 % less time per row than one launch of 64 K rows (tools/bench_net.py: trunk 4.24 vs 4.71 ms, fc0 3.15 vs
+// 3.54 ms per 65536 rows), but that is the idle gap between timed launches, not the size: back to back inside a
+// self-play episode the chunked rounds are 2-4 % SLOWER (first 8 plies of C2: 3.06 / 2.94 s unchunked, 3.13 / 3.11 s
+// at 16384, 3.10 s at 32768), so it stays off.
+__global__ void k_chunk_counts(const int32_t* __restrict__ d_count, int max_count, int chunk, int n_chunks, int32_t* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (i >= n_chunks) return;
+    int c = d_count[0];
+    if (c > max_count) c = max_count;
+    const int v = c - i * chunk;
+    out[i * 4] = v < 0 ? 0 : (v > chunk ? chunk : v);
+}
+
+static void forward_chunked(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof) {
+    static const int chunk_max = getenv("OMOK_NET_CHUNK") ? atoi(getenv("OMOK_NET_CHUNK")) : NET_CHUNK_DEFAULT;
+    if (chunk_max <= 0 || max_count <= chunk_max) {
+        forward_f16x3(net, S, max_count, from_f32, st, prof);
+        return;
+    }
+    int n_chunks = (max_count + chunk_max - 1) / chunk_max;
+    if (n_chunks > 64) n_chunks = 64;
+    const int chunk = ((max_count + n_chunks - 1) / n_chunks + GT_BS - 1) / GT_BS * GT_BS; // balanced, whole tiles
+    k_chunk_counts<<<1, 64, 0, st>>>(S.d_count, max_count, chunk, n_chunks, net.d_chunk);
+    for (int c = 0; c < n_chunks; ++c) {
+        const int base = c * chunk;
+        const int mc = max_count - base < chunk ? max_count - base : chunk;
+        if (mc <= 0) break;
+        Net v = net; // a view: same scratch buffers, outputs of this chunk's rows
+        Store S2 = S;
+        S2.req_ref += base;
+        S2.req_aux += base;
+        S2.d_count = net.d_chunk + 4 * c;
+        v.p += (size_t)base * net.rowp;
+        v.v += base;
+        v.in_f32 += (size_t)base * 3 * net.hw;
+        forward_f16x3(v, S2, mc, from_f32, st, prof);
+    }
+}
+
 void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, Prof* prof) {
     if (max_count <= 0) return;
     if (max_count > net.max_b) max_count = net.max_b;
@@ -1448,14 +1495,14 @@ void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t s
         launch_encode_requests(net.n, S, net.in_f32, max_count, st);
         forward_f32(net, S, max_count, st, prof);
     } else {
-        forward_f16x3(net, S, max_count, false, st, prof);
+        forward_chunked(net, S, max_count, false, st, prof);
     }
 }
 
 void net_forward_inputs(Net& net, const Store& S, int count, hipStream_t st, Prof* prof) {
     if (count <= 0) return;
     if (net.mode == OMOK_NET_F32) forward_f32(net, S, count, st, prof);
-    else forward_f16x3(net, S, count, true, st, prof);
+    else forward_chunked(net, S, count, true, st, prof);
 }
 
 } // namespace omok
