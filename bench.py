@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--net-mode", default="f16x3", choices=["f16x3", "f32"])
     ap.add_argument("--gather", action="store_true", help="RCCL all-gather of replay tuples at episode end")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=20, help="training steps timed after the episode (0 = skip; batch 128)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -203,7 +204,8 @@ def main():
         "game_length_percentiles": {str(q): float(np.percentile(plies, q)) for q in (0, 10, 25, 50, 75, 90, 99, 100)},
         "arena": {"max_nodes": max_nodes, "max_tables": max_tables, "peak_nodes": st["peak_nodes"], "peak_tables": st["peak_tables"]},
     }
-    if complete:  # outside the timed region: the episode-end replay post-processing row on the device
+    if complete and world == 1:  # outside the timed region (single-GPU runs only: the other ranks have left by now): the
+        # episode-end replay post-processing row on the device
         rec = sp.replay_record_bytes()
         n_rec = 6 * int(plies.sum())
         buf = torch.empty(max(n_rec, 1) * rec, dtype=torch.uint8, device=f"cuda:{local_rank}")
@@ -217,6 +219,18 @@ def main():
         out["replay_postprocess"] = {"records": got, "ms": 1e3 * dt_pp, "bound": "hbm", "achieved": alg / dt_pp / 1e9, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": alg / dt_pp / 1e9 / HBM_PEAK_GBS,
                                      "note": "z back-fill + 5 augmentations per transition (trainer.rs:207-324), rank 0, host-timed call"}
+        if args.train_steps > 0:  # also outside the timed region: the training phase on the same records
+            from omok_ai_amd import train as T
+            ph = T.TrainPhase(n, oa.weights.init_random(n, seed=0), f"cuda:{local_rank}")
+            ph.run(buf, update_count=2, batch_size=128, seed=0)  # warm-up (MIOpen / rocBLAS plans)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            v_l, p_l, l_ = ph.run(buf, update_count=args.train_steps, batch_size=128, seed=1)
+            torch.cuda.synchronize()
+            dt_tr = time.perf_counter() - t2
+            out["train_phase"] = {"steps": args.train_steps, "batch": 128, "steps_per_s": args.train_steps / dt_tr, "loss": l_,
+                                  "note": "AgentModel::train (Adadelta lr 0.01) via torch autograd on the augmented replay records, rank 0"
+                                          " (multi-GPU: gradients averaged by one RCCL all-reduce per step, tests/test_sharding_gloo.py)"}
         del buf
     if args.cpu_seconds > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, max(mean_plies, 1.0))

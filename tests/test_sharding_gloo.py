@@ -77,3 +77,57 @@ def test_two_rank_sharding_matches_single_process(tmp_path):
     assert got["secs"] == 2.0 and got["games"] == 2 * GAMES_PER_RANK  # max of times, sum of counters
     assert got["plies"] == len(single) == got["sizes"].sum()
     assert np.array_equal(got["all"], single)  # rank-major gather == global game order, bit for bit
+
+
+# ---- data-parallel training step: gradients averaged over ranks (omok-ai_amd/train.py) ------------------------------
+def _train_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import omok_ai_amd as oa
+    from omok_ai_amd import train as T
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tensors = [np.asarray(t, np.float64) * 0.25 for t in oa.weights.init_random(N, seed=2)]
+    x, pi, z = _train_batch(8)
+    ph = T.TrainPhase(N, tensors, "cpu", dtype=torch.float64, allow_cpu=True)
+    sl = slice(4 * rank, 4 * rank + 4)  # each rank trains on its half of the batch
+    for _ in range(2):
+        ph.step(torch.as_tensor(x[sl]), torch.as_tensor(pi[sl]), torch.as_tensor(z[sl]))
+    if rank == 0:
+        np.savez(out, *[p.detach().numpy() for p in ph.net.vars])
+    flat = torch.cat([p.detach().reshape(-1) for p in ph.net.vars])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])  # replicas stay bit-identical
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _train_batch(b):
+    rng = np.random.default_rng(7)
+    hw = N * N
+    x = (rng.random((b, N, N, 3)) < 0.3).astype(np.float64)
+    pi = rng.random((b, hw))
+    pi /= pi.sum(axis=1, keepdims=True)
+    z = rng.choice([-1.0, 0.0, 1.0], size=(b, 1))
+    return x, pi, z
+
+
+def test_two_rank_training_step_equals_single_process_on_the_union(tmp_path):
+    """mean over ranks of the per-rank mean-loss gradients == gradient of the mean loss over the union (equal shares)."""
+    sys.path.insert(0, ROOT)
+    import omok_ai_amd as oa
+    from omok_ai_amd import train as T
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "trained.npz")
+    mp.spawn(_train_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    tensors = [np.asarray(t, np.float64) * 0.25 for t in oa.weights.init_random(N, seed=2)]
+    x, pi, z = _train_batch(8)
+    ph = T.TrainPhase(N, tensors, "cpu", dtype=torch.float64, allow_cpu=True)
+    for _ in range(2):
+        ph.step(torch.as_tensor(x), torch.as_tensor(pi), torch.as_tensor(z))
+    for i, p in enumerate(ph.net.vars):
+        assert np.abs(got[f"arr_{i}"] - p.detach().numpy()).max() < 1e-12, i
