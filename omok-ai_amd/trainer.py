@@ -1,0 +1,93 @@
+"""One-GPU (or one-process-per-GPU) mirror of Trainer::train (src/trainer.rs:69-386) over the HIP engine.
+
+Per iteration, like the reference: clear the replay memory (:77-78), play `episode_count` self-play games (:81-205, on
+the engine), back-fill z and augment (:207-324, on the device), cap the memory at `replay_memory_size` (:326-328), run
+`parameter_update_count` training steps on `parameter_update_batch_size` transitions (:329-357), save the model
+(`saves/<model_name>`, :375, ModelIO format).  Plots and the periodic games against the naive player (:371-400) are not
+part of this mirror.  Parameters and defaults: src/config.rs:83-110 (episode_count 50, evaluate_count 600, ...).
+Multi-GPU: every rank plays its own `episode_count` games (global ids rank*episode_count + g) and trains data-parallel
+(gradients averaged per step), so all ranks hold identical weights after every iteration.
+"""
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import api, dist, weights
+from . import train as T
+
+
+@dataclass
+class Parameters:  # src/config.rs:83-110
+    model_name: str = "alpha-zero"
+    replay_memory_size: int = 600_000
+    episode_count: int = 50
+    evaluate_count: int = 600
+    evaluate_batch_size: int = 16
+    epsilon: float = 0.25
+    alpha: float = 0.03
+    temperature: float = 1.0
+    temperature_threshold: int = 30
+    parameter_update_count: int = 600
+    parameter_update_batch_size: int = 128
+
+
+class Trainer:
+    def __init__(self, params=None, board_size=15, seed=0, save_dir="saves", max_nodes=None, max_tables=None):
+        self.p = params or Parameters()
+        self.n = board_size
+        self.rank, self.local_rank, self.world = dist.shard_info()
+        self.device = f"cuda:{self.local_rank}"
+        self.save_dir = save_dir
+        sims = -(-self.p.evaluate_count // self.p.evaluate_batch_size) * self.p.evaluate_batch_size
+        max_nodes = max_nodes or min(16384, 4 * sims + 1024)
+        self.engine = api.Engine(board_size=board_size, games=self.p.episode_count, max_nodes=max_nodes,
+                                 max_tables=max_tables or max(256, max_nodes // 4), max_batch_k=self.p.evaluate_batch_size,
+                                 device=self.local_rank, seed=seed, game_offset=dist.game_offset(self.rank, self.p.episode_count))
+        path = os.path.join(save_dir, self.p.model_name)
+        if os.path.exists(path):  # Trainer::new -> this.load(model_name) (:63-65, :628-636)
+            self.engine.load(path)
+            tensors = self._engine_tensors()
+        else:
+            tensors = weights.init_random(board_size, seed=seed)
+            self.engine.load_weights(tensors)
+        self.phase = T.TrainPhase(board_size, tensors, self.device)  # the optimizer state lives across iterations like the session's
+        self.selfplay = api.SelfPlay(self.engine)
+        self.iteration = 0
+
+    def _engine_tensors(self):
+        tmp = os.path.join(self.save_dir, f".{self.p.model_name}.rank{self.rank}.tmp")
+        self.engine.save(tmp)
+        from . import model_file
+        tensors = model_file.load(tmp)[1]
+        os.remove(tmp)
+        return tensors
+
+    def train(self, iteration_count, log=print):
+        p = self.p
+        rec = self.selfplay.replay_record_bytes()
+        for _ in range(iteration_count):
+            self.iteration += 1
+            self.selfplay.reset()  # fresh agents; the engine's replay buffer is cleared with them (:77-93)
+            stats = self.selfplay.run(p.evaluate_count, p.evaluate_batch_size, p.epsilon, p.alpha, p.temperature,
+                                      p.temperature_threshold, 0)
+            _, _, plies = self.selfplay.game_info()
+            total = 6 * int(plies.sum())
+            buf = torch.empty(max(total, 1) * rec, dtype=torch.uint8, device=self.device)
+            got = self.selfplay.replay_augment_into(buf.data_ptr(), total)
+            records = buf[: got * rec].reshape(got, rec)
+            if got > p.replay_memory_size:  # pop_front until the memory fits (:326-328)
+                records = records[got - p.replay_memory_size:]
+            v_loss, p_loss, loss = self.phase.run(records, p.parameter_update_count, p.parameter_update_batch_size,
+                                                  seed=self.iteration * 7919 + self.rank)
+            self.phase.push_to(self.engine)
+            if self.rank == 0:  # Trainer::save (:605-626)
+                os.makedirs(self.save_dir, exist_ok=True)
+                self.engine.save(os.path.join(self.save_dir, p.model_name))
+            log(f"[iter={self.iteration}] games={int(stats['finished'])} transitions={got} loss={loss:.4f} "
+                f"[v_loss={v_loss:.4f}, p_loss={p_loss:.4f}]")
+        return v_loss, p_loss, loss
+
+    def close(self):
+        self.engine.close()

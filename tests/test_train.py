@@ -160,3 +160,30 @@ def test_gpu_training_phase_end_to_end():
         pt, vt = gpu.net(x[:16])
     assert np.abs(pe.reshape(16, -1) - pt.cpu().numpy()).max() < 1e-3 and np.abs(ve.ravel() - vt.cpu().numpy().ravel()).max() < 1e-3
     eng.close()
+
+
+@pytest.mark.gpu
+def test_trainer_iterations_save_and_resume(tmp_path):
+    """Trainer::train mirror (src/trainer.rs:69-386): self-play -> post-process -> train -> save, and a new Trainer resumes
+    from the saved ModelIO file."""
+    from omok_ai_amd import trainer as TR
+    from oracle import model_io as M
+    p = TR.Parameters(model_name="tiny", episode_count=8, evaluate_count=16, evaluate_batch_size=8,
+                      parameter_update_count=5, parameter_update_batch_size=32, replay_memory_size=500)
+    save_dir = str(tmp_path / "saves")
+    tr = TR.Trainer(p, board_size=9, seed=3, save_dir=save_dir)
+    w0 = tr.phase.net.tensors()
+    logs = []
+    v_loss, p_loss, loss = tr.train(2, log=logs.append)
+    assert len(logs) == 2 and np.isfinite(loss) and abs(loss - (v_loss + p_loss)) < 1e-4 * max(1.0, abs(loss))
+    w2 = tr.phase.net.tensors()
+    assert any(not np.array_equal(a, b) for a, b in zip(w0, w2))          # the variables moved
+    names, params = M.model_load(os.path.join(save_dir, "tiny"))          # Trainer::save wrote the reference's format
+    assert len(params) == 31
+    for a, b in zip(w2, params):
+        assert np.array_equal(np.asarray(a, np.float32).ravel().view(np.uint32), b.view(np.uint32))
+    tr.close()
+    tr2 = TR.Trainer(p, board_size=9, seed=99, save_dir=save_dir)           # Trainer::new -> load(model_name)
+    for a, b in zip(tr2.phase.net.tensors(), w2):
+        assert np.array_equal(np.asarray(a, np.float32).view(np.uint32), np.asarray(b, np.float32).view(np.uint32))
+    tr2.close()
