@@ -192,6 +192,9 @@ def main():
                      "traffic_unit": "HBM bytes per launch (rows per launch x per-row bytes of the committed PMC pass: "
                                      "profiles/README.md; FETCH_SIZE x2 + WRITE_SIZE)",
                      "algorithmic_bytes_per_launch": (128 * hw * 3 + 2048) * st["fc0_rows"] / max(st["fc0_launches"], 1.0) + 128 * hw * 512 * 3,
+                     "mfma_mix_bound": {"value": 832.0, "unit": "TFLOP/s", "frac_of_bound": fc0_tflops / 832.0,
+                                        "note": "the kernel's MFMA mix alone (operands in registers, random data, one wave per SIMD, every CU): "
+                                                "tools/probe/shape_probe mode 0 = 2497 TFLOP/s over the three product terms = 832 algorithmic"},
                      "note": "algorithmic flops (2*128*HW*512 per eval); per K=64 the kernel issues 4 f16 + 2 block-scaled fp8 "
                              "MFMAs (split operands) = 1.41x the pipe time of a plain-f16 product, so frac <= 0.71 by construction"},
         "roofline_net": {"bound": "mfma", "achieved": evals * flop_eval / net_s / 1e12 if net_s > 0 else 0.0,

@@ -1,0 +1,107 @@
+// shape_probe.hip — wall time per equal math of the fc0 MFMA mix on RANDOM operands, one wave per SIMD, 256 accumulator
+// registers per wave (a 128 x 128 tile), K = 64 per iteration:
+//   mode 0: 32x32 shapes: 16 tiles x (4 x v_mfma_f32_32x32x16_f16 + 2 x v_mfma_scale_f32_32x32x64_f8f6f4)
+//   mode 1: 16x16 shapes: 64 tiles x (2 x v_mfma_f32_16x16x32_f16) + per K = 128 (every second iteration) 64 tiles x
+//           2 x v_mfma_scale_f32_16x16x128_f8f6f4
+// (MI355X_MICROARCH.md 'DVFS give-back' item 7: the chip can hold a higher clock on the 16x16 shape.)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256) void probe(const uint4* src, float* out, int iters) {
+    // operands: 8 "A" and 8 "B" fragments of each kind, random bits (f16 values in a sane range; fp8 any)
+    h8 ha[4], hb[4];
+    v8i ia[4], ib[4];
+    const uint4* s = src + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ha[i] = __builtin_bit_cast(h8, s[(i) * 256]);
+        hb[i] = __builtin_bit_cast(h8, s[(8 + i) * 256]);
+        const uint4 p = s[(16 + i) * 256], q = s[(24 + i) * 256];
+        ia[i] = v8i{(int)p.x, (int)p.y, (int)p.z, (int)p.w, (int)q.x, (int)q.y, (int)q.z, (int)q.w};
+        ib[i] = v8i{(int)q.w, (int)q.z, (int)q.y, (int)q.x, (int)p.w, (int)p.z, (int)p.y, (int)p.x};
+    }
+    float sum = 0;
+    if (MODE == 0) {
+        v16f acc[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[(t >> 2) ^ (j & 1)], hb[(t & 3) ^ (j >> 1)], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ia[t >> 2], ib[t & 3], acc[t], 0, 0, 0, 116, 0, 125);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ib[(t >> 2) ^ 1], ia[(t & 3) ^ 2], acc[t], 0, 0, 0, 116, 0, 125);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[t][r];
+    } else {
+        v4f acc[64];
+#pragma unroll
+        for (int t = 0; t < 64; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = 0;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 64; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha[((t >> 3) ^ j) & 3], hb[(t & 3) ^ (t >> 5)], acc[t], 0, 0, 0);
+            if (it & 1) {
+#pragma unroll
+                for (int t = 0; t < 64; ++t) acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ia[(t >> 3) & 3], ib[t & 3], acc[t], 0, 0, 0, 116, 0, 125);
+#pragma unroll
+                for (int t = 0; t < 64; ++t) acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ib[(t >> 4) & 3], ia[(t ^ 1) & 3], acc[t], 0, 0, 0, 116, 0, 125);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 64; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum += acc[t][r];
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+int main() {
+    const size_t n = 32 * 256;
+    uint4* h = (uint4*)malloc(n * sizeof(uint4));
+    srand(1);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t w[4];
+        for (int k = 0; k < 4; ++k) {
+            if (i < 16 * 256) { // two f16 in [-2, 2): sign, exponent 10..15, random mantissa
+                uint32_t a = ((rand() & 1) << 15) | ((10 + rand() % 6) << 10) | (rand() & 1023);
+                uint32_t b = ((rand() & 1) << 15) | ((10 + rand() % 6) << 10) | (rand() & 1023);
+                w[k] = a | (b << 16);
+            } else { // four e4m3 values, no NaN (0x7f / 0xff)
+                w[k] = 0;
+                for (int q = 0; q < 4; ++q) { uint32_t v = rand() & 0xff; if ((v & 0x7f) == 0x7f) v ^= 1; w[k] |= v << (8 * q); }
+            }
+        }
+        h[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    uint4* d; float* o;
+    hipMalloc(&d, n * sizeof(uint4)); hipMalloc(&o, 256 * 256 * 4);
+    hipMemcpy(d, h, n * sizeof(uint4), hipMemcpyHostToDevice);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const int iters = 4000; // 4000 x K=64: ~9 fc0 passes worth of K per workgroup
+    for (int rep = 0; rep < 3; ++rep)
+        for (int mode = 0; mode < 2; ++mode) {
+            hipEventRecord(a);
+            if (mode == 0) probe<0><<<256, 256>>>(d, o, iters); else probe<1><<<256, 256>>>(d, o, iters);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            const double flop = 256.0 * 4 * iters * (128.0 * 128 * 64 * 2) * 3; // hi*hi + two correction terms, per wave tile
+            printf("mode %d (%s): %.3f ms  %.0f TFLOP/s (f16-term-equivalent x3)\n", mode, mode ? "16x16 shapes" : "32x32 shapes", ms, flop / ms / 1e9);
+        }
+    return 0;
+}
