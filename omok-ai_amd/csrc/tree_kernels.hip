@@ -213,6 +213,13 @@ struct Regs { // wave-uniform running state of a tree
     uint32_t n_nodes, n_tables, root_n, n_req, error;
     float root_w;
     unsigned long long bytes;
+    // select_leaf memo: between two backups nothing that the PUCT descent reads changes (an expansion only adds a child to
+    // the leaf, whose children are not scanned while it has untried actions), so the next simulation of the round reaches
+    // the same leaf.  memo_node = that leaf (-1 = none), memo_n = its n as stored in its parent's table, memo_bytes = the
+    // algorithmic bytes of the descent it stands for (the counter keeps the reference algorithm's meaning).
+    int memo_node = -1;
+    uint32_t memo_n = 0;
+    unsigned long long memo_bytes = 0;
 };
 
 // environment/src/lib.rs:104-166 on bitboards, wave-cooperative (all 64 lanes must call).
@@ -380,7 +387,13 @@ __device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, const RoundAr
     const int lane = LANE;
     int node = 0;
     uint32_t node_n = R.root_n;
-    NodeHdr h = T.hdr[0];
+    unsigned long long path_bytes = 0;
+    if (R.memo_node >= 0) { // resume at the remembered leaf (its header is re-read: the last expansion changed nch / table)
+        node = R.memo_node;
+        node_n = R.memo_n;
+        path_bytes = R.memo_bytes;
+    }
+    NodeHdr h = T.hdr[node];
     // ---- select_leaf (node.rs:43-58) with the PUCT selector (pme.rs:81-90) ----
     while (h.nch == h.legal && h.nch != 0) {
         const uint32_t pn = node_n > 1u ? node_n : 1u;
@@ -406,14 +419,19 @@ __device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, const RoundAr
         }
         best = wave_max_u64(best);
         const int a_best = (int)(best & 0xFFFFu);
-        R.bytes += 12ull * h.nch;
+        path_bytes += 12ull * h.nch;
         node_n = T.cn[tb + a_best];
         node = (int)T.cidx[tb + a_best];
         h = T.hdr[node];
     }
+    R.bytes += path_bytes;
+    R.memo_node = node;
+    R.memo_n = node_n;
+    R.memo_bytes = path_bytes;
     // ---- terminal leaf (pme.rs:92-97) ----
     if (h.status != ST_IN_PROGRESS) {
         backup<N>(T, R, node, h.status >= ST_BLACK_WIN ? 1.0f : 0.0f);
+        R.memo_node = -1; // n / w changed along the path
         __syncthreads();
         return;
     }
@@ -453,6 +471,7 @@ __device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, const RoundAr
     __syncthreads();
     if (status != ST_IN_PROGRESS) { // pme.rs:177-181
         backup<N>(T, R, child, status == ST_DRAW ? 0.0f : 1.0f);
+        R.memo_node = -1;
     } else {
         if (lane == 0) T.req[R.n_req] = (uint16_t)child;
         R.n_req += 1u;
