@@ -1219,7 +1219,7 @@ size_t net_alloc(Net& net) {
 void net_free(Net& net) {
     void** ptrs[] = {(void**)&net.p, (void**)&net.v, (void**)&net.in_f32, (void**)&net.sx, (void**)&net.sh, (void**)&net.sd,
                      (void**)&net.sg, (void**)&net.s0, (void**)&net.s1, &net.wt_trunk, (void**)&net.wt_first, &net.wt_fc0,
-                     &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part};
+                     &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part, (void**)&net.d_chunk};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     for (int i = 0; i < NET_TENSORS; ++i) { if (net.w[i]) hipFree(net.w[i]); net.w[i] = nullptr; }
 }
