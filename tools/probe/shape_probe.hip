@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void probe(const uint4* src, float* out, int i
         ib[i] = v8i{(int)q.w, (int)q.z, (int)q.y, (int)q.x, (int)p.w, (int)p.z, (int)p.y, (int)p.x};
     }
     float sum = 0;
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) { // MODE 2: the correction terms with fp6 (e2m3) operands instead of fp8
         v16f acc[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t)
@@ -38,9 +38,11 @@ __global__ __launch_bounds__(256) void probe(const uint4* src, float* out, int i
 #pragma unroll
                 for (int t = 0; t < 16; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[(t >> 2) ^ (j & 1)], hb[(t & 3) ^ (j >> 1)], acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ia[t >> 2], ib[t & 3], acc[t], 0, 0, 0, 116, 0, 125);
+            for (int t = 0; t < 16; ++t) acc[t] = MODE == 2 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ia[t >> 2], ib[t & 3], acc[t], 2, 2, 0, 116, 0, 125)
+                                                           : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ia[t >> 2], ib[t & 3], acc[t], 0, 0, 0, 116, 0, 125);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ib[(t >> 2) ^ 1], ia[(t & 3) ^ 2], acc[t], 0, 0, 0, 116, 0, 125);
+            for (int t = 0; t < 16; ++t) acc[t] = MODE == 2 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ib[(t >> 2) ^ 1], ia[(t & 3) ^ 2], acc[t], 2, 2, 0, 116, 0, 125)
+                                                           : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ib[(t >> 2) ^ 1], ia[(t & 3) ^ 2], acc[t], 0, 0, 0, 116, 0, 125);
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t)
@@ -95,13 +97,13 @@ int main() {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const int iters = 4000; // 4000 x K=64: ~9 fc0 passes worth of K per workgroup
     for (int rep = 0; rep < 3; ++rep)
-        for (int mode = 0; mode < 2; ++mode) {
+        for (int mode = 0; mode < 3; ++mode) {
             hipEventRecord(a);
-            if (mode == 0) probe<0><<<256, 256>>>(d, o, iters); else probe<1><<<256, 256>>>(d, o, iters);
+            if (mode == 0) probe<0><<<256, 256>>>(d, o, iters); else if (mode == 1) probe<1><<<256, 256>>>(d, o, iters); else probe<2><<<256, 256>>>(d, o, iters);
             hipEventRecord(b); hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
             const double flop = 256.0 * 4 * iters * (128.0 * 128 * 64 * 2) * 3; // hi*hi + two correction terms, per wave tile
-            printf("mode %d (%s): %.3f ms  %.0f TFLOP/s (f16-term-equivalent x3)\n", mode, mode ? "16x16 shapes" : "32x32 shapes", ms, flop / ms / 1e9);
+            printf("mode %d (%s): %.3f ms  %.0f TFLOP/s (f16-term-equivalent x3)\n", mode, mode == 1 ? "16x16 shapes" : mode == 2 ? "32x32 shapes, fp6 correction terms" : "32x32 shapes", ms, flop / ms / 1e9);
         }
     return 0;
 }
