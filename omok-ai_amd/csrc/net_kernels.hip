@@ -52,6 +52,9 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ inline void nt_store(const uint4& v, uint4* p) { __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, (u32x4*)p); }
 typedef short short2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x6 __attribute__((ext_vector_type(6)));
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+typedef _Float16 half32 __attribute__((ext_vector_type(32)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // x = hi + lo with hi = f16(x) (v_cvt_pk_f16_f32, round to nearest: two values per instruction) and
 // lo = f16(x - hi) computed by ONE mixed-precision fma per value (v_fma_mix{lo,hi}_f16 reads hi as f16 and x as
@@ -203,6 +206,7 @@ constexpr int GRID_STRIDE = 36; // floats per halo-grid row (32 + 4 pad: conflic
 // fc0 operand row: per (pixel tile, channel half q) one dense 6-KiB block = f16 part [32 pxl][128 B], then fp8 residual
 // part [32 pxl][64 B] (uint4 units below)
 constexpr int OP_BLK_U4 = 384, OP_LO_U4 = 256;
+constexpr bool MX6 = true;   // fc0 correction terms on fp6 (e2m3) operands with per-lane E8M0 block scales (false: fp8, global scales)
 constexpr int MX_SA = 2;        // fp8 copies of the fc0 operand are x * 2^MX_SA (|x| <= 112 representable; clamped beyond)
 
 template <int N>
@@ -540,8 +544,11 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
             const float sc_lo_inv = __uint_as_float((uint32_t)(127 - MX_SA - 11) << 23); // fp8 = (x - hi) / 2^-(SA+11)
             uint4* stage_w = (uint4*)(grid + gi * GRID_STRIDE);          // this lane's pixel row (8 slots of 16 B)
             uint32_t p8l[2][8];
+            u32x6 lo6[2];        // MX6: fp6 residuals of the lane's 32 values per channel half q, natural slot order 16*mm + reg
+            uint32_t esc[2];     // MX6: E8M0 bytes of the two block scales (hi copy | residual << 8)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
+                float res[32], amax_v = 0.0f, amax_l = 0.0f;
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
@@ -559,13 +566,28 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                             asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph), "v"(v1));
                             const int slot = 16 * mm + 8 * sx + 2 * jj; // byte slot of v0
                             const int w = slot >> 2;
-                            if ((slot & 3) == 0)
+                            if (MX6) {
+                                res[slot] = l0; res[slot + 1] = l1;
+                                // (from asm: fmaxf() drags a canonicalising v_max per operand along under IEEE mode)
+                                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax_v) : "v"(v0), "v"(v1));
+                                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax_l) : "v"(l0), "v"(l1));
+                            } else if ((slot & 3) == 0)
                                 p8l[q][w] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(short2v{0, 0}, l0, l1, sc_lo_inv, false));
                             else
                                 p8l[q][w] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(short2v, p8l[q][w]), l0, l1, sc_lo_inv, true));
                         }
                         if (valid) stage_w[(mm * 2 + sx) * 2 + h] = H.v;
                     }
+                if (MX6) { // block scales 2^(floor(log2 max) - 2) (e2m3 emax = 2) and the packed fp6 residuals
+                    int eh = (int)((__float_as_uint(amax_v) >> 23) & 0xFFu) - 2, el = (int)((__float_as_uint(amax_l) >> 23) & 0xFFu) - 2;
+                    eh = eh < 1 ? 1 : eh;
+                    el = el < 1 ? 1 : el;
+                    esc[q] = (uint32_t)eh | ((uint32_t)el << 8);
+                    f32x16v ev, od; // v_cvt_scalef32_2xpk16_fp6_f32 interleaves its two sources: field 2i = ev[i], 2i+1 = od[i]
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { ev[i] = res[2 * i]; od[i] = res[2 * i + 1]; }
+                    lo6[q] = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, __uint_as_float((uint32_t)el << 23));
+                }
                 // read back: lanes 8i'..8i'+7 hold the 8 pieces of pixel 8i + i' of the tile
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -577,8 +599,14 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
             if (valid) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    stage_w[q * 4 + h * 2 + 0] = make_uint4(p8l[q][0], p8l[q][1], p8l[q][2], p8l[q][3]);
-                    stage_w[q * 4 + h * 2 + 1] = make_uint4(p8l[q][4], p8l[q][5], p8l[q][6], p8l[q][7]);
+                    if (MX6) { // 64 B per (pixel, q): [h0 dwords 0..3][h1 dwords 0..3][h0 dwords 4,5 | h1 dwords 4,5][scale bytes h0, h1 | pad]
+                        stage_w[q * 4 + h] = make_uint4(lo6[q][0], lo6[q][1], lo6[q][2], lo6[q][3]);
+                        ((uint2*)(stage_w + q * 4 + 2))[h] = make_uint2(lo6[q][4], lo6[q][5]);
+                        ((uint16_t*)(stage_w + q * 4 + 3))[h] = (uint16_t)esc[q];
+                    } else {
+                        stage_w[q * 4 + h * 2 + 0] = make_uint4(p8l[q][0], p8l[q][1], p8l[q][2], p8l[q][3]);
+                        stage_w[q * 4 + h * 2 + 1] = make_uint4(p8l[q][4], p8l[q][5], p8l[q][6], p8l[q][7]);
+                    }
                 }
             }
 #pragma unroll
@@ -659,6 +687,22 @@ __device__ inline void f16x8_to_fp8(const half8& v, float inv_mul, uint32_t& d0,
 // by one wave with 4 independent accumulator chains.
 constexpr int NET_CHUNK_DEFAULT = 0; // rows per forward launch (0 = unchunked); OMOK_NET_CHUNK overrides
 constexpr bool A_NT = true;     // the sample-operand stream is read once: non-temporal, so it does not displace the weight stream in L2
+// MX6 helpers: fp6 (e2m3) copy of 32 f16 values (4 consecutive 8-element pieces, natural slot order) = x / 2^(E - 127)
+__device__ inline v8i f16x32_to_fp6(const half8& p0, const half8& p1, const half8& p2, const half8& p3, uint32_t e8m0) {
+    typedef _Float16 half16 __attribute__((ext_vector_type(16)));
+    const half16 lo = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const half16 hi = __builtin_shufflevector(p2, p3, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const half32 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27,
+                                             28, 29, 30, 31);
+    const u32x6 r = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(v, __uint_as_float(e8m0 << 23));
+    return v8i{(int)r[0], (int)r[1], (int)r[2], (int)r[3], (int)r[4], (int)r[5], 0, 0};
+}
+// fp6 x fp6 block-scaled MFMA; SEL_A / SEL_B = byte of the scale registers that holds this operand's E8M0 block scale
+#define MFMA6(A, B, ACC, SEL_A, SA, SEL_B, SB)                                                                                  \
+    ((SEL_B) == 0 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((A), (B), (ACC), 2, 2, (SEL_A), (int)(SA), 0, (int)(SB))  \
+   : (SEL_B) == 1 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((A), (B), (ACC), 2, 2, (SEL_A), (int)(SA), 1, (int)(SB))  \
+   : (SEL_B) == 2 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((A), (B), (ACC), 2, 2, (SEL_A), (int)(SA), 2, (int)(SB))  \
+                  : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((A), (B), (ACC), 2, 2, (SEL_A), (int)(SA), 3, (int)(SB)))
 constexpr bool STAGGER = false; // (skewing the waves by s_nops after the barrier: 3.52 -> 3.88 ms, the delay costs more than it saves)
 template <int EPI, int DBG = 0> // DBG: timing-only ablations (1 = no weight DMA, 2 = no sample DMA, 4 = no fp8 derivation, 8 = no vmcnt waits)
 __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksup,
@@ -730,6 +774,20 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     for (int j = 0; j < 4; ++j) a_rd_hi[j] = sl * 8 + ((2 * j + h) ^ ((sl >> 1) & 7));
 #pragma unroll
     for (int e = 0; e < 2; ++e) a_rd_lo[e] = 1024 + sl * 4 + ((2 * h + e) ^ ((sl >> 2) & 3));
+    // MX6: the 64 B of a sample's residual part = [h0 fp6 dwords 0..3][h1 dwords 0..3][h0 dwords 4,5 | h1 dwords 4,5][scale bytes | pad]
+    const int a_rd_lo6 = 1024 + sl * 4 + (h ^ ((sl >> 2) & 3));                          // uint4 index of this lane's first 16 B
+    const int a_rd_tail = (1024 + sl * 4 + (2 ^ ((sl >> 2) & 3))) * 16 + 8 * h;         // byte offset of its last 8 B
+    const int a_rd_esc = (1024 + sl * 4 + (3 ^ ((sl >> 2) & 3))) * 16 + 2 * h;          // byte offset of its two scale bytes (hi copy, residual)
+    uint32_t sc_hi = 0, sc_lo = 0, sc_hi_n = 0, sc_lo_n = 0; // E8M0 bytes of the 4 sample tiles (byte c), current / next super-step
+    auto read_lo6 = [&](const uint4* LA, int c, v8i& a6, uint32_t& e_hi, uint32_t& e_lo) { // sample tile c of the buffer at LA
+        const unsigned char* Bp = (const unsigned char*)LA + c * 2048;
+        const uint4 q0 = LA[c * 128 + a_rd_lo6];
+        const uint2 q1 = *(const uint2*)(Bp + a_rd_tail);
+        const uint32_t e = *(const uint16_t*)(Bp + a_rd_esc);
+        a6 = v8i{(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y, 0, 0};
+        e_hi |= (e & 0xFFu) << (8 * c);
+        e_lo |= (e >> 8) << (8 * c);
+    };
     // fp8 conversions saturate to +-448 instead of producing NaN (MODE.FP16_OVFL, probed: tools/probe/cvt_probe.hip)
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
     const float w_inv = 1.0f / sc.w_mul, a_inv = 1.0f / sc.a_mul; // powers of two
@@ -760,7 +818,10 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
 #pragma unroll
             for (int c = 0; c < 4; ++c) bh[c][j] = *(const half8*)(ldsA + c * 256 + a_rd_hi[j]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a8l[c] = v8_from(ldsA[c * 128 + a_rd_lo[0]], ldsA[c * 128 + a_rd_lo[1]]);
+        for (int c = 0; c < 4; ++c) {
+            if (MX6) read_lo6(ldsA, c, a8l[c], sc_hi, sc_lo);
+            else a8l[c] = v8_from(ldsA[c * 128 + a_rd_lo[0]], ldsA[c * 128 + a_rd_lo[1]]);
+        }
 #pragma unroll
         for (int k = 0; k < 6; ++k) wc[k] = ldsW0[w_rd_off + k * 64];
     }
@@ -785,7 +846,9 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
             half8 ah[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) ah[j] = __builtin_bit_cast(half8, wc[j]);
-            const v8i w8l = v8_from(wc[4], wc[5]);
+            const v8i w8l = MX6 ? v8i{(int)wc[4].x, (int)wc[4].y, (int)wc[4].z, (int)wc[4].w, (int)wc[5].x, (int)wc[5].y, 0, 0} : v8_from(wc[4], wc[5]);
+            const uint32_t wsc = wc[5].z; // MX6: E8M0 bytes of this lane's weight block (byte 0: fp6 copy of hi, byte 1: residual)
+            v8i w6h = {0, 0, 0, 0, 0, 0, 0, 0};
             uint32_t w8[8]; // fp8 copy of ah[0..3]: dword 2j, 2j+1
             if (g == 3) { // every wave's share of A(ul+1) must have landed before anyone reads it: its last pieces were
                           // issued at the head of stage g = 2's block-scaled phase, 6 weight pieces behind them
@@ -814,6 +877,10 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     acc[g][c] = MFMA16(ah[j], bh[c][j], acc[g][c]);
+                    if (MX6) { // one packed convert per 32 values: the weight block in the first gap, sample tile c in gap (1, c) of g = 0
+                        if (j == 0 && c == 0) w6h = (DBG & 4) ? w8l : f16x32_to_fp6(ah[0], ah[1], ah[2], ah[3], wsc & 0xFFu);
+                        if (g == 0 && j == 1) a8h[c] = (DBG & 4) ? a8l[c] : f16x32_to_fp6(bh[c][0], bh[c][1], bh[c][2], bh[c][3], (sc_hi >> (8 * c)) & 0xFFu);
+                    } else {
                     if (!(DBG & 4)) { // weight pair c of piece j -> one half of dword 2j + (c >> 1)
                         const uint4 aq = __builtin_bit_cast(uint4, ah[j]);
                         const uint32_t src = c == 0 ? aq.x : c == 1 ? aq.y : c == 2 ? aq.z : aq.w;
@@ -823,6 +890,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
                         uint32_t d0, d1;
                         if (DBG & 4) { d0 = (uint32_t)w8l[2] + c; d1 = (uint32_t)w8l[7] + j; } else f16x8_to_fp8(bh[c][j], a_inv, d0, d1);
                         a8h[c][2 * j] = (int)d0; a8h[c][2 * j + 1] = (int)d1;
+                    }
                     }
                     if (g == 3) bh[c][j] = *(const half8*)(LAn + c * 256 + a_rd_hi[j]); // next super-step's piece
                     if (j == 3) { // stage q+1's weights (issued during stage q-2): everything but the pieces of stage q-1
@@ -840,21 +908,29 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
                     GAP();
                 }
             }
-            const v8i w8h = v8i{(int)w8[0], (int)w8[1], (int)w8[2], (int)w8[3], (int)w8[4], (int)w8[5], (int)w8[6], (int)w8[7]};
+            v8i w8h;
+            if (MX6) w8h = w6h;
+            else w8h = v8i{(int)w8[0], (int)w8[1], (int)w8[2], (int)w8[3], (int)w8[4], (int)w8[5], (int)w8[6], (int)w8[7]};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8h, a8l[c], acc[g][c], 0, 0, 0, sc.wa_hi, 0, sc.ab_lo);
+                if (MX6) acc[g][c] = MFMA6(w8h, a8l[c], acc[g][c], 0, wsc, c, sc_lo); // (fp6 copy of w) x (residual of x)
+                else acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8h, a8l[c], acc[g][c], 0, 0, 0, sc.wa_hi, 0, sc.ab_lo);
                 if (c == 0) dma_piece(5);
                 if (c == 3) dma_piece(6);
-                if (g == 3) a8l[c] = v8_from(LAn[c * 128 + a_rd_lo[0]], LAn[c * 128 + a_rd_lo[1]]);
+                if (g == 3) {
+                    if (MX6) read_lo6(LAn, c, a8l[c], sc_hi_n, sc_lo_n);
+                    else a8l[c] = v8_from(LAn[c * 128 + a_rd_lo[0]], LAn[c * 128 + a_rd_lo[1]]);
+                }
                 GAP();
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8l, a8h[c], acc[g][c], 0, 0, 0, sc.wa_lo, 0, sc.ab_hi);
+                if (MX6) acc[g][c] = MFMA6(w8l, a8h[c], acc[g][c], 1, wsc, c, sc_hi); // (residual of w) x (fp6 copy of x)
+                else acc[g][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8l, a8h[c], acc[g][c], 0, 0, 0, sc.wa_lo, 0, sc.ab_hi);
                 if (c == 2) dma_piece(7);
                 GAP();
             }
+            if (MX6 && g == 3) { sc_hi = sc_hi_n; sc_lo = sc_lo_n; sc_hi_n = 0; sc_lo_n = 0; }
 #pragma unroll
             for (int k = 0; k < 6; ++k) wc[k] = wn[k];
         }
@@ -1169,6 +1245,31 @@ static uint8_t to_e4m3(float x) {
     return sign | (uint8_t)(((E + 7) << 3) | r);
 }
 
+// fp6 e2m3 (1 sign, 2 exponent, 3 mantissa; subnormal step 0.125, normals 1..7.5, no NaN / Inf): round to nearest even, saturating
+static uint8_t to_e2m3(float x) {
+    const uint8_t sign = x < 0.0f ? 0x20 : 0x00;
+    const float a = fabsf(x);
+    if (!(a == a)) return sign;
+    if (a >= 7.5f) return sign | 0x1f;
+    int best = 0;
+    float bd = 1e30f;
+    for (int c = 0; c < 32; ++c) {
+        const int ex = c >> 3, m = c & 7;
+        const float v = ex == 0 ? m * 0.125f : (1.0f + m * 0.125f) * (float)(1 << (ex - 1));
+        const float d = fabsf(v - a);
+        if (d < bd || (d == bd && !(c & 1))) { bd = d; best = c; }
+    }
+    return sign | (uint8_t)best;
+}
+// E8M0 byte of the MX block scale for a block whose largest magnitude is amax: 2^(floor(log2 amax) - 2) (e2m3 emax = 2)
+static int mx6_scale_byte(float amax) {
+    if (!(amax > 0.0f)) return 1;
+    int e;
+    frexpf(amax, &e); // amax = m * 2^e, m in [0.5, 1): floor(log2 amax) = e - 1
+    int E = 127 + (e - 1) - 2;
+    return E < 1 ? 1 : (E > 254 ? 254 : E);
+}
+
 static int heads_mt(int hw) { return ((hw + 1 + 31) / 32 + 3) / 4 * 4; }
 
 size_t net_alloc(Net& net) {
@@ -1303,6 +1404,29 @@ int net_commit(Net& net, hipStream_t st) {
                     const int mt = 4 * g + i;
                     for (int l = 0; l < 64; ++l) {
                         const int r = l & 31, hh = l >> 5, n = 32 * mt + r;
+                        if (MX6) { // fragments 4, 5 = [lane][fp6 dwords 0..3] | [lane][fp6 dwords 4, 5 | scale bytes (hi copy, residual) | 0]
+                            float whf[32], wlf[32], ah = 0.0f, al = 0.0f;
+                            for (int slot = 0; slot < 32; ++slot) {
+                                const int mm = slot >> 4, reg = slot & 15;
+                                const size_t k = (size_t)upx[u] * NC + kperm(2 * uq[u] + mm, reg >> 3, hh, reg & 7);
+                                const float wv = w[k * NF + n];
+                                whf[slot] = (float)(_Float16)wv;
+                                wlf[slot] = wv - whf[slot];
+                                ah = fmaxf(ah, fabsf(whf[slot]));
+                                al = fmaxf(al, fabsf(wlf[slot]));
+                            }
+                            const int Eh = mx6_scale_byte(ah), El = mx6_scale_byte(al);
+                            uint32_t pk6[6] = {0, 0, 0, 0, 0, 0};
+                            for (int slot = 0; slot < 32; ++slot) {
+                                const uint32_t code = to_e2m3(ldexpf(wlf[slot], 127 - El));
+                                const int bit = 6 * slot;
+                                pk6[bit >> 5] |= code << (bit & 31);
+                                if ((bit & 31) > 26) pk6[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+                            }
+                            memcpy(st + (size_t)4 * 1024 + (size_t)l * 16, pk6, 16);
+                            const uint32_t tail[4] = {pk6[4], pk6[5], (uint32_t)Eh | ((uint32_t)El << 8), 0u};
+                            memcpy(st + (size_t)5 * 1024 + (size_t)l * 16, tail, 16);
+                        }
                         for (int slot = 0; slot < 32; ++slot) { // byte slot = 16*(m&1) + reg, reg = 8*s + jj
                             const int mm = slot >> 4, reg = slot & 15;
                             const int m = 2 * uq[u] + mm;
@@ -1312,7 +1436,7 @@ int net_commit(Net& net, hipStream_t st) {
                             const float wl = wv - (float)wh;
                             const int j = 2 * mm + (reg >> 3), jj = reg & 7; // f16 piece j, element jj
                             memcpy(st + (size_t)j * 1024 + (size_t)l * 16 + jj * 2, &wh, 2);
-                            st[(size_t)(4 + (slot >> 4)) * 1024 + (size_t)l * 16 + (slot & 15)] = to_e4m3(wl * s_lo);
+                            if (!MX6) st[(size_t)(4 + (slot >> 4)) * 1024 + (size_t)l * 16 + (slot & 15)] = to_e4m3(wl * s_lo);
                         }
                     }
                 }
