@@ -802,15 +802,20 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     half8 bh[4][4];  // sample operands of the current super-step (f16 pieces)
     v8i a8l[4], a8h[4];
     uint4 wc[6];     // this wave's weight fragments of the current stage
-    { // prologue: sample operands of the first super-step, weight stages 0..2  (per wave: 6 + 18 DMA instructions)
-        const int uo = uoff(ubeg);
+    { // prologue, in the issue order of the steady state's last four stages: sample operands of super-step 0, weight stages
+      // 0..2, the first two pieces of super-step 1, weight stage 3  (per wave: 8 + 24 DMA instructions)
+        const int uo = uoff(ubeg), uo1 = uoff(ubeg + 1);
 #pragma unroll
         for (int k = 0; k < 6; ++k) issue_a1(uo, 0, k);
 #pragma unroll
         for (int st = 0; st < 3; ++st)
 #pragma unroll
             for (int k = 0; k < 6; ++k) issue_w1(st, st, k);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); // A(0) and W(0) landed
+        issue_a1(uo1, 1, 0);
+        issue_a1(uo1, 1, 1);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) issue_w1(3, 3, k);
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); // A(0) and W(0) landed
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -833,14 +838,14 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     //                     at g = 3 the LDS read that replaces the piece just consumed, at the end the next stage's
     //                     weight fragments LDS -> registers
     //   scaled-fp8 gaps : one LDS-DMA each (16-pass MFMA = 64 cycles)
-    // Stage q = (ul, g) lives in ring slot g.  The DMA of stage q+3 goes to slot (g+3)&3 (read during stage q-2,
-    // consumed by the MFMAs of stage q-1).  Per block-scaled phase the DMA order is [2 sample pieces (g < 3)], 6 weights.
+    // Stage q = (ul, g) lives in ring slot g.  The DMA of stage q+4 goes to slot g itself (its fragments were read into
+    // registers during stage q-1): four stages of weights are in flight or resident.  Per block-scaled phase the DMA order is [2 sample pieces (g < 3)], 6 weights.
     // One workgroup barrier per super-step (top of g = 3): behind it the NEXT super-step's sample operands replace the
     // current ones in registers piece by piece, each right after its last MFMA.
 #define GAP() __builtin_amdgcn_sched_barrier(0)
     for (int ul = 0; ul < ksup; ++ul) {
         const int ub = ul & 1;
-        const int uo_next = uoff(ubeg + ul + 1);
+        const int uo_next = uoff(ubeg + ul + 1), uo_next2 = uoff(ubeg + ul + 2);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             half8 ah[4];
@@ -848,11 +853,13 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
             for (int j = 0; j < 4; ++j) ah[j] = __builtin_bit_cast(half8, wc[j]);
             const v8i w8l = MX6 ? v8i{(int)wc[4].x, (int)wc[4].y, (int)wc[4].z, (int)wc[4].w, (int)wc[5].x, (int)wc[5].y, 0, 0} : v8_from(wc[4], wc[5]);
             const uint32_t wsc = wc[5].z; // MX6: E8M0 bytes of this lane's weight block (byte 0: fp6 copy of hi, byte 1: residual)
+            // this stage's DMA refills ring slot g, the slot `wc` was read from one stage ago: those reads have returned
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             v8i w6h = {0, 0, 0, 0, 0, 0, 0, 0};
             uint32_t w8[8]; // fp8 copy of ah[0..3]: dword 2j, 2j+1
             if (g == 3) { // every wave's share of A(ul+1) must have landed before anyone reads it: its last pieces were
-                          // issued at the head of stage g = 2's block-scaled phase, 6 weight pieces behind them
-                if (!(DBG & 8)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                          // issued at the head of stage g = 1, with 6 + 6 weight pieces behind them
+                if (!(DBG & 8)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 // the barrier releases the four waves in the same cycle and they would then reach every DMA gap together
@@ -864,12 +871,15 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
             uint4 wn[6];
             // DMA piece d = 0..7 of this stage: [2 sample pieces (g < 3)], 6 weight pieces; spread over the stage's 24
             // MFMA gaps (the four waves share one texture path: 30 pieces x 16 cycles per stage and CU)
-            auto dma_piece = [&](int d) {
-                if (g < 3) {
-                    if (d < 2) issue_a1(uo_next, ub ^ 1, 2 * g + d);
-                    else issue_w1(ul * 4 + g + 3, (g + 3) & 3, d - 2);
-                } else if (d < 6) {
-                    issue_w1(ul * 4 + g + 3, (g + 3) & 3, d);
+            auto dma_piece = [&](int d) { // sample pieces run two super-steps ahead: A(ul+1) pieces 2..5 at g = 0, 1; A(ul+2) pieces 0, 1 at
+                // g = 3, behind the barrier (its buffer held A(ul), which every wave finished reading before that barrier)
+                if (g == 2) {
+                    if (d < 6) issue_w1(ul * 4 + g + 4, g, d);
+                } else if (d < 2) {
+                    if (g == 3) issue_a1(uo_next2, ub, d);
+                    else issue_a1(uo_next, ub ^ 1, 2 + 2 * g + d);
+                } else {
+                    issue_w1(ul * 4 + g + 4, g, d - 2);
                 }
             };
 #pragma unroll
@@ -893,11 +903,11 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
                     }
                     }
                     if (g == 3) bh[c][j] = *(const half8*)(LAn + c * 256 + a_rd_hi[j]); // next super-step's piece
-                    if (j == 3) { // stage q+1's weights (issued during stage q-2): everything but the pieces of stage q-1
-                                  // and the first 4 of this stage has landed
+                    if (j == 3) { // stage q+1's weights (issued during stage q-3): everything but the pieces of stages q-2, q-1
+                                  // (8 each, 6 for a g = 2 stage) and the first 4 of this stage has landed
                         if (c == 0 && !(DBG & 8)) {
-                            if (g == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                            if (g == 0 || g == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
                         }
                         if (c >= 1) {
                             wn[2 * (c - 1)] = ring((g + 1) & 3)[w_rd_off + (2 * (c - 1)) * 64];
@@ -1303,7 +1313,7 @@ size_t net_alloc(Net& net) {
         const size_t row_u4 = net.row_u4;
         ok = ok && A(&net.wt_trunk, TR_WBYTES + TR_CONV_FRAGS * 1024);
         ok = ok && A((void**)&net.wt_first, sizeof(float) * (TR_SIDE_FLOATS + 2 * NF + heads_mt(net.hw) * 32));
-        ok = ok && A(&net.wt_fc0, (ks0 + 3) * (size_t)MXS_FR * 1024); // hw*2 super-steps x 4 stages (= ks0) + 3 stages of padding
+        ok = ok && A(&net.wt_fc0, (ks0 + 4) * (size_t)MXS_FR * 1024); // hw*2 super-steps x 4 stages (= ks0) + 4 stages of padding (prefetch depth)
         ok = ok && A(&net.wt_fc1, (size_t)32 * 16 * 2 * 1024);
         ok = ok && A(&net.wt_heads, (size_t)32 * heads_mt(net.hw) * 2 * 1024);
         ok = ok && A(&net.a_fc0, mb * row_u4 * 16 + 2 * OP_BLK_U4 * 16); // + slack: the prefetch of the super-step past the last one reads one block beyond the row
@@ -1395,7 +1405,7 @@ int net_commit(Net& net, hipStream_t st) {
             for (int q = 0; q < 2; ++q)
                 for (int pl = 0; pl < 32 && tile * 32 + pl < hw; ++pl) { upx.push_back(tile * 32 + pl); uq.push_back(q); }
         const size_t nsup = upx.size();
-        buf.assign((nsup * 4 + 3) * MXS_FR * 1024, 0);
+        buf.assign((nsup * 4 + 4) * MXS_FR * 1024, 0);
         const float s_lo = ldexpf(1.0f, SW + 11);
         for (size_t u = 0; u < nsup; ++u)
             for (int g = 0; g < 4; ++g)
