@@ -27,7 +27,7 @@ import torch.distributed as dist  # noqa: E402
 F16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16/f16 MFMA dense
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
 # HBM bytes per fc0 row from the committed rocprofv3 --pmc passes (profiles/README.md, B = 65536): FETCH_SIZE raw x 2
-# (gfx950 correction for 128-B requests) minus the fp8 part that is fetched in exact 64-B requests, plus WRITE_SIZE.
+# (gfx950 correction for 128-B requests) minus the residual part that is fetched in exact 64-B requests, plus WRITE_SIZE.
 FC0_HBM_BYTES_PER_ROW = {15: (3.901e6 * 1024 * 2 - 65536 * 28800.0 + 1.336e5 * 1024) / 65536}
 
 
@@ -178,7 +178,7 @@ def main():
         "metric": "self-play games/sec (15x15, 800 sims/move); MCTS nodes/sec",
         "value": games_per_s, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 (split hi+lo MFMA operands; fc0 correction terms in block-scaled fp8), fp32 accumulate" if args.net_mode == "f16x3" else "f32",
+        "dtype": "f16 (split hi+lo MFMA operands; fc0 correction terms in block-scaled fp6), fp32 accumulate" if args.net_mode == "f16x3" else "f32",
         "data": "synthetic (games from the empty board, random-init net seed 0)",
         "config": {"workload": f"{games} concurrent {n}x{n} games per GPU, {args.sims} sims/move, K={k}, two trees per game"
                                + ("" if complete else f", first {args.max_plies} plies only (games/s extrapolated)"),
@@ -192,11 +192,11 @@ def main():
                      "traffic_unit": "HBM bytes per launch (rows per launch x per-row bytes of the committed PMC pass: "
                                      "profiles/README.md; FETCH_SIZE x2 + WRITE_SIZE)",
                      "algorithmic_bytes_per_launch": (128 * hw * 3 + 2048) * st["fc0_rows"] / max(st["fc0_launches"], 1.0) + 128 * hw * 512 * 3,
-                     "mfma_mix_bound": {"value": 832.0, "unit": "TFLOP/s", "frac_of_bound": fc0_tflops / 832.0,
+                     "mfma_mix_bound": {"value": 1078.0, "unit": "TFLOP/s", "frac_of_bound": fc0_tflops / 1078.0,
                                         "note": "the kernel's MFMA mix alone (operands in registers, random data, one wave per SIMD, every CU): "
-                                                "tools/probe/shape_probe mode 0 = 2497 TFLOP/s over the three product terms = 832 algorithmic"},
-                     "note": "algorithmic flops (2*128*HW*512 per eval); per K=64 the kernel issues 4 f16 + 2 block-scaled fp8 "
-                             "MFMAs (split operands) = 1.41x the pipe time of a plain-f16 product, so frac <= 0.71 by construction"},
+                                                "tools/probe/shape_probe mode 2 = 3234 TFLOP/s over the three product terms = 1078 algorithmic"},
+                     "note": "algorithmic flops (2*128*HW*512 per eval); per K=64 the kernel issues 4 f16 + 2 block-scaled fp6 "
+                             "MFMAs (split operands) = 1.5x the pipe time of a plain-f16 product, so frac <= 0.67 by construction"},
         "roofline_net": {"bound": "mfma", "achieved": evals * flop_eval / net_s / 1e12 if net_s > 0 else 0.0,
                          "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (evals * flop_eval / net_s / 1e12 / F16_DENSE_PEAK_TFLOPS) if net_s > 0 else 0.0},

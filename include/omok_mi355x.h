@@ -37,7 +37,7 @@ extern "C" {
 #define OMOK_MODE_PLAYER 0   /* EnvTurnMode::Player   (alpha-zero/src/encoder.rs:4-8) */
 #define OMOK_MODE_OPPONENT 1 /* EnvTurnMode::Opponent */
 
-#define OMOK_NET_F16X3 0 /* split-operand MFMA (hi+lo: f16 main term, f16 / block-scaled fp8 correction terms, fp32 accumulate) */
+#define OMOK_NET_F16X3 0 /* split-operand MFMA (hi+lo: f16 main term, f16 / block-scaled fp6 correction terms, fp32 accumulate) */
 #define OMOK_NET_F32 1   /* plain fp32 VALU kernels (debug / A-B reference on the GPU) */
 
 typedef struct omok_engine omok_engine;

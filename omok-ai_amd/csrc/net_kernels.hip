@@ -621,19 +621,20 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
 }
 
 // ===============================================================================================
-// OMOK_NET_F16X3: fc0 with block-scaled fp8 correction terms
+// OMOK_NET_F16X3: fc0 with block-scaled fp6 (or fp8) correction terms
 // ===============================================================================================
-// x*w = hi*hi (f16 MFMA) + lo*hi + hi*lo, the two correction terms on v_mfma_scale_f32_32x32x64_f8f6f4 with fp8
-// (e4m3) operands: they are 2^-11 of the product, so 3 mantissa bits keep the total at ~2^-15 relative
-// (tools/precision_study.py: max|dp| 4e-5), and per K=64 the matrix pipe executes 4 f16 + 2 fp8 MFMAs
-// instead of 12 f16 MFMAs (2.1x less pipe time, tools/probe/mx_rate.hip).  Operand layout probed on the device
-// (tools/probe/mx_probe.hip): lane = row/col, 32 bytes per lane, k-slots pair by (lane-half, byte); the E8M0
-// scale byte multiplies the result by 2^(byte-127).
+// x*w = hi*hi (f16 MFMA) + lo*hi + hi*lo.  The two correction terms are 2^-11 of the product, so 4 significant bits
+// keep the total at ~2^-15 relative: they run on v_mfma_scale_f32_32x32x64_f8f6f4 with fp6 (e2m3) operands and one E8M0
+// scale byte per lane and 32-element K block (MX6; the first version used fp8 e4m3 with global scales, MX6 = false).
+// Per K = 64 the matrix pipe executes 4 f16 + 2 fp6 MFMAs of 32 cycles instead of 12 f16 MFMAs.  Probed on the device:
+//   tools/probe/fp6_probe.hip  lane l = row/col l&31, k = 32*(l>>5) + i in bits [6i, 6i+5] of the lane's 192 bits; the lane's
+//                              scale byte (selected by opsel) scales exactly that block by 2^(byte-127); the packed converts
+//                              divide by the scale and keep element order (pk32) / interleave their two sources (2xpk16)
+//   tools/probe/mx_probe.hip   the same for fp8;  shape_probe.hip / mx_rate.hip  the rates of the instruction mixes
 //
-// Tile = 512 features x 128 samples per workgroup, 8 waves.  A K=64 super-step is consumed in 4 stages, one per
-// group of 4 m-tiles: weights (32 KiB per stage) flow through a 3-slot LDS ring, the sample operands of a
-// super-step (32 KiB) are double-buffered and shared by its 4 stages.  Wave (wm, ws) owns m-tile 4g+wm of every
-// group g and sample tiles {2ws, 2ws+1}.
+// Tile = 512 features x 128 samples per workgroup, 4 waves (one per SIMD).  A K=64 super-step is consumed in 4 stages,
+// one per group of 4 m-tiles: weights (24 KiB per stage) flow through a 4-slot LDS ring, the sample operands of a
+// super-step (24 KiB) are double-buffered and stay in registers for its 4 stages (details at the kernel).
 typedef int v8i __attribute__((ext_vector_type(8)));
 #define VMCNT(n) ((((n) & 15) | (((n) >> 4) << 14)) | (7 << 4) | (15 << 8)) // s_waitcnt immediate: vmcnt(n) only
 constexpr int MXS_FR = 24;              // fragments per weight stage (4 m-tiles x {hi j0..j3, lo8 half0, half1}) and per
