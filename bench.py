@@ -28,7 +28,7 @@ F16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16/f16 MFMA dense
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
 # HBM bytes per fc0 row from the committed rocprofv3 --pmc passes (profiles/README.md, B = 65536): FETCH_SIZE raw x 2
 # (gfx950 correction for 128-B requests) minus the residual part that is fetched in exact 64-B requests, plus WRITE_SIZE.
-FC0_HBM_BYTES_PER_ROW = {15: (3.901e6 * 1024 * 2 - 65536 * 28800.0 + 1.336e5 * 1024) / 65536}
+FC0_HBM_BYTES_PER_ROW = {15: (3.873e6 * 1024 * 2 - 65536 * 28800.0 + 1.347e5 * 1024) / 65536}
 
 
 def parse():
