@@ -197,6 +197,10 @@ def main():
                                                 "tools/probe/shape_probe mode 2 = 3234 TFLOP/s over the three product terms = 1078 algorithmic"},
                      "note": "algorithmic flops (2*128*HW*512 per eval); per K=64 the kernel issues 4 f16 + 2 block-scaled fp6 "
                              "MFMAs (split operands) = 1.5x the pipe time of a plain-f16 product, so frac <= 0.67 by construction"},
+        "roofline_trunk": {"bound": "mfma", "kernel": "k_trunk", "achieved": evals * (flop_eval - flop_fc0 - 2.0 * (512 * 512 + 512 + 512 * hw)) / (st["ms_trunk"] * 1e-3) / 1e12 if st["ms_trunk"] > 0 else 0.0,
+                           "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "note": "conv_in + 3 bottleneck blocks, 3 f16 MFMAs per product; not MFMA-bound: VALU-issue / LDS / barrier-bound "
+                                   "(DESIGN.md 3.2: MFMA busy 36 %, phase model at 82 %)"},
         "roofline_net": {"bound": "mfma", "achieved": evals * flop_eval / net_s / 1e12 if net_s > 0 else 0.0,
                          "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (evals * flop_eval / net_s / 1e12 / F16_DENSE_PEAK_TFLOPS) if net_s > 0 else 0.0},
