@@ -1199,10 +1199,18 @@ __global__ __launch_bounds__(64) void k_softmax(const float* __restrict__ logits
         float mx = -INFINITY;
         for (int a = lane; a < hw; a += 64) mx = fmaxf(mx, l[a]);
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        float sum = 0.0f;
-        for (int a = lane; a < hw; a += 64) sum += expf(l[a] - mx);
+        float sum = 0.0f, e[4] = {0.0f, 0.0f, 0.0f, 0.0f}; // rowp <= 256: at most 4 cells per lane
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a = lane + 64 * i;
+            if (a < hw) { e[i] = expf(l[a] - mx); sum += e[i]; }
+        }
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        for (int a = lane; a < rowp; a += 64) p[(size_t)s * rowp + a] = a < hw ? expf(l[a] - mx) / sum : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a = lane + 64 * i;
+            if (a < rowp) p[(size_t)s * rowp + a] = a < hw ? e[i] / sum : 0.0f;
+        }
         if (lane == 0) v[s] = tanhf(l[hw]);
     }
 }
@@ -1579,7 +1587,7 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     const int MT = heads_mt(hw);
     if (MT == 8) launch_gemm<8, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st);
     else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st);
-    const int sg = max_count < 4096 ? max_count : 4096;
+    const int sg = max_count < 32768 ? max_count : 32768; // one wave per row up to 32 waves per SIMD: the row loop is a chain of dependent loads
     k_softmax<<<sg, 64, 0, st>>>(net.s0, MT * 32, hw, net.rowp, net.p, net.v, S.d_count, max_count);
     if (prof) prof->end(st);
 }
