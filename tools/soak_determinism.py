@@ -1,5 +1,7 @@
 """Determinism soak at scale: the same episode (same seed) played on fresh engines must give bit-identical replay records.
-A data race in a kernel (barriers, LDS-DMA ordering) shows up here as a mismatch.   usage: python tools/soak_determinism.py [games] [sims] [runs]"""
+A data race in a kernel (barriers, LDS-DMA ordering) shows up here as a mismatch.   usage: python tools/soak_determinism.py [games] [sims] [runs]
+Use sims > 225 (e.g. 1024 games x 512 sims): below that the root never becomes fully expanded, every simulation expands a random
+untried root child and the replay does not depend on the net at all."""
 import hashlib
 import os
 import sys
