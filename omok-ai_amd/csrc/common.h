@@ -58,11 +58,15 @@ struct __attribute__((aligned(16))) TreeState {
 struct GameState {
     uint8_t alive;
     uint8_t status;
-    uint8_t pad0, pad1;
-    int32_t plies;
+    uint8_t external; // the pending move (last_action) was supplied by the caller (omok_play_actions), not sampled
+    uint8_t pad1;
+    int32_t plies;       // moves played
     int32_t last_action;
     int32_t mirror_idx;
+    int32_t rp_len;      // transitions recorded = moves SAMPLED so far (turn_counts[index], src/trainer.rs:85,139,148)
+    int32_t pad2[3];
 };
+static_assert(sizeof(GameState) == 32, "GameState must be 32 bytes");
 
 struct Store {
     NodeHdr* hdr;
@@ -92,7 +96,7 @@ struct Store {
 struct RoundArgs {
     int side, round, K, ply;
     float epsilon, alpha;
-    uint64_t seed;
+    uint64_t seed; // Philox key of the current episode: cfg.seed + episode * 0x9E3779B97F4A7C15 (DESIGN.md "RNG contract")
     int64_t game_offset;
 };
 
@@ -110,9 +114,14 @@ void launch_env_play(int n, const int32_t* moves_dev, int batch, int len, int32_
                      uint8_t* turns_dev, uint16_t* legal_dev, hipStream_t st);
 void launch_encode_boards(int n, const uint8_t* boards_dev, const uint8_t* turns_dev, int batch, int mode,
                           float* out_dev, hipStream_t st);
-void launch_replay_pack(int n, const Store& S, uint8_t* dst_dev, long long cap_records, long long* d_total,
-                        hipStream_t st);
-void launch_replay_offsets(int n, const Store& S, long long* offsets_dev /*[games + 1]*/, hipStream_t st);
+void launch_replay_pack(int n, const Store& S, const long long* offsets_dev, uint8_t* dst_dev, long long cap_records, hipStream_t st);
+void launch_replay_offsets(int n, const Store& S, int per_transition, long long* offsets_dev /*[games + 1]*/, hipStream_t st);
+void launch_set_actions(int n, const Store& S, int side, const int32_t* actions_dev, uint32_t* d_flags /*[0] illegal, [1] missing*/, hipStream_t st);
+void launch_clear_actions(const Store& S, hipStream_t st);
+void launch_policy(int n, const Store& S, int side, float* pi_dev /*[G][HW]*/, uint8_t* has_dev /*[G]*/, hipStream_t st);
+void launch_env_place(int n, uint8_t* boards_dev, uint8_t* turns_dev, uint16_t* legal_dev, const int32_t* actions_dev, int batch,
+                      int32_t* status_dev, hipStream_t st);
+int set_advance_lds_attribute(int n, size_t bytes);
 void launch_replay_augment(int n, const Store& S, const long long* offsets_dev, int game_first, int game_count, long long base_sub,
                            uint8_t* dst_dev, long long cap_records, hipStream_t st);
 size_t advance_lds_bytes(int cap_nodes, int cap_tables);

@@ -67,6 +67,7 @@ void orc_replay_postprocess(int n, int len, const uint8_t* boards, const uint8_t
 
 /* ---- RNG contract ---- */
 enum { ORC_RNG_EXPAND = 1, ORC_RNG_NOISE = 2, ORC_RNG_SAMPLE = 3 };
+uint64_t orc_stream_key(uint64_t seed, uint64_t episode); /* seed + episode * 0x9E3779B97F4A7C15: the Philox key of an episode */
 void orc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]);
 double orc_det_log(double x);
 double orc_det_exp(double x);
@@ -87,8 +88,11 @@ void orc_net_forward(const orc_net* net, const float* in, int B, float* p, float
 typedef struct orc_sp orc_sp;
 orc_sp* orc_sp_create(int n, int games, int cap_nodes, int cap_tables, uint64_t seed, int64_t game_offset);
 void orc_sp_destroy(orc_sp* sp);
-/* Agent::new for every tree: root policy = raw evaluate_p on the empty board (agent.rs:16-35) */
+/* Agent::new for every tree: root policy = raw evaluate_p on the empty board (agent.rs:16-35).  Every reset is one
+ * trainer iteration (src/trainer.rs:74-93): it takes the episode counter as its RNG stream and advances it (the first
+ * reset after create is episode 0); orc_sp_set_episode sets the index the NEXT reset will use (resume). */
 void orc_sp_reset(orc_sp* sp, const float* root_policy /*HW*/);
+void orc_sp_set_episode(orc_sp* sp, uint64_t episode);
 int orc_sp_ply(const orc_sp* sp);
 int orc_sp_alive_count(const orc_sp* sp);
 int orc_sp_game_alive(const orc_sp* sp, int game);
@@ -114,6 +118,13 @@ int orc_sp_mirror_generate(orc_sp* sp, float* inputs, int max_req);
  * finished games retire (trainer.rs:156-201). p: [count][HW] from evaluate_p */
 void orc_sp_advance(orc_sp* sp, const float* p);
 
+/* externally chosen moves (gui/src/agent.rs:49-66 style callers): actions[g] for every alive game replaces orc_sp_sample;
+ * the following orc_sp_mirror_generate / orc_sp_advance then run ensure_action_exists + play_action on BOTH agents of the
+ * game (agent.rs:144-232) and record no transition. */
+void orc_sp_set_actions(orc_sp* sp, const int32_t* actions /*G*/);
+/* Agent::compute_policy (agent.rs:43-77) of the side-to-move agent: returns 0 for None */
+int orc_sp_compute_policy(const orc_sp* sp, int game, float* policy /*HW*/);
+
 /* canonical tree dump; side 0 = black agent's tree, 1 = white agent's tree.
  * ints: [n_nodes][8] = parent, action, status, turn, legal, nch, n, order | has_policy<<16
  * floats: [n_nodes][1+HW] = w, effective policy row.  returns n_nodes (or -needed if cap too small) */
@@ -129,6 +140,32 @@ int orc_sp_replay(const orc_sp* sp, int game, uint8_t* boards, uint8_t* turns, f
 int orc_selfplay_run(orc_sp* sp, const orc_net* net, int count, int batch_size, float epsilon,
                      float alpha, float temperature, int threshold, int max_plies, int threads,
                      double* stats);
+
+/* ---- oracle No. 2 (literal.c): the same path restated with the reference's own data structures (pointer nodes that
+ *      store p, explicit placeholder policies and refresh loops, recursive free, the trainer's swap_remove vectors).
+ *      Requests / rows are in the reference's SLOT order; *_games report the game id of each row. ---- */
+typedef struct lit_sp lit_sp;
+lit_sp* lit_create(int n, int games, uint64_t seed, int64_t game_offset);
+void lit_destroy(lit_sp* sp);
+void lit_set_episode(lit_sp* sp, uint64_t episode);
+void lit_reset(lit_sp* sp, const float* root_policy);
+int lit_ply(const lit_sp* sp);
+int lit_error(const lit_sp* sp);
+int lit_alive_count(const lit_sp* sp);
+int lit_game_alive(const lit_sp* sp, int game);
+int lit_game_status(const lit_sp* sp, int game);
+int lit_game_plies(const lit_sp* sp, int game);
+long lit_live_nodes(const lit_sp* sp);
+int lit_round_generate(lit_sp* sp, int round, int batch_size, float epsilon, float alpha, float* inputs, int32_t* req_games, int max_req);
+void lit_round_scatter(lit_sp* sp, const float* p, const float* v);
+void lit_sample(lit_sp* sp, float temperature, int threshold, int32_t* actions /*G, by game id*/);
+void lit_set_actions(lit_sp* sp, const int32_t* actions /*G, by game id*/);
+int lit_mirror_generate(lit_sp* sp, float* inputs, int32_t* row_games, int max_req);
+void lit_advance(lit_sp* sp, const float* p, int external);
+int lit_compute_policy(const lit_sp* sp, int game, float* policy);
+int lit_tree_dump(const lit_sp* sp, int game, int side, int32_t* ints, float* floats, int cap_nodes);
+int lit_tree_priors(const lit_sp* sp, int game, int side, float* p_out, float* parent_policy_at_action, int cap_nodes);
+int lit_replay(const lit_sp* sp, int game, uint8_t* boards, uint8_t* turns, float* pi, float* z, int cap_plies);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,43 @@ def lib():
     L.orc_sp_create.restype = C.c_void_p
     L.orc_sp_destroy.argtypes = [C.c_void_p]
     L.orc_sp_reset.argtypes = [C.c_void_p, fp]
+    L.orc_sp_set_episode.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_sp_set_actions.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.orc_sp_compute_policy.argtypes = [C.c_void_p, C.c_int, fp]
+    L.orc_sp_compute_policy.restype = C.c_int
+    L.orc_stream_key.argtypes = [C.c_uint64, C.c_uint64]
+    L.orc_stream_key.restype = C.c_uint64
+    # oracle No. 2 (literal.c)
+    i32p = C.POINTER(C.c_int32)
+    L.lit_create.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int64]
+    L.lit_create.restype = C.c_void_p
+    L.lit_destroy.argtypes = [C.c_void_p]
+    L.lit_set_episode.argtypes = [C.c_void_p, C.c_uint64]
+    L.lit_reset.argtypes = [C.c_void_p, fp]
+    for name in ("lit_ply", "lit_error", "lit_alive_count"):
+        getattr(L, name).argtypes = [C.c_void_p]
+        getattr(L, name).restype = C.c_int
+    L.lit_live_nodes.argtypes = [C.c_void_p]
+    L.lit_live_nodes.restype = C.c_long
+    for name in ("lit_game_alive", "lit_game_status", "lit_game_plies"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+        getattr(L, name).restype = C.c_int
+    L.lit_round_generate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, fp, i32p, C.c_int]
+    L.lit_round_generate.restype = C.c_int
+    L.lit_round_scatter.argtypes = [C.c_void_p, fp, fp]
+    L.lit_sample.argtypes = [C.c_void_p, C.c_float, C.c_int, i32p]
+    L.lit_set_actions.argtypes = [C.c_void_p, i32p]
+    L.lit_mirror_generate.argtypes = [C.c_void_p, fp, i32p, C.c_int]
+    L.lit_mirror_generate.restype = C.c_int
+    L.lit_advance.argtypes = [C.c_void_p, fp, C.c_int]
+    L.lit_compute_policy.argtypes = [C.c_void_p, C.c_int, fp]
+    L.lit_compute_policy.restype = C.c_int
+    L.lit_tree_dump.argtypes = [C.c_void_p, C.c_int, C.c_int, i32p, fp, C.c_int]
+    L.lit_tree_dump.restype = C.c_int
+    L.lit_tree_priors.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, fp, C.c_int]
+    L.lit_tree_priors.restype = C.c_int
+    L.lit_replay.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), fp, fp, C.c_int]
+    L.lit_replay.restype = C.c_int
     for name in ("orc_sp_ply", "orc_sp_alive_count", "orc_sp_error"):
         getattr(L, name).argtypes = [C.c_void_p]
         getattr(L, name).restype = C.c_int
@@ -181,6 +218,21 @@ class SelfPlay:
         assert rp.size == self.hw
         lib().orc_sp_reset(self.h, _fp(rp))
 
+    def set_episode(self, episode):
+        """index of the RNG stream the NEXT reset uses (every reset = one trainer iteration advances it)"""
+        lib().orc_sp_set_episode(self.h, int(episode))
+
+    def set_actions(self, actions):
+        """externally chosen moves for every alive game: replaces sample(); mirror_generate() / advance() follow"""
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        assert a.size == self.games
+        lib().orc_sp_set_actions(self.h, a.ctypes.data_as(C.POINTER(C.c_int32)))
+
+    def compute_policy(self, game):
+        """Agent::compute_policy of the side-to-move agent (agent.rs:43-77); None like the reference"""
+        pol = np.zeros(self.hw, dtype=np.float32)
+        return pol if lib().orc_sp_compute_policy(self.h, game, _fp(pol)) else None
+
     ply = property(lambda s: lib().orc_sp_ply(s.h))
     alive_count = property(lambda s: lib().orc_sp_alive_count(s.h))
     error = property(lambda s: lib().orc_sp_error(s.h))
@@ -254,6 +306,111 @@ class SelfPlay:
                                      max_plies, threads, stats)
         keys = ("sims", "evals", "ply_games", "finished", "t_net", "t_total")
         return err, dict(zip(keys, list(stats)))
+
+
+class Literal:
+    """Oracle No. 2 (oracle/literal.c): the reference's own data structures (pointer nodes storing p, explicit placeholder
+    policies and refresh loops, recursive free, swap_remove of finished games).  Same driving surface as SelfPlay, but
+    requests / mirror rows come in the reference's SLOT order: round_generate / mirror_generate also return the game id
+    of every row, and round_scatter / advance take rows in that same order."""
+
+    def __init__(self, n, games, seed=0, game_offset=0, cap_nodes=4096):
+        self.n, self.hw, self.games = n, n * n, games
+        self.cap_nodes = cap_nodes  # dump buffer size only: the literal tree has no arena
+        self.h = lib().lit_create(n, games, seed, game_offset)
+        assert self.h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lit_destroy(self.h)
+            self.h = None
+
+    def set_episode(self, episode):
+        lib().lit_set_episode(self.h, int(episode))
+
+    def reset(self, root_policy):
+        rp = np.ascontiguousarray(root_policy, dtype=np.float32).ravel()
+        assert rp.size == self.hw
+        lib().lit_reset(self.h, _fp(rp))
+
+    ply = property(lambda s: lib().lit_ply(s.h))
+    alive_count = property(lambda s: lib().lit_alive_count(s.h))
+    error = property(lambda s: lib().lit_error(s.h))
+    live_nodes = property(lambda s: lib().lit_live_nodes(s.h))
+
+    def game_alive(self, g):
+        return lib().lit_game_alive(self.h, g)
+
+    def game_status(self, g):
+        return lib().lit_game_status(self.h, g)
+
+    def game_plies(self, g):
+        return lib().lit_game_plies(self.h, g)
+
+    def round_generate(self, rnd, batch_size, epsilon, alpha):
+        buf = np.zeros((self.games * batch_size, 3 * self.hw), dtype=np.float32)
+        games = np.zeros(self.games * batch_size, dtype=np.int32)
+        b = lib().lit_round_generate(self.h, rnd, batch_size, epsilon, alpha, _fp(buf), games.ctypes.data_as(C.POINTER(C.c_int32)), buf.shape[0])
+        assert b >= 0
+        return buf[:b], games[:b]
+
+    def round_scatter(self, p, v):
+        p = np.ascontiguousarray(p, dtype=np.float32)
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        lib().lit_round_scatter(self.h, _fp(p), _fp(v))
+
+    def sample(self, temperature, threshold):
+        a = np.zeros(self.games, dtype=np.int32)
+        lib().lit_sample(self.h, temperature, threshold, a.ctypes.data_as(C.POINTER(C.c_int32)))
+        return a
+
+    def set_actions(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        assert a.size == self.games
+        lib().lit_set_actions(self.h, a.ctypes.data_as(C.POINTER(C.c_int32)))
+
+    def mirror_generate(self):
+        buf = np.zeros((self.games, 3 * self.hw), dtype=np.float32)
+        games = np.zeros(self.games, dtype=np.int32)
+        m = lib().lit_mirror_generate(self.h, _fp(buf), games.ctypes.data_as(C.POINTER(C.c_int32)), self.games)
+        assert m >= 0
+        return buf[:m], games[:m]
+
+    def advance(self, p, external=False):
+        p = np.ascontiguousarray(p, dtype=np.float32)
+        lib().lit_advance(self.h, _fp(p), 1 if external else 0)
+
+    def compute_policy(self, game):
+        pol = np.zeros(self.hw, dtype=np.float32)
+        return pol if lib().lit_compute_policy(self.h, game, _fp(pol)) else None
+
+    def tree_dump(self, game, side):
+        ints = np.zeros((self.cap_nodes, 8), dtype=np.int32)
+        floats = np.zeros((self.cap_nodes, 1 + self.hw), dtype=np.float32)
+        n = lib().lit_tree_dump(self.h, game, side, ints.ctypes.data_as(C.POINTER(C.c_int32)), _fp(floats), self.cap_nodes)
+        assert n >= 0, "raise cap_nodes"
+        return ints[:n].copy(), floats[:n].copy()
+
+    def tree_priors(self, game, side):
+        """(child.p as stored, parent.policy[child.action]) per node in dump order: the reference keeps them equal"""
+        a = np.zeros(self.cap_nodes, dtype=np.float32)
+        b = np.zeros(self.cap_nodes, dtype=np.float32)
+        n = lib().lit_tree_priors(self.h, game, side, _fp(a), _fp(b), self.cap_nodes)
+        assert n >= 0
+        return a[:n].copy(), b[:n].copy()
+
+    def replay(self, game):
+        cap = self.hw
+        boards = np.zeros((cap, self.hw), dtype=np.uint8)
+        turns = np.zeros(cap, dtype=np.uint8)
+        pi = np.zeros((cap, self.hw), dtype=np.float32)
+        z = np.zeros(cap, dtype=np.float32)
+        n = lib().lit_replay(self.h, game, boards.ctypes.data_as(C.POINTER(C.c_uint8)), turns.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(pi), _fp(z), cap)
+        return boards[:n], turns[:n], pi[:n], z[:n]
+
+
+def stream_key(seed, episode):
+    return int(lib().orc_stream_key(int(seed), int(episode)))
 
 
 def replay_postprocess(n, boards, turns, pi, z):

@@ -5,7 +5,9 @@
  * so it is not reproducible; "fixed seeds" therefore means the stream defined here, consumed
  * identically by this oracle and by the HIP kernels:
  *
- *   Philox4x32-10, key = (seed & 0xffffffff, seed >> 32),
+ *   Philox4x32-10, key = seed + episode * 0x9E3779B97F4A7C15 (mod 2^64; orc_stream_key) split into (low, high) words:
+ *   the reference draws fresh thread_rng values in every trainer iteration (src/trainer.rs:74-93), so every
+ *   reset (= iteration) of a self-play object advances `episode` and with it the whole stream,
  *   counter = (c0 = draw index, c1 = ply, c2 = tree_global = 2*game_global + side, c3 = purpose)
  *     purpose 1 EXPAND: c0 = simulation index inside the execute() call (round*K + i)
  *             -> untried-action index = mulhi(out[0], |A|)
@@ -17,6 +19,8 @@
  */
 #include "omok_oracle.h"
 #include <string.h>
+
+uint64_t orc_stream_key(uint64_t seed, uint64_t episode) { return seed + episode * 0x9E3779B97F4A7C15ULL; }
 
 void orc_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);

@@ -66,10 +66,11 @@ typedef struct {
 
 struct orc_sp {
     int n, hw, games, cap_nodes, cap_tables;
-    uint64_t seed;
+    uint64_t seed, episode, key; /* key = orc_stream_key(seed, episode of the current reset) */
     int64_t game_offset;
     int ply;
     int error;
+    int external; /* the pending moves came from orc_sp_set_actions */
     tree_t* trees[2];
     orc_env* envs;
     uint8_t* alive;
@@ -179,7 +180,7 @@ static void apply_noise(orc_sp* sp, tree_t* t, float epsilon, float alpha, uint3
     }
     float total = 0.0f;
     for (int a = 0; a < hw; ++a) {
-        noise[a] = orc_gamma(alpha, sp->seed, (uint32_t)a, (uint32_t)sp->ply, tree_global);
+        noise[a] = orc_gamma(alpha, sp->key, (uint32_t)a, (uint32_t)sp->ply, tree_global);
         total += noise[a];
     }
     if (total > 0.0f) {
@@ -238,7 +239,7 @@ static void run_sim(orc_sp* sp, tree_t* t, int game, uint32_t sim_index, uint32_
         if (leaf->board[a] == ORC_EMPTY && !(ltb && ltb->corder[a] != NONE8)) avail[n_avail++] = a;
     if (n_avail == 0) return;
     uint32_t o[4];
-    orc_philox(sp->seed, sim_index, (uint32_t)sp->ply, tree_global, ORC_RNG_EXPAND, o);
+    orc_philox(sp->key, sim_index, (uint32_t)sp->ply, tree_global, ORC_RNG_EXPAND, o);
     const int action = avail[(uint32_t)(((uint64_t)o[0] * (uint64_t)n_avail) >> 32)];
     /* pme.rs:128-135 */
     orc_env env;
@@ -393,7 +394,12 @@ void orc_sp_destroy(orc_sp* sp) {
     free(sp);
 }
 
+void orc_sp_set_episode(orc_sp* sp, uint64_t episode) { sp->episode = episode; }
+
 void orc_sp_reset(orc_sp* sp, const float* root_policy) {
+    sp->key = orc_stream_key(sp->seed, sp->episode);
+    sp->episode += 1;
+    sp->external = 0;
     sp->ply = 0;
     sp->error = 0;
     sp->n_req = 0;
@@ -479,6 +485,7 @@ void orc_sp_round_scatter(orc_sp* sp, const float* p, const float* v) {
 /* agent.rs:43-137 + trainer.rs:138-173 (record) */
 void orc_sp_sample(orc_sp* sp, float temperature, int threshold, int32_t* actions) {
     const int side = sp->ply & 1, hw = sp->hw;
+    sp->external = 0;
     for (int g = 0; g < sp->games; ++g) {
         actions[g] = -1;
         sp->last_action[g] = -1;
@@ -496,7 +503,7 @@ void orc_sp_sample(orc_sp* sp, float temperature, int threshold, int32_t* action
         const float sum_inv = 1.0f / sum;
         for (int a = 0; a < hw; ++a) policy[a] *= sum_inv;
         int action = 0;
-        if (sp->plies[g] < threshold) { /* Boltzmann, agent.rs:106-133 */
+        if (sp->replay[g].plies < threshold) { /* turn_counts[index] (trainer.rs:139): moves SAMPLED so far; Boltzmann, agent.rs:106-133 */
             float heated[ORC_MAX_HW];
             float hsum = 0.0f;
             const float tinv = 1.0f / temperature;
@@ -511,7 +518,7 @@ void orc_sp_sample(orc_sp* sp, float temperature, int threshold, int32_t* action
             float total = 0.0f;
             for (int a = 0; a < hw; ++a) total += heated[a];
             uint32_t o[4];
-            orc_philox(sp->seed, 0, (uint32_t)sp->ply, (uint32_t)((sp->game_offset + g) * 2 + side), ORC_RNG_SAMPLE, o);
+            orc_philox(sp->key, 0, (uint32_t)sp->ply, (uint32_t)((sp->game_offset + g) * 2 + side), ORC_RNG_SAMPLE, o);
             const float u = (float)(o[0] >> 8) * 5.9604644775390625e-8f; /* 2^-24 */
             const float target = u * total;
             float cum = 0.0f;
@@ -542,6 +549,27 @@ void orc_sp_sample(orc_sp* sp, float temperature, int threshold, int32_t* action
     }
 }
 
+void orc_sp_set_actions(orc_sp* sp, const int32_t* actions) {
+    sp->external = 1;
+    for (int g = 0; g < sp->games; ++g) sp->last_action[g] = sp->alive[g] ? actions[g] : -1;
+}
+
+int orc_sp_compute_policy(const orc_sp* sp, int game, float* policy) { /* agent.rs:43-77 */
+    const tree_t* t = &sp->trees[sp->ply & 1][game];
+    const node_t* root = &t->nodes[0];
+    const int hw = sp->hw;
+    for (int a = 0; a < hw; ++a) policy[a] = 0.0f;
+    if (!sp->alive[game] || root->table == NONE16 || root->nch == 0) return 0;
+    const table_t* tb = &t->tables[root->table];
+    float sum = 0.0f;
+    for (int a = 0; a < hw; ++a)
+        if (tb->corder[a] != NONE8) { policy[a] = (float)tb->cn[a]; sum += policy[a]; }
+    if (sum < ORC_EPS) return 0;
+    const float sum_inv = 1.0f / sum;
+    for (int a = 0; a < hw; ++a) policy[a] *= sum_inv;
+    return 1;
+}
+
 int orc_sp_mirror_generate(orc_sp* sp, float* inputs, int max_req) {
     int cnt = 0;
     for (int g = 0; g < sp->games; ++g) {
@@ -564,6 +592,7 @@ void orc_sp_advance(orc_sp* sp, const float* p) {
         tree_t* own = &sp->trees[side][g];
         tree_t* opp = &sp->trees[1 - side][g];
         const orc_env before = sp->envs[g];
+        if (sp->external) ensure_action_exists(sp, own, &before, action, p + (size_t)cnt * (size_t)hw); /* an external move need not be in the tree */
         /* agent.play_action (agent.rs:206-232) */
         if (own->nodes[0].status != ORC_IN_PROGRESS) { sp->error = 5; }
         const int status = orc_env_place_stone(&sp->envs[g], action);
@@ -573,7 +602,7 @@ void orc_sp_advance(orc_sp* sp, const float* p) {
         if (tree_transition(sp, opp, action) != 0) sp->error = 6;
         ++cnt;
         replay_t* rp = &sp->replay[g];
-        if (rp->plies < hw) {
+        if (!sp->external && rp->plies < hw) { /* transitions.push (trainer.rs:169-173): sampled moves only */
             rp->z[rp->plies] = (status == ORC_BLACK_WIN || status == ORC_WHITE_WIN) ? 1.0f : 0.0f;
             rp->plies++;
         }
@@ -582,6 +611,7 @@ void orc_sp_advance(orc_sp* sp, const float* p) {
         if (status != ORC_IN_PROGRESS) sp->alive[g] = 0;
         sp->last_action[g] = -1;
     }
+    sp->external = 0;
     sp->ply += 1;
 }
 

@@ -14,6 +14,7 @@ import pytest
 import omok_ai_amd as oa
 from omok_ai_amd import binding as B
 from oracle import oracle as O
+from helpers import draw_sequence, tree_shape
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -59,8 +60,10 @@ def test_rules_match_oracle_on_random_games(eng_env):
     n, hw = eng_env.n, eng_env.hw
     rng = np.random.default_rng(5)
     moves = np.stack([rng.permutation(hw) for _ in range(64)]).astype(np.int32)
-    moves[:, 7] = moves[:, 3]  # an occupied cell -> None
+    moves[::2, 7] = moves[::2, 3]  # an occupied cell -> None (these rows can never fill the board)
+    moves[1] = draw_sequence(n)    # a full board without an exact five: the last move is GameStatus::Draw
     st, boards, turns, legal = eng_env.env_play(moves)
+    assert st[1, -1] == oa.api.DRAW and np.all(st[1, :-1] == oa.api.IN_PROGRESS) and legal[1] == 0
     for b in range(moves.shape[0]):
         env = O.Environment(n)
         for i, m in enumerate(moves[b]):
@@ -182,36 +185,42 @@ def _compare_trees(sp, osp, games, tag):
             assert np.float32(sp.tree_root(g, side)[1]).tobytes() == np.float32(osp.tree_root(g, side)[1]).tobytes()
 
 
-@pytest.mark.parametrize("n,games,count,k,max_plies,mode", [
-    (9, 6, 48, 8, 0, B.NET_F16X3),     # whole games to the end on the reference's board size
-    (9, 3, 40, 16, 12, B.NET_F32),     # count not a multiple of K (rounds up), fp32 net path
-    (15, 3, 64, 16, 6, B.NET_F16X3),   # the benchmark board
-])
-def test_selfplay_bit_exact_vs_oracle(n, games, count, k, max_plies, mode):
-    tensors = oa.weights.init_random(n, seed=0)
-    eng = oa.Engine(board_size=n, games=games, max_nodes=2048, max_tables=1024, max_batch_k=k, seed=7, game_offset=5,
-                    net_mode=mode)
+def _drive_selfplay_vs_oracle(n, games, count, k, max_plies, mode, threshold=6, max_nodes=2048, max_tables=1024, seed=7,
+                              game_offset=5, weight_seed=0):
+    """Plays `games` games step by step on the engine and on the oracle (the oracle consumes the GPU net's p / v, so the
+    comparison isolates the tree arithmetic) and compares canonical tree dumps, request boards, moves and replay tuples bit
+    for bit.  Returns the shape of the deepest search seen by the ORACLE: (fully expanded nodes, fully expanded non-root
+    nodes, max depth, max tables) so that a test can prove it left the shallow root-plus-one-layer regime."""
+    tensors = oa.weights.init_random(n, seed=weight_seed)
+    eng = oa.Engine(board_size=n, games=games, max_nodes=max_nodes, max_tables=max_tables, max_batch_k=k, seed=seed,
+                    game_offset=game_offset, net_mode=mode)
     eng.load_weights(tensors)
     sp = oa.SelfPlay(eng)
     sp.reset()
     root_p = eng.evaluate_p(O.Environment(n).encode_nn_input(0)[None]).reshape(-1)
-    osp = O.SelfPlay(n, games, cap_nodes=2048, cap_tables=1024, seed=7, game_offset=5)
+    osp = O.SelfPlay(n, games, cap_nodes=max_nodes, cap_tables=max_tables, seed=seed, game_offset=game_offset)
     osp.reset(root_p)
     _compare_trees(sp, osp, games, "reset")
-    threshold = 6
+    shape = [0, 0, 0, 0]
     ply = 0
+    rounds = (count + k - 1) // k
     while osp.alive_count > 0 and (max_plies == 0 or ply < max_plies):
-        for rnd in range((count + k - 1) // k):
+        for rnd in range(rounds):
             nreq = sp.round_generate(rnd, k, 0.25, 0.03)
             oin = osp.round_generate(rnd, k, 0.25, 0.03)
             assert nreq == len(oin), f"ply {ply} round {rnd}: request count"
             assert np.array_equal(sp.round_inputs(), oin), f"ply {ply} round {rnd}: request boards"
-            if rnd == 0:
-                _compare_trees(sp, osp, games, f"ply {ply} after noise+round0")
+            if rnd == 0 or (rounds > 20 and rnd % 16 == 15):  # pending children of the round are in the dump as well
+                _compare_trees(sp, osp, games, f"ply {ply} after generate of round {rnd}")
             p, v = sp.round_eval()
             sp.round_scatter()
             osp.round_scatter(p, v)
         _compare_trees(sp, osp, games, f"ply {ply} after execute")
+        assert osp.error == 0
+        for g in range(games):
+            if osp.game_alive(g):
+                full, full_nr, depth = tree_shape(osp.tree_dump(g, ply & 1)[0])
+                shape = [max(shape[0], full), max(shape[1], full_nr), max(shape[2], depth), max(shape[3], osp.tree_root(g, ply & 1)[3])]
         a = sp.sample_actions(1.0, threshold)
         assert np.array_equal(a, osp.sample(1.0, threshold)), f"ply {ply}: actions"
         nm = sp.mirror_generate()
@@ -232,6 +241,40 @@ def test_selfplay_bit_exact_vs_oracle(n, games, count, k, max_plies, mode):
         assert np.array_equal(gb, ob) and np.array_equal(gt, ot) and np.array_equal(gz, oz)
         assert np.array_equal(gp.view(np.uint32), op.view(np.uint32))
     eng.close()
+    return tuple(shape)
+
+
+@pytest.mark.parametrize("n,games,count,k,max_plies,mode", [
+    (9, 6, 48, 8, 0, B.NET_F16X3),     # whole games to the end on the reference's board size
+    (9, 3, 40, 16, 12, B.NET_F32),     # count not a multiple of K (rounds up), fp32 net path
+    (15, 3, 64, 16, 6, B.NET_F16X3),   # the benchmark board, shallow
+])
+def test_selfplay_bit_exact_vs_oracle(n, games, count, k, max_plies, mode):
+    _drive_selfplay_vs_oracle(n, games, count, k, max_plies, mode)
+
+
+# The regime the headline number is measured in (BASELINE.json configs): 800 / 1600 simulations per move at N = 15 reach
+# fully expanded nodes (the 225-wide PUCT scan of k_round<15>, IT = 4), depth >= 3 (deep backup), several child tables
+# (multi-table transition<15>) and the select-leaf memo.  The asserts on the oracle's tree shape make sure these tests
+# cannot silently fall back to the root-plus-one-layer regime of the small configs above.
+@pytest.mark.parametrize("n,games,count,k,max_plies,min_full,min_full_nonroot,min_depth,min_tables", [
+    (15, 2, 800, 16, 4, 1, 1, 3, 3),    # configs[1]/[3] per-tree workload (C2/C4): first 4 plies
+    (15, 1, 1600, 16, 2, 1, 1, 3, 3),   # configs[4] (C5): 1600 simulations per move
+    (9, 4, 200, 8, 0, 1, 1, 3, 3),      # configs[2] (C3): 9x9, 200 simulations, K = 8, whole games
+])
+def test_selfplay_bit_exact_benchmark_regime(n, games, count, k, max_plies, min_full, min_full_nonroot, min_depth, min_tables):
+    cap = min(16384, 4 * count + 1024)
+    full, full_nr, depth, tables = _drive_selfplay_vs_oracle(n, games, count, k, max_plies, B.NET_F16X3, threshold=30,
+                                                              max_nodes=cap, max_tables=max(256, cap // 4))
+    print(f"oracle tree shape: {full} fully expanded nodes ({full_nr} non-root), depth {depth}, {tables} tables")
+    assert full >= min_full and full_nr >= min_full_nonroot and depth >= min_depth and tables >= min_tables
+
+
+def test_selfplay_single_game_c1_whole_game():
+    """BASELINE.json configs[0] on the engine: ONE 15x15 game, 100 simulations per move (-> 112 with K = 16), the
+    reference's mode rule (Boltzmann for 30 plies, then Best), played to the end and compared with the oracle at every
+    step (games = 1: grid of one wave, every scan / compaction kernel at its smallest size)."""
+    _drive_selfplay_vs_oracle(15, 1, 100, 16, 0, B.NET_F16X3, threshold=30, max_nodes=4096, max_tables=1024, seed=0, game_offset=0)
 
 
 def test_execute_matches_stepwise_and_is_deterministic():
