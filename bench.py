@@ -1,41 +1,52 @@
 #!/usr/bin/env python3
 """bench.py — self-play throughput of the MI355X engine on BASELINE.json's metric.
 
-A "step" is ONE self-play episode: `games` concurrent 15x15 games per GPU, two agents (trees) per
-game, `sims` PUCT simulations per move in rounds of K with one batched net forward per round,
-random-init net (seed 0), played until every game has ended (src/trainer.rs:95-205).
-`value` = completed games / second over the timed steps, whole job (all ranks).
+A "step" is ONE self-play episode: `games` concurrent 15x15 games per GPU, two agents (trees) per game, `sims` PUCT
+simulations per move in rounds of K with one batched net forward per round, random-init net (seed 0), played until every
+game has ended (src/trainer.rs:95-205).  Every step runs on its own RNG stream (one reset = one trainer iteration).
+`value` = completed games / second over the timed steps, whole job (all ranks).  Warm-up steps are episodes cut after
+--warmup-plies plies (untimed: they warm clocks, code objects and allocations; the timed steps are whole episodes).
 
-Default workload = BASELINE.json configs[1]: 4096 concurrent 15x15 games, 800 sims/move, K=16.
-Multi-GPU (configs[3]): one process per GPU (torchrun), games sharded by global id
-(game_offset = rank * games), no collective on the hot path; --gather adds the optional RCCL
-all-gather of (s, pi, z) replay tuples at episode end (configs[4]).
+Default workload = BASELINE.json configs[1]: 4096 concurrent 15x15 games, 800 sims/move, K = 16.
+Multi-GPU (configs[3]): one process per GPU, games sharded by global id (game_offset = rank * games), no collective on the
+hot path; --gather adds the RCCL all-gather-v of (s, pi, z) replay tuples at episode end (configs[4]).  `python bench.py
+--gpus N` starts its N ranks by itself (torch.distributed.run as a child process, before the parent touches the GPU);
+started under torchrun it uses the environment it finds.
+
+Output: rank 0 prints the result line as soon as the timed region ends (flush), and -- if the extra legs ran -- the same
+line again enriched with `cpu_baseline`, `precision`, `replay_postprocess`, `train_phase`.  The LAST line is the complete
+one; the first one exists so that a run killed at its time limit still leaves a measured line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
+T_PROCESS_START = time.perf_counter()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 F16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16/f16 MFMA dense
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
-# HBM bytes per fc0 row from the committed rocprofv3 --pmc passes (profiles/README.md, B = 65536): FETCH_SIZE raw x 2
-# (gfx950 correction for 128-B requests) minus the residual part that is fetched in exact 64-B requests, plus WRITE_SIZE.
-FC0_HBM_BYTES_PER_ROW = {15: (3.873e6 * 1024 * 2 - 65536 * 28800.0 + 1.347e5 * 1024) / 65536}
+# HBM bytes per net row from the committed rocprofv3 --pmc passes (profiles/README.md): (FETCH_SIZE x 2 [gfx950 128-B
+# request correction] + WRITE_SIZE) KiB / rows of the profiled launch.  {board: {kernel: bytes per row}}
+PMC_HBM_BYTES_PER_ROW = {15: {"k_trunk": None, "k_fc0_mx": (3.873e6 * 1024 * 2 - 65536 * 28800.0 + 1.347e5 * 1024) / 65536}}
+try:  # refreshed by tools/collect_profiles.sh -> profiles/pmc_bytes.json (per-row / per-sim HBM bytes with the guide's corrections)
+    with open(os.path.join(ROOT, "profiles", "pmc_bytes.json")) as _f:
+        PMC_FILE = json.load(_f)
+except Exception:
+    PMC_FILE = {}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--warmup-plies", type=int, default=4, help="plies of a warm-up step (0 = whole episodes)")
     ap.add_argument("--board", type=int, default=15)
     ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=800)
@@ -44,114 +55,263 @@ def parse():
     ap.add_argument("--max-nodes", type=int, default=0)
     ap.add_argument("--max-tables", type=int, default=0)
     ap.add_argument("--net-mode", default="f16x3", choices=["f16x3", "f32"])
-    ap.add_argument("--gather", action="store_true", help="RCCL all-gather of replay tuples at episode end")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--gather", action="store_true", help="RCCL all-gather-v of replay tuples at episode end")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=20, help="training steps timed after the episode (0 = skip; batch 128)")
+    ap.add_argument("--precision-rows", type=int, default=4096, help="rows of the in-run precision check (0 = skip)")
+    ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("OMOK_BENCH_BUDGET_S", "540")),
+                    help="wall-clock budget of the whole process: the extra legs only run while there is room")
     ap.add_argument("--seed", type=int, default=0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(args, mean_plies):
-    """The oracle (CPU restatement, kind 'port') timed on this host on a bounded sample of the same
-    workload: G games x `sims` sims x a few plies, all host cores (OpenMP over net batches)."""
+def elapsed():
+    return time.perf_counter() - T_PROCESS_START
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a torchrun environment
+# ------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """Start N ranks as a CHILD process (torch.distributed.run) and relay its exit code.  Nothing in this process has
+    touched the GPU yet (torch.cuda.device_count() does not initialise it on this image)."""
+    import torch
+    backend = os.environ.get("OMOK_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count() if backend == "nccl" else args.gpus
+    if have < args.gpus:
+        msg = f"--gpus {args.gpus}: {args.gpus} GPUs needed, {have} visible on this host; nothing was run"
+        print(json.dumps({"error": msg, "n_gpus": args.gpus, "gpus_visible": have, "value": None}), flush=True)
+        print(msg, file=sys.stderr)
+        return 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# extra legs (outside the timed region, rank 0 of a 1-GPU run only)
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(args, mean_plies, budget_s):
+    """the CPU restatement of the reference path on this host's cores: oracle tree code (C) + a BLAS-backed fp32
+    forward (torch-CPU on the graph of omok-ai_amd/train.py), kind "port".  Workloads: C1 exactly (one 15x15 game, 100
+    sims/move -> 112 with K = 16, played to the end or to the leg's time share) and C2' (64 games, 800 sims/move, first
+    plies), each at ALL threads and at 1 thread, every leg bounded by its share of `budget_s`."""
+    import numpy as np
+    import torch
     from oracle import oracle as O
     import omok_ai_amd as oa
+    from omok_ai_amd import train as T
+    n, k = args.board, args.batch_k
+    hw = n * n
     cores = os.cpu_count() or 1
-    n = args.board
     tensors = oa.weights.init_random(n, seed=0)
-    net = O.Net(n, tensors)
-    root_p, _ = net.forward(O.Environment(n).encode_nn_input(0)[None])
-    games = max(1, cores // 2)
-    # calibrate: one round of K sims
-    sp = O.SelfPlay(n, games, cap_nodes=max(2048, args.sims * 2 + 64), cap_tables=1024, seed=args.seed)
-    sp.reset(root_p[0])
-    t0 = time.perf_counter()
-    err, st = sp.run(net, args.batch_k, args.batch_k, max_plies=1, threads=cores)
-    t_round = max(time.perf_counter() - t0, 1e-3)
-    rounds_per_ply = (args.sims + args.batch_k - 1) // args.batch_k
-    plies = int(max(1, min(4, args.cpu_seconds / (t_round * rounds_per_ply))))
-    sims = args.sims
-    if t_round * rounds_per_ply > 1.5 * args.cpu_seconds:  # even one ply is over budget: scale sims down, say so
-        sims = max(args.batch_k, int(args.sims * args.cpu_seconds / (t_round * rounds_per_ply)) // args.batch_k * args.batch_k)
-    sp = O.SelfPlay(n, games, cap_nodes=max(2048, args.sims * 2 + 64), cap_tables=1024, seed=args.seed)
-    sp.reset(root_p[0])
-    t0 = time.perf_counter()
-    err, st = sp.run(net, sims, args.batch_k, max_plies=plies, threads=cores)
-    dt = time.perf_counter() - t0
-    assert err == 0
-    sims_per_s = st["sims"] / dt
-    games_per_s = sims_per_s / (args.sims * mean_plies)
-    return {
-        "value": games_per_s, "unit": "games/s", "cores": cores, "kind": "port",
-        "sample": f"{games} games x {plies} plies x {sims} sims/move (K={args.batch_k}), {n}x{n}, oracle C restatement "
-                  f"with OpenMP net; {sims_per_s:.1f} sims/s measured, converted with {mean_plies:.1f} plies/game from the GPU run",
-        "sims_per_s": sims_per_s, "seconds": dt, "net_seconds": st["t_net"],
+    net = T.Network(n, tensors, "cpu", allow_cpu=True)
+
+    def forward(x):
+        with torch.no_grad():
+            p, v = net(torch.from_numpy(np.ascontiguousarray(x)).reshape(-1, n, n, 3))
+        return p.numpy().reshape(len(x), hw), v.numpy().reshape(-1)
+
+    def leg(games, sims, threads, seconds, max_plies):
+        torch.set_num_threads(threads)
+        root_p, _ = forward(O.Environment(n).encode_nn_input(0)[None])
+        sp = O.SelfPlay(n, games, cap_nodes=min(16384, 4 * sims + 1024), cap_tables=max(256, sims + 256), seed=args.seed)
+        sp.reset(root_p[0])
+        rounds = (sims + k - 1) // k
+        t0 = time.perf_counter()
+        t_net = 0.0
+        n_sims = n_evals = 0
+        plies = 0
+        out_of_time = False
+        while sp.alive_count > 0 and plies < max_plies and not out_of_time:
+            for rnd in range(rounds):
+                inp = sp.round_generate(rnd, k, 0.25, 0.03)
+                n_sims += k * sp.alive_count
+                if len(inp):
+                    t1 = time.perf_counter()
+                    p, v = forward(inp)
+                    t_net += time.perf_counter() - t1
+                    n_evals += len(inp)
+                    sp.round_scatter(p, v)
+                if time.perf_counter() - t0 > seconds:
+                    out_of_time = True
+                    break
+            if out_of_time:
+                break
+            sp.sample(1.0, 30)
+            m = sp.mirror_generate()
+            t1 = time.perf_counter()
+            p, _ = forward(m)
+            t_net += time.perf_counter() - t1
+            n_evals += len(m)
+            sp.advance(p)
+            plies += 1
+        dt = time.perf_counter() - t0
+        return {"games": games, "sims_per_move": rounds * k, "threads": threads, "seconds": dt, "plies_completed": plies,
+                "sims": n_sims, "sims_per_s": n_sims / dt, "nn_evals_per_s": n_evals / dt, "net_seconds": t_net,
+                "tree_seconds": dt - t_net, "finished": sp.alive_count == 0}
+
+    share = budget_s / 4.0
+    legs = {
+        "c1_all_threads": leg(1, 100, cores, share, 10 ** 6),
+        "c1_one_thread": leg(1, 100, 1, share, 10 ** 6),
+        "c2p_all_threads": leg(64, args.sims, cores, share, 5),
+        "c2p_one_thread": leg(64, args.sims, 1, share, 5),
     }
+    torch.set_num_threads(cores)
+    best = legs["c2p_all_threads"]
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    rounds_up = (args.sims + k - 1) // k * k
+    return {"value": best["sims_per_s"] / (rounds_up * mean_plies), "unit": "games/s", "cores": cores, "kind": "port",
+            "sample": f"C2' = 64 games x {rounds_up} sims/move x up to 5 plies (bounded to {share:.0f} s) on {cores} threads: oracle C tree "
+                      f"code + torch-CPU fp32 forward (BLAS); {best['sims_per_s']:.0f} sims/s, converted with {mean_plies:.1f} plies/game "
+                      f"from the GPU run.  Also C1 (1 game, 100->112 sims/move, whole game or {share:.0f} s) and both again on 1 thread: see legs",
+            "cpu_model": model, "sims_per_s": best["sims_per_s"],
+            "one_thread_value": legs["c2p_one_thread"]["sims_per_s"] / (rounds_up * mean_plies),
+            "c1_games_per_s": {kk: (1.0 / v["seconds"] if v["finished"] else v["sims_per_s"] / (112 * mean_plies)) for kk, v in legs.items() if kk.startswith("c1")},
+            "legs": legs}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs torchrun --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
+def precision_check(args, rows, device):
+    """Precision evidence inside the run: `rows` request rows of real self-play rounds (positions 6 and 14 plies into games
+    of this net), evaluated by the product path (f16 split operands, fp6 corrections) and by the OMOK_NET_F32 kernels on the
+    same GPU.  Reports the outputs the reference API returns (p after softmax, v after tanh: the 1e-3 contract) and the
+    quantities in front of the last ops (logits, pre-tanh value)."""
+    import numpy as np
     import omok_ai_amd as oa
     from omok_ai_amd import binding as B
+    n, k = args.board, args.batch_k
+    games = max(8, rows // (2 * k))
+    eng = oa.Engine(board_size=n, games=games, max_nodes=2048, max_tables=512, max_batch_k=k, device=device, seed=args.seed + 1)
+    eng.load_random_weights(0)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    xs = []
+    for stop in (6, 14):
+        sp.run(64, k, 0.25, 0.03, 1.0, 30, stop - sp.ply)
+        if sp.alive_count == 0:
+            break
+        sp.round_generate(0, k)
+        xs.append(sp.round_inputs())
+        sp.round_eval()
+        sp.round_scatter()
+        for rnd in range(1, 4):
+            sp.round_generate(rnd, k)
+            sp.round_eval()
+            sp.round_scatter()
+        sp.sample_actions(1.0, 30)
+        sp.advance()
+    x = np.concatenate(xs)[:rows]
+    p, v = eng.evaluate_pv(x)
+    lg, vp = eng.evaluate_logits(x)
+    eng.close()
+    ref = oa.Engine(board_size=n, games=64, max_nodes=8, max_tables=4, max_batch_k=k, device=device, net_mode=B.NET_F32)
+    ref.load_random_weights(0)
+    p32, v32 = ref.evaluate_pv(x)
+    lg32, vp32 = ref.evaluate_logits(x)
+    ref.close()
+    return {"rows": int(len(x)), "reference": "OMOK_NET_F32 kernels on the same GPU (fp32 VALU, k-ascending sums)",
+            "max_dp": float(np.abs(p - p32).max()), "max_dv": float(np.abs(v - v32).max()),
+            "max_dlogit": float(np.abs(lg - lg32).max()), "max_dvpre": float(np.abs(vp - vp32).max()),
+            "logit_abs_max": float(np.abs(lg32).max()), "logit_std": float(lg32.std()),
+            "contract": "1e-3 on the outputs of AgentModel::evaluate_pv (p after softmax, v after tanh)"}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0 and args.gpus > 1:
+        sys.exit(self_launch(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = max(world, 1)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: using the launcher's world size", file=sys.stderr)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    backend = os.environ.get("OMOK_BENCH_BACKEND", "nccl")
+    use_cuda = backend == "nccl"
+    device = f"cuda:{local_rank}" if use_cuda else "cpu"
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
+    if world > 1:
+        if use_cuda:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+
+    import importlib
+    oa = importlib.import_module(os.environ.get("OMOK_BENCH_ENGINE", "omok_ai_amd"))  # (tests substitute a GPU-free stand-in)
+    B = oa.binding
 
     n, games, k = args.board, args.games, args.batch_k
     max_nodes = args.max_nodes or min(16384, 4 * args.sims + 1024)
     max_tables = args.max_tables or max(256, max_nodes // 4)
     eng = oa.Engine(board_size=n, games=games, max_nodes=max_nodes, max_tables=max_tables, max_batch_k=k,
                     device=local_rank, net_mode=B.NET_F16X3 if args.net_mode == "f16x3" else B.NET_F32,
-                    seed=args.seed, game_offset=rank * games)
+                    seed=args.seed, game_offset=oa.dist.game_offset(rank, games))
     eng.load_random_weights(0)
     sp = oa.SelfPlay(eng)
     eng.set_profiling(True)
 
     def barrier():
-        torch.cuda.synchronize()
+        if use_cuda:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if use_cuda:
+            torch.cuda.synchronize()
 
-    gather_buf = None
-    if args.gather:
-        rec = sp.replay_record_bytes()
-        cap = games * n * n
-        gather_buf = torch.empty(cap * rec, dtype=torch.uint8, device=f"cuda:{local_rank}")
+    rec = sp.replay_record_bytes()
+    gather_buf = torch.empty(games * n * n * rec, dtype=torch.uint8, device=device) if args.gather else None
+    gathered = {"records": 0, "bytes": 0, "seconds": 0.0}
 
-    def episode():
+    def episode(max_plies):
         sp.reset()
-        st = sp.run(args.sims, k, 0.25, 0.03, 1.0, 30, args.max_plies)
+        st = sp.run(args.sims, k, 0.25, 0.03, 1.0, 30, max_plies)
         if args.gather:
-            cnt = sp.replay_pack_into(gather_buf.data_ptr(), gather_buf.numel() // sp.replay_record_bytes())
-            if world > 1:
-                counts = [torch.zeros(1, dtype=torch.int64, device=gather_buf.device) for _ in range(world)]
-                dist.all_gather(counts, torch.tensor([cnt], dtype=torch.int64, device=gather_buf.device))
-                bufs = [torch.empty_like(gather_buf) for _ in range(world)]
-                dist.all_gather(bufs, gather_buf)  # fixed-capacity slabs; counts say how much of each is live
+            t1 = time.perf_counter()
+            cnt = sp.replay_pack_into(gather_buf.data_ptr(), gather_buf.numel() // rec)
+            live = gather_buf[: cnt * rec].view(cnt, rec)
+            allrec, counts = oa.dist.gather_replay(live)  # counts exchange + exact-size all-gather-v
+            if use_cuda:
+                torch.cuda.synchronize()
+            gathered["records"] += int(allrec.shape[0])
+            gathered["bytes"] += int(allrec.numel())
+            gathered["seconds"] += time.perf_counter() - t1
         return st
 
     for _ in range(args.warmup):
-        episode()
+        episode(args.warmup_plies if args.max_plies == 0 else min(args.warmup_plies or args.max_plies, args.max_plies))
     eng.reset_stats()
+    for key in gathered:
+        gathered[key] = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        episode()
+        episode(args.max_plies)
     barrier()
     dt = time.perf_counter() - t0
     st = eng.stats()
     alive, status, plies = sp.game_info()
 
-    t = torch.tensor([dt, st["finished"], st["sims"], st["evals"], st["ply_games"]], dtype=torch.float64,
-                     device=f"cuda:{local_rank}")
+    t = torch.tensor([dt, st["finished"], st["sims"], st["evals"], st["ply_games"]], dtype=torch.float64, device=device)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -160,96 +320,140 @@ def main():
     finished, sims, evals, ply_games = (float(x) for x in t[1:])
     if rank != 0:
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
     hw = n * n
     flop_eval = 2.0 * (3 * 128 * hw + 3 * hw * (128 * 32 + 9 * 32 + 32 * 32 + 32 * 128) + 128 * hw * 512 + 512 * 512 + 512 + 512 * hw)
     flop_fc0 = 2.0 * 128 * hw * 512
+    flop_tail = 2.0 * (512 * 512 + 512 + 512 * hw)
+    flop_trunk = flop_eval - flop_fc0 - flop_tail
     complete = args.max_plies == 0
     mean_plies = ply_games / max(finished, 1.0) if complete else float(plies.mean())
     games_per_s = finished / dt if complete else (ply_games / max(mean_plies, 1.0)) / dt
-    # dominant kernel = fc0 GEMM (68 % of the net's MACs): algorithmic flops / HIP-event time (rank 0)
-    fc0_s = st["ms_fc0"] * 1e-3
-    fc0_tflops = st["fc0_rows"] * flop_fc0 / fc0_s / 1e12 if fc0_s > 0 else 0.0
+    rows = st["fc0_rows"]                       # net rows evaluated on rank 0 in the timed region
+    launches = max(st["fc0_launches"], 1.0)     # one trunk + one fc0 launch per forward
+    k_ms = {"k_trunk": st["ms_trunk"], "k_fc0_mx": st["ms_fc0"], "tail (fc1, heads, softmax)": st["ms_tail"],
+            "tree (k_round, k_scan, k_scatter)": st["ms_tree"], "ply (sample, mirror, advance)": st["ms_ply"]}
+    dominant = max(("k_trunk", "k_fc0_mx"), key=lambda kk: k_ms[kk])
+    pmc = PMC_FILE.get(str(n), {})
+
+    def mfma_roofline(kernel, flop_row, note):
+        sec = k_ms[kernel] * 1e-3
+        ach = rows * flop_row / sec / 1e12 if sec > 0 else 0.0
+        per_row = pmc.get(kernel + "_hbm_bytes_per_row") or PMC_HBM_BYTES_PER_ROW.get(n, {}).get(kernel)
+        alg_row = {"k_trunk": 2 * 8 * ((hw + 63) // 64) + 16 + 384.0 * hw, "k_fc0_mx": 384.0 * hw + 2048}[kernel]
+        return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / F16_DENSE_PEAK_TFLOPS, "traffic": per_row * rows / launches if per_row else None,
+                "traffic_unit": "HBM bytes per (average) launch: per-row bytes of the committed rocprofv3 --pmc pass "
+                                "(FETCH_SIZE x 2 + WRITE_SIZE, profiles/README.md) x rows per launch",
+                "algorithmic_bytes_per_launch": alg_row * rows / launches + ({"k_trunk": 110e3, "k_fc0_mx": 128.0 * hw * 512 * 3}[kernel]),
+                "avg_launch_ms": k_ms[kernel] / launches, "rows_per_launch": rows / launches, "share_of_kernel_time": k_ms[kernel] / max(sum(k_ms.values()), 1e-9),
+                "note": note}
+
+    note_trunk = ("conv_in + 3 bottleneck blocks, algorithmic flops 2*MAC (13.0 MFLOP/eval at N = 15); every product runs as 3 f16 MFMAs "
+                  "(split operands: hi*hi + lo*hi + hi*lo), so frac <= 0.33 by construction; measured live with HIP events on the engine's stream")
+    note_fc0 = ("algorithmic flops 2*128*HW*512 per eval; per K = 64 the kernel issues 4 f16 + 2 block-scaled fp6 MFMAs (split operands) = 1.5x the "
+                "pipe time of a plain-f16 product, so frac <= 0.67 by construction")
     net_s = (st["ms_trunk"] + st["ms_fc0"] + st["ms_tail"]) * 1e-3
-    round_s = st["ms_tree"] * 1e-3
+    tree_s = st["ms_tree"] * 1e-3
+    tree_traffic = pmc.get("tree_hbm_bytes_per_sim")
     out = {
         "metric": "self-play games/sec (15x15, 800 sims/move); MCTS nodes/sec",
         "value": games_per_s, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 (split hi+lo MFMA operands; fc0 correction terms in block-scaled fp6), fp32 accumulate" if args.net_mode == "f16x3" else "f32",
-        "data": "synthetic (games from the empty board, random-init net seed 0)",
+        "data": "synthetic (games from the empty board, random-init net seed 0, one RNG stream per step)",
         "config": {"workload": f"{games} concurrent {n}x{n} games per GPU, {args.sims} sims/move, K={k}, two trees per game"
                                + ("" if complete else f", first {args.max_plies} plies only (games/s extrapolated)"),
                    "games_per_gpu": games, "board": n, "sims_per_move": args.sims, "batch_k": k,
-                   "parallelism": f"games sharded x{world}, no hot-path collective" + (", RCCL replay gather" if args.gather else "")},
+                   "warmup_step": f"episode cut after {args.warmup_plies} plies" if args.warmup_plies else "whole episode",
+                   "parallelism": f"games sharded x{world}, no hot-path collective" + (", RCCL all-gather-v of replay tuples per episode" if args.gather else "")},
         "mcts_sims_per_s": sims / dt, "nn_evals_per_s": evals / dt, "plies_per_s": ply_games / dt,
         "mean_plies_per_game": mean_plies, "games_finished": finished,
-        "roofline": {"bound": "mfma", "kernel": "k_fc0_mx (fc0)", "achieved": fc0_tflops, "peak": F16_DENSE_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": fc0_tflops / F16_DENSE_PEAK_TFLOPS,
-                     "traffic": FC0_HBM_BYTES_PER_ROW.get(n, 0) * st["fc0_rows"] / max(st["fc0_launches"], 1.0) or None,
-                     "traffic_unit": "HBM bytes per launch (rows per launch x per-row bytes of the committed PMC pass: "
-                                     "profiles/README.md; FETCH_SIZE x2 + WRITE_SIZE)",
-                     "algorithmic_bytes_per_launch": (128 * hw * 3 + 2048) * st["fc0_rows"] / max(st["fc0_launches"], 1.0) + 128 * hw * 512 * 3,
-                     "mfma_mix_bound": {"value": 1078.0, "unit": "TFLOP/s", "frac_of_bound": fc0_tflops / 1078.0,
-                                        "note": "the kernel's MFMA mix alone (operands in registers, random data, one wave per SIMD, every CU): "
-                                                "tools/probe/shape_probe mode 2 = 3234 TFLOP/s over the three product terms = 1078 algorithmic"},
-                     "note": "algorithmic flops (2*128*HW*512 per eval); per K=64 the kernel issues 4 f16 + 2 block-scaled fp6 "
-                             "MFMAs (split operands) = 1.5x the pipe time of a plain-f16 product, so frac <= 0.67 by construction"},
-        "roofline_trunk": {"bound": "mfma", "kernel": "k_trunk", "achieved": evals * (flop_eval - flop_fc0 - 2.0 * (512 * 512 + 512 + 512 * hw)) / (st["ms_trunk"] * 1e-3) / 1e12 if st["ms_trunk"] > 0 else 0.0,
-                           "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "note": "conv_in + 3 bottleneck blocks, 3 f16 MFMAs per product; not MFMA-bound: VALU-issue / LDS / barrier-bound "
-                                   "(DESIGN.md 3.2: MFMA busy 36 %, phase model at 82 %)"},
-        "roofline_net": {"bound": "mfma", "achieved": evals * flop_eval / net_s / 1e12 if net_s > 0 else 0.0,
-                         "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (evals * flop_eval / net_s / 1e12 / F16_DENSE_PEAK_TFLOPS) if net_s > 0 else 0.0},
-        "roofline_tree": {"bound": "hbm", "kernel": "k_round+k_scan+k_scatter", "achieved": st["tree_bytes"] / round_s / 1e9 if round_s > 0 else 0.0,
-                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": (st["tree_bytes"] / round_s / 1e9 / HBM_PEAK_GBS) if round_s > 0 else 0.0, "traffic": None},
+        "roofline": mfma_roofline(dominant, flop_trunk if dominant == "k_trunk" else flop_fc0, note_trunk if dominant == "k_trunk" else note_fc0),
+        "roofline_trunk": mfma_roofline("k_trunk", flop_trunk, note_trunk),
+        "roofline_fc0": mfma_roofline("k_fc0_mx", flop_fc0, note_fc0),
+        "roofline_net": {"bound": "mfma", "achieved": rows * flop_eval / net_s / 1e12 if net_s > 0 else 0.0, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (rows * flop_eval / net_s / 1e12 / F16_DENSE_PEAK_TFLOPS) if net_s > 0 else 0.0,
+                         "note": "whole forward per SURVEY 8d: evals x 43.25 MFLOP / (trunk + fc0 + tail time)"},
+        "roofline_tree": {"bound": "hbm", "kernel": "k_round+k_scan+k_scatter", "achieved": st["tree_bytes"] / tree_s / 1e9 if tree_s > 0 else 0.0,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (st["tree_bytes"] / tree_s / 1e9 / HBM_PEAK_GBS) if tree_s > 0 else 0.0,
+                          "algorithmic_bytes_per_sim": st["tree_bytes"] / max(st["sims"], 1.0),
+                          "traffic": tree_traffic * st["sims"] / max(st["round_launches"], 1.0) if tree_traffic else None,
+                          "traffic_unit": "HBM bytes per round (k_round + k_scan + k_fill + k_scatter*): PMC bytes per simulation (profiles/) x simulations per round"},
         "rank0_kernel_ms": {kk: st[kk] for kk in ("ms_round", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply")},
+        "rank0_timed_region_ms": 1e3 * dt,
         "game_length_percentiles": {str(q): float(np.percentile(plies, q)) for q in (0, 10, 25, 50, 75, 90, 99, 100)},
         "arena": {"max_nodes": max_nodes, "max_tables": max_tables, "peak_nodes": st["peak_nodes"], "peak_tables": st["peak_tables"]},
+        "cpu_baseline": None,
+        "seconds_since_process_start": elapsed(),
     }
-    if complete and world == 1:  # outside the timed region (single-GPU runs only: the other ranks have left by now): the
-        # episode-end replay post-processing row on the device
-        rec = sp.replay_record_bytes()
-        n_rec = 6 * int(plies.sum())
-        buf = torch.empty(max(n_rec, 1) * rec, dtype=torch.uint8, device=f"cuda:{local_rank}")
-        sp.replay_augment_into(buf.data_ptr(), n_rec)  # warm-up
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        got = sp.replay_augment_into(buf.data_ptr(), n_rec)
-        dt_pp = time.perf_counter() - t1
-        nw = (hw + 63) // 64
-        alg = (n_rec // 6) * (16 * nw + 1 + 4 * hw + 4) + n_rec * rec  # transitions read once + records written
-        out["replay_postprocess"] = {"records": got, "ms": 1e3 * dt_pp, "bound": "hbm", "achieved": alg / dt_pp / 1e9, "peak": HBM_PEAK_GBS,
-                                     "unit": "GB/s", "frac": alg / dt_pp / 1e9 / HBM_PEAK_GBS,
-                                     "note": "z back-fill + 5 augmentations per transition (trainer.rs:207-324), rank 0, host-timed call"}
-        if args.train_steps > 0:  # also outside the timed region: the training phase on the same records
-            try:
-                from omok_ai_amd import train as T
-                ph = T.TrainPhase(n, oa.weights.init_random(n, seed=0), f"cuda:{local_rank}")
-                ph.run(buf, update_count=2, batch_size=128, seed=0)  # warm-up (MIOpen / rocBLAS plans)
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-                v_l, p_l, l_ = ph.run(buf, update_count=args.train_steps, batch_size=128, seed=1)
-                torch.cuda.synchronize()
-                dt_tr = time.perf_counter() - t2
-                out["train_phase"] = {"steps": args.train_steps, "batch": 128, "steps_per_s": args.train_steps / dt_tr, "loss": l_,
-                                      "note": "AgentModel::train (Adadelta lr 0.01) via torch autograd on the augmented replay records, rank 0"
-                                              " (multi-GPU: gradients averaged by one RCCL all-reduce per step, tests/test_sharding_gloo.py)"}
-            except Exception as ex:  # an extra line of the report must never cost the bench line itself
-                out["train_phase"] = {"error": repr(ex)}
-        del buf
-    if args.cpu_seconds > 0 and world == 1:
-        try:
-            out["cpu_baseline"] = cpu_baseline(args, max(mean_plies, 1.0))
-        except Exception as ex:  # (the GPU measurement above stands on its own)
-            out["cpu_baseline"] = {"error": repr(ex)}
-    print(json.dumps(out))
+    if args.gather:
+        out["replay_gather"] = {"records_per_episode": gathered["records"] / max(args.steps, 1), "bytes_per_episode": gathered["bytes"] / max(args.steps, 1),
+                                "seconds_per_episode": gathered["seconds"] / max(args.steps, 1), "inside_timed_region": True,
+                                "method": "8 x int64 counts all-gather, then exact-size grouped send/recv (all-gather-v)"}
+    print(json.dumps(out), flush=True)  # the measured line exists from here on, whatever happens to the extra legs
+
+    # ---- extra legs, outside the timed region, only while the wall-clock budget has room ----------------------------
+    extras = False
+
+    def room(need):
+        return elapsed() + need < args.budget_seconds
+
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if use_cuda and world == 1 and complete:
+        if args.precision_rows > 0 and room(25):
+            try:
+                out["precision"] = precision_check(args, args.precision_rows, local_rank)
+            except Exception as ex:
+                out["precision"] = {"error": repr(ex)}
+            extras = True
+        if room(15):  # the episode-end replay post-processing row on the device
+            try:
+                n_rec = 6 * int(plies.sum())
+                buf = torch.empty(max(n_rec, 1) * rec, dtype=torch.uint8, device=device)
+                sp.replay_augment_into(buf.data_ptr(), n_rec)  # warm-up
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                got = sp.replay_augment_into(buf.data_ptr(), n_rec)
+                dt_pp = time.perf_counter() - t1
+                nw = (hw + 63) // 64
+                alg = (n_rec // 6) * (16 * nw + 1 + 4 * hw + 4) + n_rec * rec  # transitions read once + records written
+                out["replay_postprocess"] = {"records": got, "ms": 1e3 * dt_pp, "bound": "hbm", "achieved": alg / dt_pp / 1e9, "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": alg / dt_pp / 1e9 / HBM_PEAK_GBS,
+                                             "note": "z back-fill + 5 augmentations per transition (trainer.rs:207-324), rank 0, host-timed call"}
+                if args.train_steps > 0 and room(30):  # the training phase on the same records
+                    from omok_ai_amd import train as T
+                    ph = T.TrainPhase(n, oa.weights.init_random(n, seed=0), device)
+                    ph.run(buf, update_count=2, batch_size=128, seed=0)  # warm-up (MIOpen / rocBLAS plans)
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    v_l, p_l, l_ = ph.run(buf, update_count=args.train_steps, batch_size=128, seed=1)
+                    torch.cuda.synchronize()
+                    dt_tr = time.perf_counter() - t2
+                    out["train_phase"] = {"steps": args.train_steps, "batch": 128, "steps_per_s": args.train_steps / dt_tr, "loss": l_,
+                                          "note": "AgentModel::train (Adadelta lr 0.01) via torch autograd on the augmented replay records, rank 0"}
+                del buf
+            except Exception as ex:  # an extra line of the report must never cost the bench line itself
+                out["replay_postprocess_error"] = repr(ex)
+            extras = True
+    if args.cpu_seconds > 0 and world == 1:
+        share = min(args.cpu_seconds, args.budget_seconds - elapsed() - 10.0)
+        if share >= 8.0:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, max(mean_plies, 1.0), share)
+            except Exception as ex:  # (the GPU measurement above stands on its own)
+                out["cpu_baseline"] = {"error": repr(ex)}
+        else:
+            out["cpu_baseline"] = {"skipped": f"no room in the {args.budget_seconds:.0f} s budget ({elapsed():.0f} s used)"}
+        extras = True
+    if extras:
+        out["seconds_since_process_start"] = elapsed()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -40,18 +40,22 @@ extern "C" {
 #define OMOK_NET_F16X3 0 /* split-operand MFMA (hi+lo: f16 main term, f16 / block-scaled fp6 correction terms, fp32 accumulate) */
 #define OMOK_NET_F32 1   /* plain fp32 VALU kernels (debug / A-B reference on the GPU) */
 
+#define OMOK_MAX_ARENA 16384 /* largest max_nodes / max_tables: node and table indices are 16-bit, and the re-rooting kernel keeps
+                               3 B per node + 2 B per table of scratch in LDS (82 KiB at the maximum, inside gfx950's 160 KiB) */
+
 typedef struct omok_engine omok_engine;
 
 typedef struct {
     int32_t board_size;  /* N: 9 (reference, environment/src/lib.rs:70) or 15 */
     int32_t games;       /* G concurrent games = episode_count (src/config.rs:90); two trees each */
-    int32_t max_nodes;   /* per-tree node arena (<= 65535) */
-    int32_t max_tables;  /* per-tree child-table arena (<= 65535) */
+    int32_t max_nodes;   /* per-tree node arena, 2 .. OMOK_MAX_ARENA (omok_create rejects more, and sizes whose re-rooting scratch
+                            does not fit the device's LDS) */
+    int32_t max_tables;  /* per-tree child-table arena, 1 .. OMOK_MAX_ARENA */
     int32_t max_batch_k; /* largest evaluate_batch_size that will be used (<= 64) */
     int32_t device;      /* HIP device ordinal */
     int32_t net_mode;    /* OMOK_NET_* */
     int32_t reserved;
-    uint64_t seed;       /* RNG key */
+    uint64_t seed;       /* RNG seed; the Philox key of episode i is seed + i * 0x9E3779B97F4A7C15 (omok_set_episode) */
     int64_t game_offset; /* global id of game 0 (multi-GPU sharding: rank * games) */
 } omok_config;
 
@@ -80,6 +84,10 @@ int omok_net_save_file(omok_engine* e, const char* path);
 /* AgentModel::evaluate_pv (agent_model.rs:116-134): in [B][N][N][3] f32 (encoder.rs layout),
  * p [B][N*N] softmax probabilities, v [B] tanh.  evaluate_p (:105-114) = same with v NULL. */
 int omok_evaluate_pv(omok_engine* e, const float* in, int32_t batch, float* p, float* v);
+/* The same forward, returning what sits in front of the last two ops of the graph: logits [B][N*N] = input of the Softmax
+ * (network.rs:236-247), vpre [B] = input of the Tanh (network.rs:197-200; may be NULL).  Precision evidence / debugging: the
+ * reference API has no such call. */
+int omok_evaluate_logits(omok_engine* e, const float* in, int32_t batch, float* logits, float* vpre);
 
 /* ---- environment crate on device (environment/src/lib.rs:62-166), batched.
  *      Plays `len` moves per row from Environment::new(); status_out[b][i] is the
@@ -92,10 +100,20 @@ int omok_env_play(omok_engine* e, const int32_t* moves, int32_t batch, int32_t l
 int omok_encode_nn_input(omok_engine* e, const uint8_t* boards, const uint8_t* turns, int32_t batch,
                          int32_t mode, float* out);
 
+/* Environment::place_stone (environment/src/lib.rs:104-166) on `batch` caller-held environments: boards [B][N*N] Stone bytes,
+ * turns [B], legal [B] (legal_move_count) are updated in place; status_out[b] = Option<GameStatus> (-1 = None: the cell is
+ * occupied or out of range and environment b is left unchanged).  batch = 1 is the scalar call of the Rust API. */
+int omok_env_place_stone(omok_engine* e, uint8_t* boards, uint8_t* turns, uint16_t* legal, const int32_t* actions,
+                         int32_t batch, int32_t* status_out);
+
 /* ---- self-play: G games x two agents (src/trainer.rs:81-205) ---------------------------- */
 /* Agent::new for both agents of every game (alpha-zero/src/agent.rs:16-35): root policy = raw
- * evaluate_p of the empty board.  Also clears the replay buffer. */
+ * evaluate_p of the empty board.  Also clears the replay buffer.  Every reset is one trainer iteration
+ * (src/trainer.rs:74-93, fresh thread_rng draws): it takes RNG stream `episode` and advances the counter; the first reset
+ * after omok_create is episode 0. */
 int omok_selfplay_reset(omok_engine* e);
+/* index of the RNG stream the NEXT omok_selfplay_reset uses (resuming a training run at iteration i: omok_set_episode(e, i)) */
+int omok_set_episode(omok_engine* e, uint64_t episode);
 /* ParallelMCTSExecutor::execute (alpha-zero/src/parallel_mcts_executor.rs:26-35) on the
  * side-to-move agents of all live games: rounds of `batch_size` simulations per tree, one net
  * forward per round, ordered scatter; simulations round up to a multiple of batch_size. */
@@ -109,6 +127,19 @@ int omok_sample_actions(omok_engine* e, float temperature, int32_t threshold, in
  * opponent's tree (agent.rs:144-232, trainer.rs:156-167), finished games retire
  * (trainer.rs:175-201).  Uses the actions chosen by the last omok_sample_actions. */
 int omok_advance(omok_engine* e);
+/* Agent::compute_policy (agent.rs:43-77) of the side-to-move agent of every game: pi [G][N*N] = child visit counts / their
+ * sum; has_policy[g] = 0 where the reference returns None (finished game, no children, or no visits; the row is then 0).
+ * has_policy may be NULL. */
+int omok_compute_policy(omok_engine* e, float* pi, uint8_t* has_policy);
+/* Externally chosen moves, actions [G] (ignored for finished games; every live game must move: all games share the side to
+ * move, trainer.rs:96-97): Agent::ensure_action_exists(action) + Agent::play_action(action) on BOTH agents of each game
+ * (agent.rs:144-232) -- what gui/src/agent.rs:49-66 and benchmark/src/agent.rs:34-50 do with a move their own search did not
+ * pick.  One batched evaluate_p serves both agents of a game (same position).  No Transition is recorded (the trainer
+ * records only moves it sampled, trainer.rs:138-173).  An occupied / out-of-range cell returns OMOK_ERR_ILLEGAL and leaves
+ * every game unchanged (Option::None of play_action). */
+int omok_play_actions(omok_engine* e, const int32_t* actions);
+/* step-wise form for parity tests: stages the moves like omok_sample_actions does; omok_mirror_* / omok_advance follow */
+int omok_set_actions(omok_engine* e, const int32_t* actions);
 /* whole self-play phase of one trainer iteration (trainer.rs:95-205): repeats
  * execute/sample/advance until every game is finished or max_plies (>0) plies were played.
  * stats (may be NULL, 16 doubles): see OMOK_STAT_* */
@@ -141,17 +172,22 @@ int omok_game_info(omok_engine* e, uint8_t* alive, uint8_t* status, int32_t* pli
 int omok_tree_dump(omok_engine* e, int32_t game, int32_t side, int32_t* ints, float* floats, int32_t cap_nodes);
 int omok_tree_root(omok_engine* e, int32_t game, int32_t side, uint32_t* root_n, float* root_w,
                    int32_t* n_nodes, int32_t* n_tables);
+/* Node::children of a root in insertion order (mcts/src/node.rs:10-21; MCTS::root, mcts/src/lib.rs:34-36): action, n, w and
+ * p (= root.policy[action], which the reference keeps equal to child.p) of the first min(children, cap) children.  Returns
+ * the number of children.  Any output may be NULL. */
+int omok_root_children(omok_engine* e, int32_t game, int32_t side, int32_t* actions, uint32_t* n, float* w, float* p, int32_t cap);
 /* Transition{env, policy, z} records of one game (trainer.rs:20-24,169-173; z as recorded at play
  * time, before the back-fill of trainer.rs:207-214).  returns the ply count. */
 int omok_replay_game(omok_engine* e, int32_t game, uint8_t* boards, uint8_t* turns, float* pi, float* z,
                      int32_t cap_plies);
 /* replay tuples of all games packed on the device for an RCCL gather: record = board u8[N*N],
- * turn u8, pad to 4, pi f32[N*N], z f32.  Writes at most cap_records to dst_dev (a device
- * pointer the caller owns, e.g. a torch tensor) and returns the record count. */
+ * turn u8, zero pad to 4, pi f32[N*N], z f32; games in id order, transitions in play order (the same bytes on every run).
+ * Writes at most cap_records to dst_dev (a device pointer the caller owns, e.g. a torch tensor) and returns the record
+ * count. */
 int64_t omok_replay_pack_dev(omok_engine* e, void* dst_dev, int64_t cap_records);
 int32_t omok_replay_record_bytes(const omok_engine* e);
 /* Replay post-processing of Trainer::train (src/trainer.rs:207-324) on the device.  Per game, in game-id order (the
- * reference appends games in completion order): the game's L transitions with z back-filled (walking backwards from the
+ * reference walks `transitions` by game index too, trainer.rs:208): the game's L transitions with z back-filled (walking backwards from the
  * last transition z alternates sign, :209-214), then 5L augmented copies, transition-major, in the reference's order
  * rotate_90, rotate_180, rotate_270, flip_horizontal, flip_vertical of board and policy (src/utils.rs:1-64), turn and z
  * unchanged.  Records as in omok_replay_pack_dev.  Returns the record count 6 * sum(L) (records beyond cap are dropped). */

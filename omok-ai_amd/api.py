@@ -79,6 +79,15 @@ class Engine:
         self._chk(B.lib().omok_evaluate_pv(self.h, B.fptr(x), b, B.fptr(p), B.fptr(v)))
         return p.reshape(b, self.n, self.n), v.reshape(b, 1)
 
+    def evaluate_logits(self, inputs):
+        """pre-softmax policy logits [B][HW] and pre-tanh value [B] of the same forward (precision evidence)"""
+        x = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 3 * self.hw)
+        b = x.shape[0]
+        lg = np.zeros((b, self.hw), dtype=np.float32)
+        vp = np.zeros(b, dtype=np.float32)
+        self._chk(B.lib().omok_evaluate_logits(self.h, B.fptr(x), b, B.fptr(lg), B.fptr(vp)))
+        return lg, vp
+
     def evaluate_p(self, inputs):
         return self.evaluate_pv(inputs)[0]
 
@@ -96,6 +105,17 @@ class Engine:
         self._chk(B.lib().omok_env_play(self.h, B.iptr(moves), b, l, B.iptr(status), B.u8ptr(boards), B.u8ptr(turns),
                                         legal.ctypes.data_as(C.POINTER(C.c_uint16))))
         return status[:, :l], boards, turns, legal
+
+    def env_place_stone(self, boards, turns, legal, actions):
+        """Environment::place_stone on caller-held environments (updated in place); returns status [B] (-1 = None)."""
+        b = len(actions)
+        assert boards.dtype == np.uint8 and boards.shape == (b, self.hw) and boards.flags.c_contiguous
+        assert turns.dtype == np.uint8 and legal.dtype == np.uint16
+        actions = np.ascontiguousarray(actions, dtype=np.int32)
+        status = np.zeros(b, dtype=np.int32)
+        self._chk(B.lib().omok_env_place_stone(self.h, B.u8ptr(boards), B.u8ptr(turns), legal.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                               B.iptr(actions), b, B.iptr(status)))
+        return status
 
     def encode_nn_input(self, boards, turns, mode=B.MODE_PLAYER):
         boards = np.ascontiguousarray(boards, dtype=np.uint8).reshape(-1, self.hw)
@@ -118,27 +138,22 @@ class Engine:
 
 
 class Environment:
-    """environment::Environment backed by the device rules kernel (replays its move list)."""
+    """environment::Environment (environment/src/lib.rs:62-166): the caller holds board / turn / legal_move_count, the
+    device rules kernel applies place_stone to them (omok_env_place_stone, batch of one)."""
 
     def __init__(self, engine):
         self.eng = engine
-        self.moves = []
-        self._sync()
+        self._board = np.zeros((1, engine.hw), dtype=np.uint8)   # Environment::new (:73-79)
+        self._turn = np.zeros(1, dtype=np.uint8)
+        self._legal = np.full(1, engine.hw, dtype=np.uint16)
 
-    def _sync(self):
-        m = np.array([self.moves], dtype=np.int32).reshape(1, len(self.moves))
-        st, boards, turns, legal = self.eng.env_play(m)
-        self.board, self.turn, self.legal_move_count = boards[0], int(turns[0]), int(legal[0])
-        return st[0]
+    board = property(lambda s: s._board[0])
+    turn = property(lambda s: int(s._turn[0]))
+    legal_move_count = property(lambda s: int(s._legal[0]))
 
     def place_stone(self, index):
-        self.moves.append(int(index))
-        st = self._sync()
-        s = int(st[-1])
-        if s < 0:
-            self.moves.pop()
-            return None
-        return s
+        s = int(self.eng.env_place_stone(self._board, self._turn, self._legal, [int(index)])[0])
+        return None if s < 0 else s
 
     def encode_board(self, turn):
         """Environment::encode_board(turn): the first 2*HW floats of the NN input with that perspective."""
@@ -157,6 +172,39 @@ class SelfPlay:
 
     def reset(self):
         self._chk(B.lib().omok_selfplay_reset(self.h))
+
+    def set_episode(self, episode):
+        """index of the RNG stream the NEXT reset uses (each reset = one trainer iteration advances it by itself)"""
+        self._chk(B.lib().omok_set_episode(self.h, int(episode)))
+
+    def compute_policy(self):
+        """Agent::compute_policy of the side-to-move agents: (pi [G][HW], has [G]); has == 0 where the reference returns None"""
+        pi = np.zeros((self.games, self.hw), dtype=np.float32)
+        has = np.zeros(self.games, dtype=np.uint8)
+        self._chk(B.lib().omok_compute_policy(self.h, B.fptr(pi), B.u8ptr(has)))
+        return pi, has
+
+    def play_actions(self, actions):
+        """externally chosen moves: ensure_action_exists + play_action on both agents of every live game"""
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        assert a.size == self.games
+        self._chk(B.lib().omok_play_actions(self.h, B.iptr(a)))
+
+    def set_actions(self, actions):
+        """step-wise form of play_actions (mirror_generate / mirror_eval|inject / mirror_apply follow)"""
+        a = np.ascontiguousarray(actions, dtype=np.int32)
+        assert a.size == self.games
+        self._chk(B.lib().omok_set_actions(self.h, B.iptr(a)))
+
+    def root_children(self, game, side):
+        """(actions, n, w, p) of the root's children in insertion order"""
+        cap = self.hw
+        a = np.zeros(cap, dtype=np.int32)
+        n = np.zeros(cap, dtype=np.uint32)
+        w = np.zeros(cap, dtype=np.float32)
+        p = np.zeros(cap, dtype=np.float32)
+        k = self._chk(B.lib().omok_root_children(self.h, game, side, B.iptr(a), n.ctypes.data_as(C.POINTER(C.c_uint32)), B.fptr(w), B.fptr(p), cap))
+        return a[:k], n[:k], w[:k], p[:k]
 
     @property
     def ply(self):

@@ -19,7 +19,8 @@ STAT_NAMES = ["sims", "evals", "ply_games", "finished", "ms_tree", "ms_trunk", "
 # every symbol include/omok_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "omok_create", "omok_destroy", "omok_last_error", "omok_net_num_tensors", "omok_net_tensor_size", "omok_net_load",
-    "omok_net_commit", "omok_net_load_file", "omok_net_save_file", "omok_evaluate_pv", "omok_env_play", "omok_encode_nn_input", "omok_selfplay_reset", "omok_execute",
+    "omok_net_commit", "omok_net_load_file", "omok_net_save_file", "omok_evaluate_pv", "omok_evaluate_logits", "omok_env_play", "omok_env_place_stone", "omok_encode_nn_input", "omok_selfplay_reset", "omok_set_episode", "omok_execute",
+    "omok_compute_policy", "omok_play_actions", "omok_set_actions", "omok_root_children",
     "omok_sample_actions", "omok_advance", "omok_selfplay_run", "omok_round_generate", "omok_round_inputs",
     "omok_round_eval", "omok_round_outputs", "omok_round_inject", "omok_round_scatter", "omok_mirror_generate",
     "omok_mirror_inputs", "omok_mirror_eval", "omok_mirror_outputs", "omok_mirror_inject", "omok_mirror_apply",
@@ -70,9 +71,16 @@ def lib():
     L.omok_net_load_file.argtypes = [H, C.c_char_p]
     L.omok_net_save_file.argtypes = [H, C.c_char_p]
     L.omok_evaluate_pv.argtypes = [H, fp, C.c_int32, fp, fp]
+    L.omok_evaluate_logits.argtypes = [H, fp, C.c_int32, fp, fp]
     L.omok_env_play.argtypes = [H, ip, C.c_int32, C.c_int32, ip, u8p, u8p, C.POINTER(C.c_uint16)]
     L.omok_encode_nn_input.argtypes = [H, u8p, u8p, C.c_int32, C.c_int32, fp]
     L.omok_selfplay_reset.argtypes = [H]
+    L.omok_set_episode.argtypes = [H, C.c_uint64]
+    L.omok_env_place_stone.argtypes = [H, u8p, u8p, C.POINTER(C.c_uint16), ip, C.c_int32, ip]
+    L.omok_compute_policy.argtypes = [H, fp, u8p]
+    L.omok_play_actions.argtypes = [H, ip]
+    L.omok_set_actions.argtypes = [H, ip]
+    L.omok_root_children.argtypes = [H, C.c_int32, C.c_int32, ip, C.POINTER(C.c_uint32), fp, fp, C.c_int32]
     L.omok_execute.argtypes = [H, C.c_int32, C.c_int32, C.c_float, C.c_float]
     L.omok_sample_actions.argtypes = [H, C.c_float, C.c_int32, ip]
     L.omok_advance.argtypes = [H]

@@ -81,6 +81,8 @@ struct omok_engine {
     int ply = 0;
     bool reset_done = false;
     bool sampled = false;
+    uint64_t episode = 0;  // index of the RNG stream the NEXT omok_selfplay_reset takes (one reset = one trainer iteration)
+    uint64_t key = 0;      // Philox key of the current episode: cfg.seed + episode * 0x9E3779B97F4A7C15
     int round_reqs = -1;   // step-wise API state
     int round_cap = 0;     // alive * batch_size of the generated round: the net's max_count (same as omok_execute uses)
     int mirror_reqs = -1;
@@ -88,7 +90,9 @@ struct omok_engine {
     int32_t* d_actions = nullptr;
     uint32_t* d_error = nullptr; // [0] error bits, [1] alive count
     unsigned long long* d_evals = nullptr;
-    long long* d_pack_total = nullptr;
+    uint32_t* d_flags = nullptr;        // [0] illegal external moves, [1] live games without a move (omok_play_actions)
+    float* d_pi = nullptr;              // [G][HW] omok_compute_policy
+    uint8_t* d_has = nullptr;           // [G]
     long long* d_aug_offsets = nullptr; // [games + 1] first augmented-replay record of every game
     uint8_t* d_aug_scratch = nullptr;   // one game's 6 * HW records (omok_replay_augmented_game)
     // host-side stats
@@ -113,6 +117,13 @@ static int fail(omok_engine* e, int code, const char* fmt, ...) {
     do {                                                                                       \
         hipError_t _r = (call);                                                                \
         if (_r != hipSuccess) return fail(e, OMOK_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_r)); \
+    } while (0)
+
+// every entry point runs on the engine's own device, whatever the calling thread's current device is
+#define ENTER(e)                                    \
+    do {                                            \
+        if (!(e)) return OMOK_ERR_INVALID;          \
+        HIPCHK(e, hipSetDevice((e)->cfg.device));   \
     } while (0)
 
 template <typename Tp>
@@ -183,14 +194,23 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     if (cfg->board_size != 9 && cfg->board_size != 15)
         return fail(nullptr, OMOK_ERR_INVALID, "board_size must be 9 or 15 (got %d)", cfg->board_size);
     if (cfg->games < 1 || cfg->games > 32767) return fail(nullptr, OMOK_ERR_INVALID, "games must be in [1, 32767]");
-    if (cfg->max_nodes < 2 || cfg->max_nodes > 16384 || cfg->max_tables < 1 || cfg->max_tables > 16384)
-        return fail(nullptr, OMOK_ERR_INVALID, "max_nodes / max_tables must be in [2, 16384]");
+    if (cfg->max_nodes < 2 || cfg->max_nodes > OMOK_MAX_ARENA || cfg->max_tables < 1 || cfg->max_tables > OMOK_MAX_ARENA)
+        return fail(nullptr, OMOK_ERR_INVALID, "max_nodes must be in [2, %d] and max_tables in [1, %d]", OMOK_MAX_ARENA, OMOK_MAX_ARENA);
     if (cfg->max_batch_k < 1 || cfg->max_batch_k > KMAX) return fail(nullptr, OMOK_ERR_INVALID, "max_batch_k must be in [1, 64]");
     if (cfg->net_mode != OMOK_NET_F16X3 && cfg->net_mode != OMOK_NET_F32) return fail(nullptr, OMOK_ERR_INVALID, "bad net_mode");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, OMOK_ERR_HIP, "no HIP device available: this library has no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, OMOK_ERR_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
+    { // the re-rooting kernel keeps 3 B per node + 2 B per table in LDS: refuse arenas it could not launch with
+        hipDeviceProp_t prop;
+        const size_t lds = advance_lds_bytes(cfg->max_nodes, cfg->max_tables);
+        if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(nullptr, OMOK_ERR_HIP, "hipGetDeviceProperties failed");
+        const size_t limit = prop.sharedMemPerBlockOptin > prop.sharedMemPerBlock ? prop.sharedMemPerBlockOptin : prop.sharedMemPerBlock;
+        if (lds > limit)
+            return fail(nullptr, OMOK_ERR_INVALID, "max_nodes=%d / max_tables=%d need %zu bytes of LDS in the re-rooting kernel, the device allows %zu",
+                        cfg->max_nodes, cfg->max_tables, lds, limit);
+    }
     omok_engine* e = new omok_engine();
     e->cfg = *cfg;
     e->n = cfg->board_size;
@@ -236,7 +256,9 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     rc |= dalloc(e, &e->d_actions, G);
     rc |= dalloc(e, &e->d_error, 4);
     rc |= dalloc(e, &e->d_evals, 2);
-    rc |= dalloc(e, &e->d_pack_total, 2);
+    rc |= dalloc(e, &e->d_flags, 4);
+    rc |= dalloc(e, &e->d_pi, G * HW);
+    rc |= dalloc(e, &e->d_has, G);
     rc |= dalloc(e, &e->d_aug_offsets, G + 1);
     if (rc) {
         g_create_error = e->err;
@@ -249,6 +271,12 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     hipMemsetAsync(e->d_evals, 0, 16, e->st);
     hipMemsetAsync(S.gs, 0, sizeof(GameState) * G, e->st);
     hipMemsetAsync(S.ts, 0, sizeof(TreeState) * T, e->st);
+    if (set_advance_lds_attribute(e->n, advance_lds_bytes(cfg->max_nodes, cfg->max_tables)) != 0) {
+        g_create_error = "hipFuncSetAttribute(k_advance, max dynamic LDS) failed";
+        omok_destroy(e);
+        return OMOK_ERR_HIP;
+    }
+    e->net.device = cfg->device;
     e->net.n = e->n;
     e->net.hw = e->hw;
     e->net.rowp = e->rowp;
@@ -403,6 +431,8 @@ static int sync_and_check(omok_engine* e, const char* what) {
 extern "C" int omok_evaluate_pv(omok_engine* e, const float* in, int32_t batch, float* p, float* v) {
     if (!e || !in || !p || batch < 0) return OMOK_ERR_INVALID;
     if (need_net(e)) return OMOK_ERR_STATE;
+    if (e->round_reqs >= 0 || e->mirror_reqs >= 0) // the forward reuses the request counter and the output rows of the pending batch
+        return fail(e, OMOK_ERR_STATE, "omok_evaluate_pv between omok_round_generate / omok_mirror_generate and their scatter / apply");
     HIPCHK(e, hipSetDevice(e->cfg.device));
     const size_t in_row = 3 * (size_t)e->hw;
     float* d_pack = e->net.in_f32; // reused as the packed output staging after the forward
@@ -416,6 +446,33 @@ extern "C" int omok_evaluate_pv(omok_engine* e, const float* in, int32_t batch, 
         HIPCHK(e, hipMemcpyAsync(p + (size_t)done * e->hw, d_pack, sizeof(float) * tot, hipMemcpyDeviceToHost, e->st));
         if (v) HIPCHK(e, hipMemcpyAsync(v + done, e->net.v, sizeof(float) * b, hipMemcpyDeviceToHost, e->st));
         if (sync_and_check(e, "evaluate_pv")) return OMOK_ERR_HIP;
+        e->evals += b;
+    }
+    return OMOK_OK;
+}
+
+// Debug / evidence entry point: the same forward, but the PRE-softmax policy logits and the PRE-tanh value (network.rs:188-247
+// before the Tanh / Softmax ops), so that precision can be stated on logits as well as on the outputs the reference API returns.
+extern "C" int omok_evaluate_logits(omok_engine* e, const float* in, int32_t batch, float* logits, float* vpre) {
+    if (!e || !in || !logits || batch < 0) return OMOK_ERR_INVALID;
+    if (need_net(e)) return OMOK_ERR_STATE;
+    if (e->round_reqs >= 0 || e->mirror_reqs >= 0) return fail(e, OMOK_ERR_STATE, "omok_evaluate_logits while a round / mirror batch is pending");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    const size_t in_row = 3 * (size_t)e->hw;
+    const int piece = e->net.mode == OMOK_NET_F32 ? std::min(e->net.chunk, e->net.max_b) : e->net.max_b;
+    float* d_pack = e->net.in_f32;
+    for (int32_t done = 0; done < batch; done += piece) {
+        const int b = std::min<int32_t>(piece, batch - done);
+        HIPCHK(e, hipMemcpyAsync(e->net.in_f32, in + (size_t)done * in_row, sizeof(float) * in_row * b, hipMemcpyHostToDevice, e->st));
+        HIPCHK(e, hipMemcpyAsync(e->S.d_count, &b, sizeof(int32_t), hipMemcpyHostToDevice, e->st));
+        net_forward_inputs(e->net, e->S, b, e->st, &e->prof);
+        int stride = 0;
+        const float* lg = net_logits(e->net, &stride);
+        const size_t tot = (size_t)b * e->hw;
+        k_pack_rows<<<(unsigned)((tot + 255) / 256), 256, 0, e->st>>>(lg, d_pack, e->hw, stride, b);
+        HIPCHK(e, hipMemcpyAsync(logits + (size_t)done * e->hw, d_pack, sizeof(float) * tot, hipMemcpyDeviceToHost, e->st));
+        if (vpre) HIPCHK(e, hipMemcpyAsync(vpre + done, e->net.vpre, sizeof(float) * b, hipMemcpyDeviceToHost, e->st));
+        if (sync_and_check(e, "evaluate_logits")) return OMOK_ERR_HIP;
         e->evals += b;
     }
     return OMOK_OK;
@@ -500,6 +557,8 @@ extern "C" int omok_selfplay_reset(omok_engine* e) {
     launch_reset(e->n, e->S, e->d_root_policy, e->st);
     if (sync_and_check(e, "selfplay_reset")) return OMOK_ERR_HIP;
     e->evals += 1;
+    e->key = e->cfg.seed + e->episode * 0x9E3779B97F4A7C15ULL; // a fresh RNG stream per episode (the reference draws thread_rng anew, trainer.rs:71-93)
+    e->episode += 1;
     e->ply = 0;
     e->reset_done = true;
     e->sampled = false;
@@ -514,7 +573,7 @@ static int need_reset(omok_engine* e) {
 
 static void enqueue_round(omok_engine* e, int round, int K, float eps, float alpha, bool eval_and_scatter, int alive) {
     const int side = e->ply & 1;
-    RoundArgs a{side, round, K, e->ply, eps, alpha, e->cfg.seed, e->cfg.game_offset};
+    RoundArgs a{side, round, K, e->ply, eps, alpha, e->key, e->cfg.game_offset};
     e->prof.begin(PC_ROUND, e->st);
     launch_round(e->n, e->S, a, e->st);
     e->prof.end(e->st);
@@ -563,7 +622,7 @@ extern "C" int omok_execute(omok_engine* e, int32_t count, int32_t batch_size, f
 
 static void enqueue_sample(omok_engine* e, float temperature, int threshold) {
     e->prof.begin(PC_PLY, e->st);
-    launch_sample(e->n, e->S, e->ply & 1, e->ply, temperature, threshold, e->cfg.seed, e->cfg.game_offset, e->d_actions, e->st);
+    launch_sample(e->n, e->S, e->ply & 1, e->ply, temperature, threshold, e->key, e->cfg.game_offset, e->d_actions, e->st);
     e->prof.end(e->st);
 }
 
@@ -637,6 +696,124 @@ extern "C" int omok_selfplay_run(omok_engine* e, int32_t count, int32_t batch_si
     return OMOK_OK;
 }
 
+
+extern "C" int omok_set_episode(omok_engine* e, uint64_t episode) {
+    if (!e) return OMOK_ERR_INVALID;
+    e->episode = episode;
+    return OMOK_OK;
+}
+
+// Agent::compute_policy for every game (agent.rs:43-77)
+extern "C" int omok_compute_policy(omok_engine* e, float* pi, uint8_t* has_policy) {
+    if (!e || !pi) return OMOK_ERR_INVALID;
+    if (need_reset(e)) return OMOK_ERR_STATE;
+    ENTER(e);
+    launch_policy(e->n, e->S, e->ply & 1, e->d_pi, e->d_has, e->st);
+    HIPCHK(e, hipMemcpyAsync(pi, e->d_pi, sizeof(float) * (size_t)e->cfg.games * e->hw, hipMemcpyDeviceToHost, e->st));
+    if (has_policy) HIPCHK(e, hipMemcpyAsync(has_policy, e->d_has, (size_t)e->cfg.games, hipMemcpyDeviceToHost, e->st));
+    return sync_and_check(e, "compute_policy") ? OMOK_ERR_HIP : OMOK_OK;
+}
+
+// Externally chosen moves: Agent::ensure_action_exists + Agent::play_action on BOTH agents of every live game
+// (agent.rs:144-232; the flow of gui/src/agent.rs:49-66 and benchmark/src/agent.rs:34-50 for a move the search did not pick).
+static int stage_actions(omok_engine* e, const int32_t* actions) {
+    uint32_t flags[4] = {0, 0, 0, 0};
+    HIPCHK(e, hipMemsetAsync(e->d_flags, 0, 16, e->st));
+    HIPCHK(e, hipMemcpyAsync(e->d_actions, actions, sizeof(int32_t) * e->cfg.games, hipMemcpyHostToDevice, e->st));
+    launch_set_actions(e->n, e->S, e->ply & 1, e->d_actions, e->d_flags, e->st);
+    HIPCHK(e, hipMemcpyAsync(flags, e->d_flags, 16, hipMemcpyDeviceToHost, e->st));
+    if (sync_and_check(e, "play_actions")) return OMOK_ERR_HIP;
+    if (flags[0] || flags[1]) { // nothing has been played yet: drop the staged moves, the position is unchanged
+        launch_clear_actions(e->S, e->st);
+        if (sync_and_check(e, "play_actions")) return OMOK_ERR_HIP;
+        if (flags[0]) return fail(e, OMOK_ERR_ILLEGAL, "%u illegal move(s): cell occupied or out of range (place_stone -> None)", flags[0]);
+        return fail(e, OMOK_ERR_INVALID, "%u live game(s) without a move: every live game moves in a ply (all games share the side to move)", flags[1]);
+    }
+    return OMOK_OK;
+}
+
+extern "C" int omok_set_actions(omok_engine* e, const int32_t* actions) {
+    if (!e || !actions) return OMOK_ERR_INVALID;
+    if (need_reset(e)) return OMOK_ERR_STATE;
+    ENTER(e);
+    const int rc = stage_actions(e, actions);
+    if (rc == OMOK_OK) e->sampled = true;
+    return rc;
+}
+
+extern "C" int omok_play_actions(omok_engine* e, const int32_t* actions) {
+    if (!e || !actions) return OMOK_ERR_INVALID;
+    if (need_net(e) || need_reset(e)) return OMOK_ERR_STATE;
+    ENTER(e);
+    const int rc = stage_actions(e, actions);
+    if (rc != OMOK_OK) return rc;
+    e->sampled = true;
+    return omok_advance(e);
+}
+
+// children of a root in insertion order (Node::children of MCTS::root, mcts/src/node.rs:10-21): action, n, w, p
+extern "C" int omok_root_children(omok_engine* e, int32_t game, int32_t side, int32_t* actions, uint32_t* n, float* w, float* p, int32_t cap) {
+    if (!e || game < 0 || game >= e->cfg.games || (side != 0 && side != 1) || cap < 0) return OMOK_ERR_INVALID;
+    ENTER(e);
+    const size_t t = (size_t)side * e->cfg.games + game, rp = (size_t)e->rowp, nw2 = 2 * (size_t)e->nw;
+    const size_t tn = t * (size_t)e->cfg.max_nodes, tt = t * (size_t)e->cfg.max_tables;
+    NodeHdr h0;
+    HIPCHK(e, hipMemcpyAsync(&h0, e->S.hdr + tn, sizeof(h0), hipMemcpyDeviceToHost, e->st));
+    if (sync_and_check(e, "root_children")) return OMOK_ERR_HIP;
+    if (h0.table == NONE16 || h0.nch == 0) return 0;
+    std::vector<uint32_t> cn(rp);
+    std::vector<float> cw(rp), pol(rp);
+    std::vector<uint8_t> co(rp);
+    std::vector<uint64_t> bb(nw2);
+    const size_t row = (tt + h0.table) * rp;
+    hipMemcpyAsync(cn.data(), e->S.tcn + row, 4 * rp, hipMemcpyDeviceToHost, e->st);
+    hipMemcpyAsync(cw.data(), e->S.tcw + row, 4 * rp, hipMemcpyDeviceToHost, e->st);
+    hipMemcpyAsync(co.data(), e->S.tcorder + row, rp, hipMemcpyDeviceToHost, e->st);
+    hipMemcpyAsync(pol.data(), e->S.policy + tn * rp, 4 * rp, hipMemcpyDeviceToHost, e->st);
+    hipMemcpyAsync(bb.data(), e->S.board + tn * nw2, 8 * nw2, hipMemcpyDeviceToHost, e->st);
+    if (sync_and_check(e, "root_children")) return OMOK_ERR_HIP;
+    for (int a = 0; a < e->hw; ++a) {
+        const int rank = co[a];
+        if (rank == NONE8 || rank >= cap) continue;
+        if (actions) actions[rank] = a;
+        if (n) n[rank] = cn[a];
+        if (w) w[rank] = cw[a];
+        if (p) { // child.p == root.policy[action] (node.rs:76, pme.rs:71-75,256-261)
+            const bool occ = ((bb[a / 64] | bb[e->nw + a / 64]) >> (a % 64)) & 1ULL;
+            p[rank] = h0.has_policy ? pol[a] : ((occ || h0.legal == 0) ? 0.0f : 1.0f / (float)h0.legal);
+        }
+    }
+    return h0.nch;
+}
+
+// Environment::place_stone on caller-held environments (environment/src/lib.rs:104-166), batched
+extern "C" int omok_env_place_stone(omok_engine* e, uint8_t* boards, uint8_t* turns, uint16_t* legal, const int32_t* actions,
+                                    int32_t batch, int32_t* status_out) {
+    if (!e || !boards || !turns || !legal || !actions || !status_out || batch < 1) return OMOK_ERR_INVALID;
+    ENTER(e);
+    uint8_t *d_boards = nullptr, *d_turns = nullptr;
+    uint16_t* d_legal = nullptr;
+    int32_t *d_act = nullptr, *d_status = nullptr;
+    const size_t B = (size_t)batch;
+    HIPCHK(e, hipMalloc((void**)&d_boards, B * e->hw));
+    HIPCHK(e, hipMalloc((void**)&d_turns, B));
+    HIPCHK(e, hipMalloc((void**)&d_legal, B * 2));
+    HIPCHK(e, hipMalloc((void**)&d_act, B * 4));
+    HIPCHK(e, hipMalloc((void**)&d_status, B * 4));
+    hipMemcpyAsync(d_boards, boards, B * e->hw, hipMemcpyHostToDevice, e->st);
+    hipMemcpyAsync(d_turns, turns, B, hipMemcpyHostToDevice, e->st);
+    hipMemcpyAsync(d_legal, legal, B * 2, hipMemcpyHostToDevice, e->st);
+    hipMemcpyAsync(d_act, actions, B * 4, hipMemcpyHostToDevice, e->st);
+    launch_env_place(e->n, d_boards, d_turns, d_legal, d_act, batch, d_status, e->st);
+    hipMemcpyAsync(boards, d_boards, B * e->hw, hipMemcpyDeviceToHost, e->st);
+    hipMemcpyAsync(turns, d_turns, B, hipMemcpyDeviceToHost, e->st);
+    hipMemcpyAsync(legal, d_legal, B * 2, hipMemcpyDeviceToHost, e->st);
+    hipMemcpyAsync(status_out, d_status, B * 4, hipMemcpyDeviceToHost, e->st);
+    const int rc = sync_and_check(e, "env_place_stone");
+    hipFree(d_boards); hipFree(d_turns); hipFree(d_legal); hipFree(d_act); hipFree(d_status);
+    return rc ? OMOK_ERR_HIP : OMOK_OK;
+}
+
 // ---- step-wise API (parity tests) --------------------------------------------------------------
 extern "C" int omok_round_generate(omok_engine* e, int32_t round, int32_t batch_size, float epsilon, float alpha, int32_t* n_requests) {
     if (!e) return OMOK_ERR_INVALID;
@@ -684,11 +861,12 @@ static int inject_outputs(omok_engine* e, int cnt, const float* p, const float* 
 
 extern "C" int omok_round_inputs(omok_engine* e, float* inputs) {
     if (!e || !inputs) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
     return requests_to_inputs(e, e->round_reqs, inputs);
 }
 extern "C" int omok_round_eval(omok_engine* e) {
-    if (!e) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (need_net(e)) return OMOK_ERR_STATE;
     if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
     if (e->round_reqs == 0) return OMOK_OK;
@@ -697,16 +875,18 @@ extern "C" int omok_round_eval(omok_engine* e) {
 }
 extern "C" int omok_round_outputs(omok_engine* e, float* p, float* v) {
     if (!e || !p) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
     return outputs_to_host(e, e->round_reqs, p, v);
 }
 extern "C" int omok_round_inject(omok_engine* e, const float* p, const float* v) {
     if (!e || !p || !v) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
     return inject_outputs(e, e->round_reqs, p, v);
 }
 extern "C" int omok_round_scatter(omok_engine* e) {
-    if (!e) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
     if (e->round_reqs > 0) launch_scatter(e->n, e->S, e->ply & 1, e->net.p, e->net.v, e->round_reqs, e->st);
     e->round_reqs = -1;
@@ -714,7 +894,7 @@ extern "C" int omok_round_scatter(omok_engine* e) {
 }
 
 extern "C" int omok_mirror_generate(omok_engine* e, int32_t* n_requests) {
-    if (!e) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (need_reset(e)) return OMOK_ERR_STATE;
     if (!e->sampled) return fail(e, OMOK_ERR_STATE, "omok_sample_actions must precede the mirror step");
     launch_mirror_scan(e->n, e->S, e->ply & 1, e->st);
@@ -728,11 +908,12 @@ extern "C" int omok_mirror_generate(omok_engine* e, int32_t* n_requests) {
 }
 extern "C" int omok_mirror_inputs(omok_engine* e, float* inputs) {
     if (!e || !inputs) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (e->mirror_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated mirror batch");
     return requests_to_inputs(e, e->mirror_reqs, inputs);
 }
 extern "C" int omok_mirror_eval(omok_engine* e) {
-    if (!e) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (need_net(e)) return OMOK_ERR_STATE;
     if (e->mirror_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated mirror batch");
     if (e->mirror_reqs > 0) net_forward_requests(e->net, e->S, e->mirror_reqs, e->st, &e->prof);
@@ -740,16 +921,18 @@ extern "C" int omok_mirror_eval(omok_engine* e) {
 }
 extern "C" int omok_mirror_outputs(omok_engine* e, float* p) {
     if (!e || !p) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (e->mirror_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated mirror batch");
     return outputs_to_host(e, e->mirror_reqs, p, nullptr);
 }
 extern "C" int omok_mirror_inject(omok_engine* e, const float* p) {
     if (!e || !p) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (e->mirror_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated mirror batch");
     return inject_outputs(e, e->mirror_reqs, p, nullptr);
 }
 extern "C" int omok_mirror_apply(omok_engine* e) {
-    if (!e) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (e->mirror_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated mirror batch");
     uint32_t bits = 0, before = 0, after = 0;
     if (read_status(e, &bits, &before)) return OMOK_ERR_HIP;
@@ -765,7 +948,7 @@ extern "C" int omok_mirror_apply(omok_engine* e) {
 
 // ---- inspection ----------------------------------------------------------------------------------
 extern "C" int omok_alive_count(omok_engine* e) {
-    if (!e) return OMOK_ERR_INVALID;
+    ENTER(e);
     uint32_t bits = 0, alive = 0;
     if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
     return (int)alive;
@@ -774,6 +957,7 @@ extern "C" int omok_current_ply(omok_engine* e) { return e ? e->ply : OMOK_ERR_I
 
 extern "C" int omok_game_info(omok_engine* e, uint8_t* alive, uint8_t* status, int32_t* plies) {
     if (!e) return OMOK_ERR_INVALID;
+    ENTER(e);
     std::vector<GameState> gs((size_t)e->cfg.games);
     HIPCHK(e, hipMemcpyAsync(gs.data(), e->S.gs, sizeof(GameState) * gs.size(), hipMemcpyDeviceToHost, e->st));
     if (sync_and_check(e, "game_info")) return OMOK_ERR_HIP;
@@ -787,6 +971,7 @@ extern "C" int omok_game_info(omok_engine* e, uint8_t* alive, uint8_t* status, i
 
 extern "C" int omok_tree_root(omok_engine* e, int32_t game, int32_t side, uint32_t* root_n, float* root_w, int32_t* n_nodes, int32_t* n_tables) {
     if (!e || game < 0 || game >= e->cfg.games || (side != 0 && side != 1)) return OMOK_ERR_INVALID;
+    ENTER(e);
     TreeState ts;
     HIPCHK(e, hipMemcpyAsync(&ts, e->S.ts + (size_t)side * e->cfg.games + game, sizeof(ts), hipMemcpyDeviceToHost, e->st));
     if (sync_and_check(e, "tree_root")) return OMOK_ERR_HIP;
@@ -799,6 +984,7 @@ extern "C" int omok_tree_root(omok_engine* e, int32_t game, int32_t side, uint32
 
 extern "C" int omok_tree_dump(omok_engine* e, int32_t game, int32_t side, int32_t* ints, float* floats, int32_t cap_nodes) {
     if (!e || !ints || !floats || game < 0 || game >= e->cfg.games || (side != 0 && side != 1)) return OMOK_ERR_INVALID;
+    ENTER(e);
     const size_t t = (size_t)side * e->cfg.games + game;
     TreeState ts;
     HIPCHK(e, hipMemcpyAsync(&ts, e->S.ts + t, sizeof(ts), hipMemcpyDeviceToHost, e->st));
@@ -853,10 +1039,11 @@ extern "C" int omok_tree_dump(omok_engine* e, int32_t game, int32_t side, int32_
 
 extern "C" int omok_replay_game(omok_engine* e, int32_t game, uint8_t* boards, uint8_t* turns, float* pi, float* z, int32_t cap_plies) {
     if (!e || game < 0 || game >= e->cfg.games) return OMOK_ERR_INVALID;
+    ENTER(e);
     GameState gs;
     HIPCHK(e, hipMemcpyAsync(&gs, e->S.gs + game, sizeof(gs), hipMemcpyDeviceToHost, e->st));
     if (sync_and_check(e, "replay_game")) return OMOK_ERR_HIP;
-    const int plies = gs.plies < e->hw ? gs.plies : e->hw;
+    const int plies = gs.rp_len < e->hw ? gs.rp_len : e->hw;
     const int n = plies < cap_plies ? plies : cap_plies;
     if (n <= 0) return plies;
     const size_t rp = (size_t)e->rowp, nw2 = 2 * (size_t)e->nw, hw = (size_t)e->hw;
@@ -886,10 +1073,11 @@ extern "C" int32_t omok_replay_record_bytes(const omok_engine* e) {
 
 extern "C" int64_t omok_replay_pack_dev(omok_engine* e, void* dst_dev, int64_t cap_records) {
     if (!e || !dst_dev || cap_records < 0) return OMOK_ERR_INVALID;
-    hipMemsetAsync(e->d_pack_total, 0, 16, e->st);
-    launch_replay_pack(e->n, e->S, (uint8_t*)dst_dev, cap_records, e->d_pack_total, e->st);
+    if (hipSetDevice(e->cfg.device) != hipSuccess) return OMOK_ERR_HIP;
+    launch_replay_offsets(e->n, e->S, 1, e->d_aug_offsets, e->st);
+    launch_replay_pack(e->n, e->S, e->d_aug_offsets, (uint8_t*)dst_dev, cap_records, e->st);
     long long total = 0;
-    if (hipMemcpyAsync(&total, e->d_pack_total, 8, hipMemcpyDeviceToHost, e->st) != hipSuccess) return OMOK_ERR_HIP;
+    if (hipMemcpyAsync(&total, e->d_aug_offsets + e->cfg.games, 8, hipMemcpyDeviceToHost, e->st) != hipSuccess) return OMOK_ERR_HIP;
     if (sync_and_check(e, "replay_pack")) return OMOK_ERR_HIP;
     return total;
 }
@@ -898,7 +1086,7 @@ extern "C" int64_t omok_replay_pack_dev(omok_engine* e, void* dst_dev, int64_t c
 extern "C" int64_t omok_replay_augment_dev(omok_engine* e, void* dst_dev, int64_t cap_records) {
     if (!e || !dst_dev || cap_records < 0) return OMOK_ERR_INVALID;
     if (hipSetDevice(e->cfg.device) != hipSuccess) return OMOK_ERR_HIP;
-    launch_replay_offsets(e->n, e->S, e->d_aug_offsets, e->st);
+    launch_replay_offsets(e->n, e->S, 6, e->d_aug_offsets, e->st);
     launch_replay_augment(e->n, e->S, e->d_aug_offsets, 0, e->cfg.games, 0, (uint8_t*)dst_dev, cap_records, e->st);
     long long total = 0;
     if (hipMemcpyAsync(&total, e->d_aug_offsets + e->cfg.games, 8, hipMemcpyDeviceToHost, e->st) != hipSuccess) return OMOK_ERR_HIP;
@@ -912,7 +1100,7 @@ extern "C" int omok_replay_augmented_game(omok_engine* e, int32_t game, uint8_t*
     const size_t hw = (size_t)e->hw, brd = (hw + 1 + 3) / 4 * 4, rec = brd + 4 * hw + 4, max_rec = 6 * hw;
     if (!e->d_aug_scratch && dalloc(e, &e->d_aug_scratch, max_rec * rec)) return OMOK_ERR_HIP;
     long long off[2] = {0, 0};
-    launch_replay_offsets(e->n, e->S, e->d_aug_offsets, e->st);
+    launch_replay_offsets(e->n, e->S, 6, e->d_aug_offsets, e->st);
     HIPCHK(e, hipMemcpyAsync(off, e->d_aug_offsets + game, 16, hipMemcpyDeviceToHost, e->st));
     if (sync_and_check(e, "replay_augmented_game")) return OMOK_ERR_HIP;
     const int total = (int)(off[1] - off[0]);
@@ -961,7 +1149,7 @@ extern "C" int omok_get_stats(omok_engine* e, double* stats) {
 }
 
 extern "C" int omok_reset_stats(omok_engine* e) {
-    if (!e) return OMOK_ERR_INVALID;
+    ENTER(e);
     if (sync_and_check(e, "reset_stats")) return OMOK_ERR_HIP;
     e->prof.resolve();
     for (int i = 0; i < PC_COUNT; ++i) { e->prof.ms[i] = 0; e->prof.launches[i] = 0; }

@@ -12,6 +12,7 @@ constexpr int NF = 512; // FC_0_SIZE / FC_1_SIZE (:29-30)
 
 struct Net {
     int n = 0, hw = 0, rowp = 0, mode = 0;
+    int device = 0;   // HIP device ordinal (keys the per-device launch caches)
     int max_b = 0;
     bool committed = false;
     bool loaded[NET_TENSORS] = {};
@@ -20,6 +21,7 @@ struct Net {
     // outputs: p [max_b][ROWP] softmax probabilities (pad cells 0), v [max_b]
     float* p = nullptr;
     float* v = nullptr;
+    float* vpre = nullptr; // [max_b] value head before tanh (omok_evaluate_logits)
     float* in_f32 = nullptr; // [max_b][3*HW] encoder.rs layout (evaluate_pv / step-wise API / f32 path)
     // ---- OMOK_NET_F32 scratch (chunked) ----
     int chunk = 0;
@@ -71,6 +73,8 @@ void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t s
 void net_forward_inputs(Net& net, const Store& S, int count, hipStream_t st, struct Prof* prof);
 // Packs the raw tensors into the MFMA operand layouts (host-side repack + upload).
 int net_commit(Net& net, hipStream_t st);
+// pre-softmax policy logits of the LAST forward (rows of the last chunk in OMOK_NET_F32 mode): pointer and row stride in floats
+const float* net_logits(const Net& net, int* row_stride);
 size_t net_alloc(Net& net); // allocates buffers for net.max_b; returns bytes, 0 on failure
 void net_free(Net& net);
 

@@ -163,6 +163,13 @@ __global__ void k32_softmax(const float* __restrict__ logits, float* __restrict_
     for (int a = lane; a < rowp; a += 64) po[a] = a < hw ? expf(l[a] - mx) / sum : 0.0f;
 }
 
+__global__ void k32_tanh(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ d_count, int base, int chunk) {
+    int cnt = d_count[0] - base;
+    if (cnt > chunk) cnt = chunk;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) out[i] = tanhf(in[i]);
+}
+
 static void forward_f32(Net& net, const Store& S, int max_count, hipStream_t st, Prof* prof) {
     const int hw = net.hw, n = net.n;
     const int grid = 2048, blk = 256;
@@ -182,7 +189,8 @@ static void forward_f32(Net& net, const Store& S, int max_count, hipStream_t st,
         k32_linear<1><<<grid, blk, 0, st>>>(net.sx, net.w[23], net.w[24], nullptr, net.s0, 1, NC * hw, NF, S.d_count, base, ch);
         if (prof) { prof->end(st); prof->begin(PC_TAIL, st); }
         k32_linear<1><<<grid, blk, 0, st>>>(net.s0, net.w[25], net.w[26], nullptr, net.s1, 1, NF, NF, S.d_count, base, ch);
-        k32_linear<3><<<grid, blk, 0, st>>>(net.s1, net.w[27], net.w[28], nullptr, net.v + base, 1, NF, 1, S.d_count, base, ch);
+        k32_linear<0><<<grid, blk, 0, st>>>(net.s1, net.w[27], net.w[28], nullptr, net.vpre + base, 1, NF, 1, S.d_count, base, ch);
+        k32_tanh<<<(ch + 255) / 256, 256, 0, st>>>(net.vpre + base, net.v + base, S.d_count, base, ch);
         k32_linear<0><<<grid, blk, 0, st>>>(net.s1, net.w[29], net.w[30], nullptr, net.sh, 1, NF, hw, S.d_count, base, ch);
         k32_softmax<<<ch, 64, 0, st>>>(net.sh, net.p, hw, net.rowp, S.d_count, base, ch);
         if (prof) prof->end(st);
@@ -1190,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__
 
 // policy softmax (network.rs:236-247) + value tanh (network.rs:197-200); one wave per sample
 __global__ __launch_bounds__(64) void k_softmax(const float* __restrict__ logits, int lrow, int hw, int rowp, float* __restrict__ p,
-                                                float* __restrict__ v, const int32_t* __restrict__ d_count, int max_count) {
+                                                float* __restrict__ v, float* __restrict__ vpre, const int32_t* __restrict__ d_count, int max_count) {
     int count = d_count[0];
     if (count > max_count) count = max_count;
     const int lane = threadIdx.x;
@@ -1211,7 +1219,7 @@ __global__ __launch_bounds__(64) void k_softmax(const float* __restrict__ logits
             const int a = lane + 64 * i;
             if (a < rowp) p[(size_t)s * rowp + a] = a < hw ? e[i] / sum : 0.0f;
         }
-        if (lane == 0) v[s] = tanhf(l[hw]);
+        if (lane == 0) { v[s] = tanhf(l[hw]); vpre[s] = l[hw]; }
     }
 }
 
@@ -1293,6 +1301,12 @@ static int mx6_scale_byte(float amax) {
 
 static int heads_mt(int hw) { return ((hw + 1 + 31) / 32 + 3) / 4 * 4; }
 
+const float* net_logits(const Net& net, int* row_stride) {
+    if (net.mode == OMOK_NET_F32) { *row_stride = net.hw; return net.sh; } // forward_f32 leaves the chunk's logits in sh
+    *row_stride = heads_mt(net.hw) * 32;
+    return net.s0;
+}
+
 size_t net_alloc(Net& net) {
     const size_t hw = net.hw, rp = net.rowp;
     const size_t mb = ((size_t)net.max_b + GT_BS - 1) / GT_BS * GT_BS;
@@ -1308,6 +1322,7 @@ size_t net_alloc(Net& net) {
     ok = ok && A((void**)&net.d_chunk, sizeof(int32_t) * 64 * 4);
     ok = ok && A((void**)&net.p, sizeof(float) * mb * rp);
     ok = ok && A((void**)&net.v, sizeof(float) * mb);
+    ok = ok && A((void**)&net.vpre, sizeof(float) * mb);
     ok = ok && A((void**)&net.in_f32, sizeof(float) * mb * 3 * hw);
     if (net.mode == OMOK_NET_F32) {
         net.chunk = (int)std::min<size_t>(mb, 1024);
@@ -1339,7 +1354,7 @@ size_t net_alloc(Net& net) {
 }
 
 void net_free(Net& net) {
-    void** ptrs[] = {(void**)&net.p, (void**)&net.v, (void**)&net.in_f32, (void**)&net.sx, (void**)&net.sh, (void**)&net.sd,
+    void** ptrs[] = {(void**)&net.p, (void**)&net.v, (void**)&net.vpre, (void**)&net.in_f32, (void**)&net.sx, (void**)&net.sh, (void**)&net.sd,
                      (void**)&net.sg, (void**)&net.s0, (void**)&net.s1, &net.wt_trunk, (void**)&net.wt_first, &net.wt_fc0,
                      &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part, (void**)&net.d_chunk};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
@@ -1488,11 +1503,11 @@ int net_commit(Net& net, hipStream_t st) {
 template <int N, bool FROM_F32, int ABL = 0>
 static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st) {
     using TG = TrunkGeo<N>;
-    static bool attr_done = false;
+    static bool attr_done[64] = {}; // per device: the attribute belongs to the device's copy of the code object
     auto kern = k_trunk<N, FROM_F32, ABL>;
-    if (!attr_done) {
+    if (!attr_done[net.device & 63]) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TG::LDS_BYTES);
-        attr_done = true;
+        attr_done[net.device & 63] = true;
     }
     const int wgs = (max_count + TG::SPW - 1) / TG::SPW;
     const int grid = wgs < 256 ? wgs : 256;
@@ -1502,13 +1517,13 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
 template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
 static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_row_u4, int k_full, int last_cnt, int lo_off,
                         const float* bias, void* out_split, size_t out_row_u4, float* out_logits, const Store& S, int max_count,
-                        hipStream_t st, int nsplit = 1) {
+                        hipStream_t st, int device, int nsplit = 1) {
     constexpr int LDS = (MT * 2 + 8) * 1024 * NST;
-    static bool attr_done = false;
+    static bool attr_done[64] = {};
     auto kern = k_gemm_t<MT, EPI, TAG, NST, PRIO>;
-    if (!attr_done) {
+    if (!attr_done[device & 63]) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_done = true;
+        attr_done[device & 63] = true;
     }
     const dim3 grid((max_count + GT_BS - 1) / GT_BS, nsplit);
     kern<<<grid, 512, LDS, st>>>((const uint4*)wp, (const uint4*)act, ksteps, act_row_u4, k_full, last_cnt, lo_off, bias, (uint4*)out_split,
@@ -1548,11 +1563,11 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
         // their parallelism from d alone.  d must divide the super-step count and its fp32 partials must fit the slab.
         int nsplit = 1;
         {
-            static int n_cu = 0;
+            static int n_cu_dev[64] = {};
+            int& n_cu = n_cu_dev[net.device & 63];
             if (!n_cu) {
-                int dev = 0;
                 hipDeviceProp_t prop;
-                n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+                n_cu = (hipGetDeviceProperties(&prop, net.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
             }
             double best = 1e30;
             for (int d = 1; d <= 16; ++d) {
@@ -1583,12 +1598,12 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
         }
     }
     if (prof) { prof->end(st); prof->begin(PC_TAIL, st); }
-    launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st);
+    launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st, net.device);
     const int MT = heads_mt(hw);
-    if (MT == 8) launch_gemm<8, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st);
-    else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st);
+    if (MT == 8) launch_gemm<8, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
+    else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
     const int sg = max_count < 32768 ? max_count : 32768; // one wave per row up to 32 waves per SIMD: the row loop is a chain of dependent loads
-    k_softmax<<<sg, 64, 0, st>>>(net.s0, MT * 32, hw, net.rowp, net.p, net.v, S.d_count, max_count);
+    k_softmax<<<sg, 64, 0, st>>>(net.s0, MT * 32, hw, net.rowp, net.p, net.v, net.vpre, S.d_count, max_count);
     if (prof) prof->end(st);
 }
 
@@ -1628,6 +1643,7 @@ static void forward_chunked(Net& net, const Store& S, int max_count, bool from_f
         S2.d_count = net.d_chunk + 4 * c;
         v.p += (size_t)base * net.rowp;
         v.v += base;
+        v.vpre += base;
         v.in_f32 += (size_t)base * 3 * net.hw;
         forward_f16x3(v, S2, mc, from_f32, st, prof);
     }

@@ -643,7 +643,8 @@ __global__ __launch_bounds__(64) void k_reset(Store S, const float* __restrict__
         TreeState s{1u, 0u, 0u, 0.0f, 0u, 0u, 0u, 0u};
         *T.ts = s;
         if (t < S.games) {
-            GameState gs{1, ST_IN_PROGRESS, 0, 0, 0, -1, -1};
+            GameState gs{};
+            gs.alive = 1; gs.status = ST_IN_PROGRESS; gs.last_action = -1; gs.mirror_idx = -1;
             S.gs[t] = gs;
         }
     }
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(64) void k_sample(Store S, int side, int ply, float
 #pragma unroll
     for (int j = 0; j < G::IT; ++j) pi[j] = (float)nv[j] * sum_inv;
     int action;
-    const int plies = S.gs[g].plies;
+    const int plies = S.gs[g].rp_len; // turn_counts[index] (trainer.rs:139): moves sampled so far = transitions recorded
     if (plies < threshold) { // Boltzmann (agent.rs:106-133)
         const float tinv = __fdiv_rn(1.0f, temperature);
 #pragma unroll
@@ -746,7 +747,72 @@ __global__ __launch_bounds__(64) void k_sample(Store S, int side, int ply, float
         for (int j = 0; j < G::IT; ++j) S.rp_pi[rec * ROWP + j * 64 + lane] = pi[j];
         if (lane == 0) { S.rp_turn[rec] = h0.turn; S.rp_z[rec] = 0.0f; }
     }
-    if (lane == 0) { actions[g] = action; S.gs[g].last_action = action; }
+    if (lane == 0) { actions[g] = action; S.gs[g].last_action = action; S.gs[g].external = 0; }
+}
+
+// Agent::compute_policy (agent.rs:43-77) of the side-to-move agent of every game: pi [G][HW], has [G] (0 = None: finished
+// game, no children or no visits)
+template <int N>
+__global__ __launch_bounds__(64) void k_policy(Store S, int side, float* __restrict__ pi, uint8_t* __restrict__ has) {
+    using G = Geo<N>;
+    constexpr int ROWP = G::ROWP;
+    const int g = blockIdx.x;
+    const int lane = LANE;
+    const Tree<N> T(S, side * S.games + g);
+    const NodeHdr h0 = T.hdr[0];
+    uint32_t nv[G::IT];
+    uint32_t tot = 0;
+    const bool any = S.gs[g].alive && h0.table != NONE16 && h0.nch != 0;
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        nv[j] = (any && T.corder[(size_t)h0.table * ROWP + a] != NONE8) ? T.cn[(size_t)h0.table * ROWP + a] : 0u;
+        tot += nv[j];
+    }
+    tot = wave_sum_u32(tot);
+    const float sum = (float)tot;
+    const bool some = any && !(sum < F32_EPS);
+    const float sum_inv = some ? __fdiv_rn(1.0f, sum) : 0.0f;
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        if (a < G::HW) pi[(size_t)g * G::HW + a] = some ? (float)nv[j] * sum_inv : 0.0f;
+    }
+    if (lane == 0) has[g] = some ? 1 : 0;
+}
+
+// omok_play_actions: externally chosen moves (gui/src/agent.rs:49-66, benchmark/src/agent.rs:34-50 style callers) take the
+// place of k_sample.  flags[0] counts illegal moves (out of range / occupied cell: Option::None of place_stone,
+// environment/src/lib.rs:105-107), flags[1] live games without a move.  Nothing is recorded: the trainer pushes a Transition
+// only for moves it sampled (trainer.rs:138-173).
+template <int N>
+__global__ __launch_bounds__(256) void k_set_actions(Store S, int side, const int32_t* __restrict__ actions, uint32_t* __restrict__ flags) {
+    using G = Geo<N>;
+    constexpr int NW = G::NW;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= S.games) return;
+    GameState gs = S.gs[g];
+    gs.last_action = -1;
+    gs.external = 1;
+    if (gs.alive) {
+        const int a = actions[g];
+        if (a < 0) atomicAdd(&flags[1], 1u);
+        else if (a >= G::HW) atomicAdd(&flags[0], 1u);
+        else {
+            const uint64_t* bb = S.board + (size_t)(side * S.games + g) * (size_t)S.cap_nodes * (2 * NW); // root = node 0
+            const uint64_t occ = bb[a >> 6] | bb[NW + (a >> 6)];
+            if ((occ >> (a & 63)) & 1ULL) atomicAdd(&flags[0], 1u);
+            else gs.last_action = a;
+        }
+    }
+    S.gs[g] = gs;
+}
+__global__ __launch_bounds__(256) void k_clear_actions(Store S) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= S.games) return;
+    S.gs[g].last_action = -1;
+    S.gs[g].external = 0;
+    S.gs[g].mirror_idx = -1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -917,6 +983,49 @@ __device__ int transition(const Store& S, const Tree<N>& T, int action, uint8_t*
     return 0;
 }
 
+// Agent::ensure_action_exists (agent.rs:144-197) on tree T: p_row = evaluate_p of (root position + action, Opponent mode)
+template <int N>
+__device__ void ensure_action_exists(const Store& S, const Tree<N>& T, int action, const float* __restrict__ p_row, float* s_row) {
+    using G = Geo<N>;
+    constexpr int ROWP = G::ROWP, NW = G::NW;
+    const int lane = LANE;
+    const NodeHdr h0 = T.hdr[0];
+    uint64_t bb[2 * NW];
+#pragma unroll
+    for (int i = 0; i < 2 * NW; ++i) bb[i] = T.board[i];
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        const bool empty = a < G::HW && !(((bb[j] | bb[NW + j]) >> lane) & 1ULL);
+        s_row[a] = (empty && a != action) ? p_row[a] : 0.0f; // agent.rs:166-171
+    }
+    __syncthreads();
+    const float sum = seq_sum(s_row, G::HW);
+    const bool renorm = F32_EPS <= sum;
+    const float inv = renorm ? __fdiv_rn(1.0f, sum) : 1.0f;
+    const bool exists = h0.table != NONE16 && T.corder[(size_t)h0.table * ROWP + action] != NONE8;
+    if (!exists) { // node.rs:69-71 returns None when the child is already there
+        const TreeState ts = *T.ts;
+        Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
+        if (!get_bit<NW>(bb, action) && !get_bit<NW>(bb + NW, action)) (void)place_and_status<N>(bb, h0.turn, h0.legal, action);
+        const int idx = add_child<N>(S, T, R, 0, h0, action, bb, ST_IN_PROGRESS, 1 - h0.turn, 1);
+        if (idx >= 0) {
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) {
+                const int a = j * 64 + lane;
+                const float x = s_row[a];
+                T.pol[(size_t)idx * ROWP + a] = renorm ? x * inv : x;
+            }
+        }
+        if (lane == 0) {
+            TreeState o = ts;
+            o.n_nodes = R.n_nodes; o.n_tables = R.n_tables; o.error = R.error;
+            *T.ts = o;
+        }
+    }
+    __syncthreads();
+}
+
 template <int N>
 __global__ __launch_bounds__(64) void k_advance(Store S, int side, const float* __restrict__ P) {
     using G = Geo<N>;
@@ -933,45 +1042,11 @@ __global__ __launch_bounds__(64) void k_advance(Store S, int side, const float* 
     const int action = gs.last_action;
     const Tree<N> own(S, side * S.games + g);
     const Tree<N> opp(S, (1 - side) * S.games + g);
-    // ---- opposite_agent.ensure_action_exists (agent.rs:144-197) on the pre-move root ----
-    {
-        const NodeHdr h0 = opp.hdr[0];
-        uint64_t bb[2 * NW];
-#pragma unroll
-        for (int i = 0; i < 2 * NW; ++i) bb[i] = opp.board[i];
-        const size_t d = (size_t)gs.mirror_idx;
-#pragma unroll
-        for (int j = 0; j < G::IT; ++j) {
-            const int a = j * 64 + lane;
-            const bool empty = a < G::HW && !(((bb[j] | bb[NW + j]) >> lane) & 1ULL);
-            s_row[a] = (empty && a != action) ? P[d * ROWP + a] : 0.0f; // agent.rs:166-171
-        }
-        __syncthreads();
-        const float sum = seq_sum(s_row, G::HW);
-        const bool renorm = F32_EPS <= sum;
-        const float inv = renorm ? __fdiv_rn(1.0f, sum) : 1.0f;
-        const bool exists = h0.table != NONE16 && opp.corder[(size_t)h0.table * ROWP + action] != NONE8;
-        if (!exists) { // node.rs:69-71 returns None when the child is already there
-            const TreeState ts = *opp.ts;
-            Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
-            if (!get_bit<NW>(bb, action) && !get_bit<NW>(bb + NW, action)) (void)place_and_status<N>(bb, h0.turn, h0.legal, action);
-            const int idx = add_child<N>(S, opp, R, 0, h0, action, bb, ST_IN_PROGRESS, 1 - h0.turn, 1);
-            if (idx >= 0) {
-#pragma unroll
-                for (int j = 0; j < G::IT; ++j) {
-                    const int a = j * 64 + lane;
-                    const float x = s_row[a];
-                    opp.pol[(size_t)idx * ROWP + a] = renorm ? x * inv : x;
-                }
-            }
-            if (lane == 0) {
-                TreeState o = ts;
-                o.n_nodes = R.n_nodes; o.n_tables = R.n_tables; o.error = R.error;
-                *opp.ts = o;
-            }
-        }
-        __syncthreads();
-    }
+    // ---- ensure_action_exists (agent.rs:144-197) on the pre-move root: always for the opposite agent (trainer.rs:163-166);
+    //      an externally supplied move need not be in the mover's own tree either, so it gets the same treatment there (both
+    //      agents hold the same position, hence the same evaluate_p row) ----
+    if (gs.external) ensure_action_exists<N>(S, own, action, P + (size_t)gs.mirror_idx * ROWP, s_row);
+    ensure_action_exists<N>(S, opp, action, P + (size_t)gs.mirror_idx * ROWP, s_row);
     // ---- agent.play_action (agent.rs:206-232): status from the real rules on the root board ----
     int status;
     {
@@ -987,8 +1062,12 @@ __global__ __launch_bounds__(64) void k_advance(Store S, int side, const float* 
     if (lane == 0) {
         if (err) own.ts->error |= (uint32_t)err;
         GameState o = gs;
-        if (gs.plies < G::HW)
-            S.rp_z[(size_t)g * G::HW + gs.plies] = (status == ST_BLACK_WIN || status == ST_WHITE_WIN) ? 1.0f : 0.0f;
+        if (!gs.external) { // transitions.push (trainer.rs:169-173): only moves the trainer sampled
+            if (gs.rp_len < G::HW)
+                S.rp_z[(size_t)g * G::HW + gs.rp_len] = (status == ST_BLACK_WIN || status == ST_WHITE_WIN) ? 1.0f : 0.0f;
+            o.rp_len = gs.rp_len + 1;
+        }
+        o.external = 0;
         o.plies = gs.plies + 1;
         o.status = (uint8_t)status;
         o.alive = status == ST_IN_PROGRESS ? 1 : 0;
@@ -1086,6 +1165,37 @@ __global__ __launch_bounds__(64) void k_env_play(const int32_t* __restrict__ mov
     if (lane == 0) { turns[b] = (uint8_t)turn; legal[b] = (uint16_t)lg; }
 }
 
+// Environment::place_stone (environment/src/lib.rs:104-166) on caller-held environments: boards [B][HW] Stone bytes, turns [B],
+// legal [B] are updated in place; status [B] = Option<GameStatus> (-1 = None: out of range or occupied, nothing changes)
+template <int N>
+__global__ __launch_bounds__(64) void k_env_place(uint8_t* __restrict__ boards, uint8_t* __restrict__ turns, uint16_t* __restrict__ legal,
+                                                  const int32_t* __restrict__ actions, int32_t* __restrict__ status_out) {
+    using G = Geo<N>;
+    constexpr int NW = G::NW;
+    const int b = blockIdx.x;
+    const int lane = LANE;
+    uint64_t bb[2 * NW];
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        const int s = a < G::HW ? boards[(size_t)b * G::HW + a] : 0;
+        bb[j] = __ballot(s == 1);
+        bb[NW + j] = __ballot(s == 2);
+    }
+    const int turn = turns[b] & 1, lg = legal[b];
+    const int a = actions[b];
+    int st = -1;
+    if (a >= 0 && a < G::HW && !get_bit<NW>(bb, a) && !get_bit<NW>(bb + NW, a)) {
+        st = place_and_status<N>(bb, turn, lg, a);
+        if (lane == 0) {
+            boards[(size_t)b * G::HW + a] = (uint8_t)(turn == 0 ? 1 : 2);
+            turns[b] = (uint8_t)(1 - turn);
+            legal[b] = (uint16_t)(lg - 1);
+        }
+    }
+    if (lane == 0) status_out[b] = st;
+}
+
 template <int N>
 __global__ __launch_bounds__(256) void k_encode_boards(const uint8_t* __restrict__ boards, const uint8_t* __restrict__ turns,
                                                        int mode, float* __restrict__ out) {
@@ -1106,18 +1216,17 @@ __global__ __launch_bounds__(256) void k_encode_boards(const uint8_t* __restrict
     }
 }
 
-// replay tuples packed for an RCCL gather: board u8[HW], turn u8, pad to 4, pi f32[HW], z f32
+// replay tuples packed for an RCCL gather: board u8[HW], turn u8, pad (zero) to 4, pi f32[HW], z f32; games in id order
+// (offsets = exclusive scan of the transition counts), transitions in play order: the packed buffer is deterministic
 template <int N>
-__global__ __launch_bounds__(64) void k_replay_pack(Store S, uint8_t* __restrict__ dst, long long cap, long long* __restrict__ d_total) {
+__global__ __launch_bounds__(64) void k_replay_pack(Store S, const long long* __restrict__ offsets, uint8_t* __restrict__ dst, long long cap) {
     using G = Geo<N>;
     constexpr int NW = G::NW, ROWP = G::ROWP;
     constexpr int BRD = (G::HW + 1 + 3) / 4 * 4, REC = BRD + 4 * G::HW + 4;
     const int g = blockIdx.x;
     const int lane = LANE;
-    const int plies = S.gs[g].plies < G::HW ? S.gs[g].plies : G::HW;
-    long long base = 0;
-    if (lane == 0) base = (long long)atomicAdd((unsigned long long*)d_total, (unsigned long long)plies);
-    base = __shfl(base, 0, 64);
+    const int plies = S.gs[g].rp_len < G::HW ? S.gs[g].rp_len : G::HW;
+    const long long base = offsets[g];
     for (int p = 0; p < plies; ++p) {
         if (base + p >= cap) break;
         uint8_t* r = dst + (size_t)(base + p) * REC;
@@ -1131,10 +1240,8 @@ __global__ __launch_bounds__(64) void k_replay_pack(Store S, uint8_t* __restrict
                 ((float*)(r + BRD))[a] = S.rp_pi[rec * ROWP + a];
             }
         }
-        if (lane == 0) {
-            r[G::HW] = S.rp_turn[rec];
-            ((float*)(r + BRD))[G::HW] = S.rp_z[rec];
-        }
+        if (lane < BRD - G::HW) r[G::HW + lane] = lane == 0 ? S.rp_turn[rec] : (uint8_t)0;
+        if (lane == 0) ((float*)(r + BRD))[G::HW] = S.rp_z[rec];
     }
 }
 
@@ -1146,13 +1253,13 @@ __global__ __launch_bounds__(64) void k_replay_pack(Store S, uint8_t* __restrict
 // (replay_memory.extend(transitions), :320), then the 5L augmented ones, transition-major (:321).  Record layout as in
 // k_replay_pack.  offsets[g] = first record of game g (exclusive scan of 6 * plies).
 template <int N>
-__global__ void k_replay_offsets(Store S, long long* __restrict__ offsets) {
+__global__ void k_replay_offsets(Store S, int per_transition, long long* __restrict__ offsets) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     long long acc = 0;
     for (int g = 0; g < S.games; ++g) {
         offsets[g] = acc;
-        const int plies = S.gs[g].plies < Geo<N>::HW ? S.gs[g].plies : Geo<N>::HW;
-        acc += 6LL * plies;
+        const int plies = S.gs[g].rp_len < Geo<N>::HW ? S.gs[g].rp_len : Geo<N>::HW;
+        acc += (long long)per_transition * plies;
     }
     offsets[S.games] = acc;
 }
@@ -1178,7 +1285,7 @@ __global__ __launch_bounds__(64) void k_replay_augment(Store S, const long long*
     constexpr int BRD = (G::HW + 1 + 3) / 4 * 4, REC = BRD + 4 * G::HW + 4;
     const int g = game_first + blockIdx.y; // one wave per transition: grid = (HW plies, games)
     const int lane = LANE;
-    const int L = S.gs[g].plies < G::HW ? S.gs[g].plies : G::HW;
+    const int L = S.gs[g].rp_len < G::HW ? S.gs[g].rp_len : G::HW;
     const int p = blockIdx.x;
     if (p >= L) return;
     const long long base = offsets[g] - base_sub;
@@ -1206,10 +1313,8 @@ __global__ __launch_bounds__(64) void k_replay_augment(Store S, const long long*
                     ((float*)(r + BRD))[a] = S.rp_pi[rec * ROWP + s];
                 }
             }
-            if (lane == 0) {
-                r[G::HW] = turn; // env.turn is cloned unchanged (:224)
-                ((float*)(r + BRD))[G::HW] = z;
-            }
+            if (lane < BRD - G::HW) r[G::HW + lane] = lane == 0 ? turn : (uint8_t)0; // env.turn is cloned unchanged (:224); pad bytes zero
+            if (lane == 0) ((float*)(r + BRD))[G::HW] = z;
         }
     }
 }
@@ -1262,8 +1367,26 @@ void launch_encode_boards(int n, const uint8_t* boards, const uint8_t* turns, in
     DISPATCH_N(n, (k_encode_boards<9><<<batch, 256, 0, st>>>(boards, turns, mode, out)),
                (k_encode_boards<15><<<batch, 256, 0, st>>>(boards, turns, mode, out)));
 }
-void launch_replay_offsets(int n, const Store& S, long long* offsets, hipStream_t st) {
-    DISPATCH_N(n, (k_replay_offsets<9><<<1, 64, 0, st>>>(S, offsets)), (k_replay_offsets<15><<<1, 64, 0, st>>>(S, offsets)));
+void launch_replay_offsets(int n, const Store& S, int per_transition, long long* offsets, hipStream_t st) {
+    DISPATCH_N(n, (k_replay_offsets<9><<<1, 64, 0, st>>>(S, per_transition, offsets)), (k_replay_offsets<15><<<1, 64, 0, st>>>(S, per_transition, offsets)));
+}
+void launch_set_actions(int n, const Store& S, int side, const int32_t* actions, uint32_t* flags, hipStream_t st) {
+    const int grid = (S.games + 255) / 256;
+    DISPATCH_N(n, (k_set_actions<9><<<grid, 256, 0, st>>>(S, side, actions, flags)), (k_set_actions<15><<<grid, 256, 0, st>>>(S, side, actions, flags)));
+}
+void launch_clear_actions(const Store& S, hipStream_t st) { k_clear_actions<<<(S.games + 255) / 256, 256, 0, st>>>(S); }
+void launch_policy(int n, const Store& S, int side, float* pi, uint8_t* has, hipStream_t st) {
+    DISPATCH_N(n, (k_policy<9><<<S.games, 64, 0, st>>>(S, side, pi, has)), (k_policy<15><<<S.games, 64, 0, st>>>(S, side, pi, has)));
+}
+void launch_env_place(int n, uint8_t* boards, uint8_t* turns, uint16_t* legal, const int32_t* actions, int batch, int32_t* status, hipStream_t st) {
+    DISPATCH_N(n, (k_env_place<9><<<batch, 64, 0, st>>>(boards, turns, legal, actions, status)),
+               (k_env_place<15><<<batch, 64, 0, st>>>(boards, turns, legal, actions, status)));
+}
+// k_advance keeps 3 B per node and 2 B per table of re-rooting scratch in LDS: above 64 KiB the kernel needs the opt-in
+// attribute; returns 0 when `bytes` fits the device limit and the attribute is set for both board sizes
+int set_advance_lds_attribute(int n, size_t bytes) {
+    const void* f = n == 9 ? (const void*)k_advance<9> : (const void*)k_advance<15>;
+    return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
 }
 void launch_replay_augment(int n, const Store& S, const long long* offsets, int game_first, int game_count, long long base_sub,
                            uint8_t* dst, long long cap, hipStream_t st) {
@@ -1271,9 +1394,9 @@ void launch_replay_augment(int n, const Store& S, const long long* offsets, int 
     DISPATCH_N(n, (k_replay_augment<9><<<dim3(81, game_count), 64, 0, st>>>(S, offsets, game_first, base_sub, dst, cap)),
                (k_replay_augment<15><<<dim3(225, game_count), 64, 0, st>>>(S, offsets, game_first, base_sub, dst, cap)));
 }
-void launch_replay_pack(int n, const Store& S, uint8_t* dst, long long cap, long long* d_total, hipStream_t st) {
-    DISPATCH_N(n, (k_replay_pack<9><<<S.games, 64, 0, st>>>(S, dst, cap, d_total)),
-               (k_replay_pack<15><<<S.games, 64, 0, st>>>(S, dst, cap, d_total)));
+void launch_replay_pack(int n, const Store& S, const long long* offsets, uint8_t* dst, long long cap, hipStream_t st) {
+    DISPATCH_N(n, (k_replay_pack<9><<<S.games, 64, 0, st>>>(S, offsets, dst, cap)),
+               (k_replay_pack<15><<<S.games, 64, 0, st>>>(S, offsets, dst, cap)));
 }
 
 } // namespace omok

@@ -55,6 +55,9 @@ class Trainer:
         self.phase = T.TrainPhase(board_size, tensors, self.device)  # the optimizer state lives across iterations like the session's
         self.selfplay = api.SelfPlay(self.engine)
         self.iteration = 0
+        it_path = path + ".iteration"  # (not in the reference, whose thread_rng is fresh on every start): a resumed run must
+        if os.path.exists(it_path):    # not replay the RNG streams of the iterations it has already played
+            self.iteration = int(open(it_path).read().strip() or 0)
 
     def _engine_tensors(self):
         tmp = os.path.join(self.save_dir, f".{self.p.model_name}.rank{self.rank}.tmp")
@@ -68,6 +71,7 @@ class Trainer:
         p = self.p
         rec = self.selfplay.replay_record_bytes()
         for _ in range(iteration_count):
+            self.selfplay.set_episode(self.iteration)  # RNG stream of this iteration (key = seed + iteration * golden ratio)
             self.iteration += 1
             self.selfplay.reset()  # fresh agents; the engine's replay buffer is cleared with them (:77-93)
             stats = self.selfplay.run(p.evaluate_count, p.evaluate_batch_size, p.epsilon, p.alpha, p.temperature,
@@ -85,6 +89,8 @@ class Trainer:
             if self.rank == 0:  # Trainer::save (:605-626)
                 os.makedirs(self.save_dir, exist_ok=True)
                 self.engine.save(os.path.join(self.save_dir, p.model_name))
+                with open(os.path.join(self.save_dir, p.model_name + ".iteration"), "w") as f:
+                    f.write(str(self.iteration))
             log(f"[iter={self.iteration}] games={int(stats['finished'])} transitions={got} loss={loss:.4f} "
                 f"[v_loss={v_loss:.4f}, p_loss={p_loss:.4f}]")
         return v_loss, p_loss, loss
