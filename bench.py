@@ -287,11 +287,13 @@ def main():
         st = sp.run(args.sims, k, 0.25, 0.03, 1.0, 30, max_plies)
         if args.gather:
             t1 = time.perf_counter()
-            cnt = sp.replay_pack_into(gather_buf.data_ptr(), gather_buf.numel() // rec)
+            cnt = sp.pack_tensor(gather_buf, rec) if hasattr(sp, "pack_tensor") else sp.replay_pack_into(gather_buf.data_ptr(), gather_buf.numel() // rec)
             live = gather_buf[: cnt * rec].view(cnt, rec)
             allrec, counts = oa.dist.gather_replay(live)  # counts exchange + exact-size all-gather-v
             if use_cuda:
                 torch.cuda.synchronize()
+            gathered["last_counts"] = counts
+            gathered["last_ids"] = allrec[:, :8].contiguous().view(torch.int64).reshape(-1).tolist() if os.environ.get("OMOK_MOCK_DIR") else None
             gathered["records"] += int(allrec.shape[0])
             gathered["bytes"] += int(allrec.numel())
             gathered["seconds"] += time.perf_counter() - t1
@@ -300,7 +302,7 @@ def main():
     for _ in range(args.warmup):
         episode(args.warmup_plies if args.max_plies == 0 else min(args.warmup_plies or args.max_plies, args.max_plies))
     eng.reset_stats()
-    for key in gathered:
+    for key in ("records", "bytes", "seconds"):
         gathered[key] = 0
     barrier()
     t0 = time.perf_counter()
@@ -393,7 +395,8 @@ def main():
     if args.gather:
         out["replay_gather"] = {"records_per_episode": gathered["records"] / max(args.steps, 1), "bytes_per_episode": gathered["bytes"] / max(args.steps, 1),
                                 "seconds_per_episode": gathered["seconds"] / max(args.steps, 1), "inside_timed_region": True,
-                                "method": "8 x int64 counts all-gather, then exact-size grouped send/recv (all-gather-v)"}
+                                "method": "8 x int64 counts all-gather, then exact-size grouped send/recv (all-gather-v)",
+                                "last_counts": gathered.get("last_counts"), "last_ids": gathered.get("last_ids")}
     print(json.dumps(out), flush=True)  # the measured line exists from here on, whatever happens to the extra legs
 
     # ---- extra legs, outside the timed region, only while the wall-clock budget has room ----------------------------

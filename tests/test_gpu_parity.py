@@ -172,6 +172,96 @@ def test_net_large_batch_kernel_paths(games, rows):
     big.close()
 
 
+def test_evaluate_logits_is_the_same_forward():
+    """omok_evaluate_logits returns what sits in front of the Softmax / Tanh ops of the same forward."""
+    n = 15
+    x = _random_positions(n, 200, 4)
+    for mode in (B.NET_F16X3, B.NET_F32):
+        eng = oa.Engine(board_size=n, games=16, max_nodes=16, max_tables=8, max_batch_k=16, net_mode=mode)
+        eng.load_random_weights(0)
+        p, v = eng.evaluate_pv(x)
+        lg, vp = eng.evaluate_logits(x)
+        e = np.exp((lg - lg.max(axis=1, keepdims=True)).astype(np.float64))
+        sm = e / e.sum(axis=1, keepdims=True)
+        assert np.abs(sm - p.reshape(len(x), -1)).max() < 2e-6
+        assert np.abs(np.tanh(vp.astype(np.float64)) - v.reshape(-1)).max() < 2e-6
+        eng.close()
+
+
+def _precision_report(n, tensors, x, tag):
+    """max |product path - reference| for p, v (the contract) and for the logits / pre-tanh value, against BOTH references:
+    the oracle's fp32 C forward (p, v) and the OMOK_NET_F32 kernels on the GPU (p, v, logits, vpre)."""
+    eng = oa.Engine(board_size=n, games=32, max_nodes=16, max_tables=8, max_batch_k=16)
+    ref = oa.Engine(board_size=n, games=32, max_nodes=16, max_tables=8, max_batch_k=16, net_mode=B.NET_F32)
+    eng.load_weights(tensors)
+    ref.load_weights(tensors)
+    p, v = eng.evaluate_pv(x)
+    lg, vp = eng.evaluate_logits(x)
+    p32, v32 = ref.evaluate_pv(x)
+    lg32, vp32 = ref.evaluate_logits(x)
+    pc, vc = O.Net(n, tensors).forward(x, threads=8)
+    p, p32 = p.reshape(len(x), -1), p32.reshape(len(x), -1)
+    out = {"dp_oracle": np.abs(p - pc).max(), "dv_oracle": np.abs(v.reshape(-1) - vc).max(),
+           "dp_f32": np.abs(p - p32).max(), "dv_f32": np.abs(v - v32).max(),
+           "dlogit": np.abs(lg - lg32).max(), "dvpre": np.abs(vp - vp32).max(), "logit_std": lg32.std(), "logit_max": np.abs(lg32).max(),
+           "f32_vs_oracle_dp": np.abs(p32 - pc).max()}
+    print(f"precision[{tag}] " + " ".join(f"{k}={val:.3e}" for k, val in out.items()))
+    eng.close()
+    ref.close()
+    return out
+
+
+@pytest.mark.parametrize("n", [9, 15])
+def test_net_precision_on_scaled_and_heavy_tailed_weights(n):
+    """The 1e-3 contract away from the random initialiser: all weights x0.5 and x2 (logit scale x0.5^k .. 2^k through the
+    layers is tamed by using the scale on fc0 / heads only), and a heavy-tailed fc0 (a few entries 50x larger: the worst
+    case for a block-scaled low-precision correction term)."""
+    x = _random_positions(n, 192, 9)
+    base = oa.weights.init_random(n, seed=1)
+    variants = {}
+    for name, f in (("x0.5", 0.5), ("x2", 2.0)):
+        t = [a.copy() for a in base]
+        t[23] = t[23] * f   # fc0_w
+        t[29] = t[29] * f   # p_fc0_w: logits scale with f^2
+        variants[name] = t
+    heavy = [a.copy() for a in base]
+    rng = np.random.default_rng(0)
+    idx = rng.choice(heavy[23].size, size=heavy[23].size // 2000, replace=False)
+    heavy[23].reshape(-1)[idx] *= 50.0
+    variants["heavy-tailed fc0"] = heavy
+    for name, t in variants.items():
+        r = _precision_report(n, t, x, f"n={n} {name}")
+        assert r["dp_oracle"] < TOL and r["dv_oracle"] < TOL and r["dp_f32"] < TOL and r["dv_f32"] < TOL, (name, r)
+
+
+def test_net_precision_after_training_steps():
+    """Weights after 200 TrainPhase steps (Adadelta on replay records of a short self-play episode of the same net): larger
+    fc0 / head magnitudes and structured activations instead of random-init statistics."""
+    import torch
+    from omok_ai_amd import train as T
+    n = 9
+    tensors = oa.weights.init_random(n, seed=0)
+    eng = oa.Engine(board_size=n, games=32, max_nodes=512, max_tables=256, max_batch_k=8, seed=4)
+    eng.load_weights(tensors)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    sp.run(32, 8)
+    _, _, plies = sp.game_info()
+    rec = sp.replay_record_bytes()
+    total = 6 * int(plies.sum())
+    buf = torch.empty(total * rec, dtype=torch.uint8, device="cuda")
+    assert sp.replay_augment_into(buf.data_ptr(), total) == total
+    ph = T.TrainPhase(n, tensors, "cuda")
+    ph.run(buf, update_count=200, batch_size=128, seed=0)
+    trained = ph.net.tensors()
+    eng.close()
+    moved = max(float(np.abs(a - b).max()) for a, b in zip(trained, tensors))
+    assert moved > 1e-3, "training did not move the weights"
+    x = _random_positions(n, 256, 21)
+    r = _precision_report(n, trained, x, "n=9 after 200 training steps")
+    assert r["dp_oracle"] < TOL and r["dv_oracle"] < TOL and r["dp_f32"] < TOL and r["dv_f32"] < TOL, r
+
+
 # ---- self-play: tree arithmetic bit-exact ---------------------------------------------------------
 def _compare_trees(sp, osp, games, tag):
     for g in range(games):

@@ -54,14 +54,10 @@ def _worker(rank, world, port, out):
     r, lr, w = oa.dist.shard_info()
     assert (r, w) == (rank, world)
     recs = _play(N, GAMES_PER_RANK, oa.dist.game_offset(r, GAMES_PER_RANK))
-    cap = GAMES_PER_RANK * N * N
-    slab = torch.zeros((cap, REC), dtype=torch.uint8)
-    slab[: len(recs)] = torch.from_numpy(recs)
-    parts = oa.dist.gather_replay(slab, len(recs))
+    allrec, counts = oa.dist.gather_replay(torch.from_numpy(recs))  # counts exchange + exact-size all-gather-v
     secs, (games, plies) = oa.dist.reduce_timing(1.0 + rank, [GAMES_PER_RANK, len(recs)], "cpu")
     if rank == 0:
-        np.savez(out, all=torch.cat(parts).numpy(), secs=secs, games=games, plies=plies,
-                 sizes=np.array([len(p) for p in parts]))
+        np.savez(out, all=allrec.numpy(), secs=secs, games=games, plies=plies, sizes=np.array(counts))
     dist.barrier()
     dist.destroy_process_group()
 
