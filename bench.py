@@ -156,15 +156,21 @@ def cpu_baseline(args, mean_plies, budget_s):
                 "sims": n_sims, "sims_per_s": n_sims / dt, "nn_evals_per_s": n_evals / dt, "net_seconds": t_net,
                 "tree_seconds": dt - t_net, "finished": sp.alive_count == 0}
 
-    share = budget_s / 4.0
+    # "All threads" for torch-CPU means intra-op threads of each GEMM: on a 256-thread host the 16..1024-row forwards of this
+    # path run SLOWER on 256 threads than on 1 (measured: 176 vs 1620 sims/s), so the multi-thread legs use the fastest of a few
+    # thread counts, found by a short calibration (the reference's rayon + libtensorflow pools size themselves the same way).
+    share = budget_s / 5.0
+    cand = sorted({t for t in (8, 16, 32, 64, cores) if t <= cores})
+    calib = {t: leg(64, args.sims, t, min(1.5, share / len(cand)), 1)["sims_per_s"] for t in cand}
+    best_t = max(calib, key=calib.get)
     legs = {
-        "c1_all_threads": leg(1, 100, cores, share, 10 ** 6),
+        "c1_best_threads": leg(1, 100, best_t, share, 10 ** 6),
         "c1_one_thread": leg(1, 100, 1, share, 10 ** 6),
-        "c2p_all_threads": leg(64, args.sims, cores, share, 5),
+        "c2p_best_threads": leg(64, args.sims, best_t, share, 5),
         "c2p_one_thread": leg(64, args.sims, 1, share, 5),
     }
     torch.set_num_threads(cores)
-    best = legs["c2p_all_threads"]
+    best = legs["c2p_best_threads"]
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -174,8 +180,9 @@ def cpu_baseline(args, mean_plies, budget_s):
     except OSError:
         pass
     rounds_up = (args.sims + k - 1) // k * k
-    return {"value": best["sims_per_s"] / (rounds_up * mean_plies), "unit": "games/s", "cores": cores, "kind": "port",
-            "sample": f"C2' = 64 games x {rounds_up} sims/move x up to 5 plies (bounded to {share:.0f} s) on {cores} threads: oracle C tree "
+    return {"value": best["sims_per_s"] / (rounds_up * mean_plies), "unit": "games/s", "cores": best_t, "host_threads": cores, "kind": "port",
+            "thread_calibration_sims_per_s": {str(t): v for t, v in calib.items()},
+            "sample": f"C2' = 64 games x {rounds_up} sims/move x up to 5 plies (bounded to {share:.0f} s) on {best_t} of {cores} threads (fastest of {cand}): oracle C tree "
                       f"code + torch-CPU fp32 forward (BLAS); {best['sims_per_s']:.0f} sims/s, converted with {mean_plies:.1f} plies/game "
                       f"from the GPU run.  Also C1 (1 game, 100->112 sims/move, whole game or {share:.0f} s) and both again on 1 thread: see legs",
             "cpu_model": model, "sims_per_s": best["sims_per_s"],

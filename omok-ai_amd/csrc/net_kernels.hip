@@ -254,7 +254,8 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const half8* ldsW = (const half8*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int slot = (tid >> 6) / TG::TILES, tile = (tid >> 6) % TG::TILES; // sample slot of the workgroup, pixel tile
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index: uniform, and the compiler knows it (scalar loads / SALU below)
+    const int slot = wv / TG::TILES, tile = wv % TG::TILES;      // sample slot of the workgroup, pixel tile
     const int stid = tid - slot * TG::THREADS;                              // thread index inside the sample
     float* grid = (float*)(smem + TR_WBYTES) + slot * (TG::GRID_BYTES / 4);
     const float* lside = (const float*)(smem + TR_WBYTES + TG::SPW * TG::GRID_BYTES);
@@ -288,6 +289,21 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
         st_ok[i] = p < HW;
     }
     const half8* convW = (const half8*)(wt + TR_WBYTES / 16);
+    // input decode (board bits -> conv_in operand), lane-constant part: see the sample loop
+    const int dec_base = 48 * tile; // first cell of the tile's 48-cell window (m = 96 * tile)
+    const int dec_wlo = dec_base >> 6, dec_sh = dec_base & 63;
+    uint32_t dec_mask[3][4], dec_shift[3];
+    bool dec_plane[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int m = 3 * pxc + c;
+        dec_plane[c] = m >= 2 * HW;
+        const int rel = dec_plane[c] ? 0 : (m >> 1) - dec_base; // 0..47
+        const int piece = ((m & 1) ? 2 : 0) + (rel >= 32 ? 1 : 0); // mine / theirs x low / high piece
+        dec_shift[c] = (uint32_t)(rel >= 32 ? rel - 16 : rel);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dec_mask[c][q] = piece == q ? 0xFFFFFFFFu : 0u;
+    }
 
     // Inputs of a sample are fetched one sample ahead, BEFORE the output stores of the current sample are
     // issued: vmcnt retires in order, so the (younger) stores never sit in front of a load we wait for and
@@ -337,11 +353,19 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
         const int b_next = b + b_stride;
         const bool has_next = b_next < count;
         if (!FROM_F32 && has_next) { ref_n = req_ref[b_next]; aux_n = req_aux[b_next]; } // used at the end of this sample
-        // ---- the pixel's three input floats in the flat encoder.rs layout ----
-        float f0, f1, f2;
+        // ---- conv_in 1x1 3->128 + bias + lrelu as one 16-deep k-step: k = (f0, f1, f2, 1, 0...) on lane-half 0, where f0..f2 are
+        //      the pixel's three input floats in the flat encoder.rs layout ----
+        half8 bh, bl;
         if (FROM_F32) {
-            f0 = in.f[0]; f1 = in.f[1]; f2 = in.f[2];
+            float v[8];
+            v[0] = h == 0 ? in.f[0] : 0.0f; v[1] = h == 0 ? in.f[1] : 0.0f; v[2] = h == 0 ? in.f[2] : 0.0f; v[3] = h == 0 ? 1.0f : 0.0f;
+            v[4] = 0.0f; v[5] = 0.0f; v[6] = 0.0f; v[7] = 0.0f;
+            split8(v, bh, bl);
         } else {
+            // Board inputs are bits.  The flat layout puts (mine, theirs) of cell m >> 1 at m = 3 px + c (m < 2 HW) and the turn
+            // plane behind it, so the 32 pixels of a tile touch the 48 consecutive cells from 48 * tile on: everything up to a
+            // 48-bit window of each colour is wave-uniform (scalar unit), and a lane only picks its three bits out of the windows
+            // (lane-constant selectors, precomputed) and writes them down as f16 0 / 1: no float conversion, no operand split.
             uint64_t bb[2 * NW];
 #pragma unroll
             for (int i = 0; i < 2 * NW; ++i) bb[i] = in.bb[i];
@@ -364,38 +388,40 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                 }
             }
             const int persp = mode == 0 ? turn : 1 - turn; // encoder.rs:24-27
-            const float tplane = turn == 0 ? 1.0f : 0.0f;  // encoder.rs:34-37
-            float fv[3];
+            // 48-bit windows [cell_base, cell_base + 48) of the two colours as seen from `persp`, in two overlapping 32-bit pieces
+            // (bits 0..31 and 16..47): a lane's bit index is then a 32-bit extract
+            uint64_t wm = 0, wt = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const uint64_t mi = persp == 0 ? bb[i] : bb[NW + i], ti = persp == 0 ? bb[NW + i] : bb[i];
+                if (i == dec_wlo) { wm |= mi >> dec_sh; wt |= ti >> dec_sh; }
+                if (i == dec_wlo + 1 && dec_sh != 0) { wm |= mi << (64 - dec_sh); wt |= ti << (64 - dec_sh); }
+            }
+            const uint32_t pieces[4] = {(uint32_t)wm, (uint32_t)(wm >> 16), (uint32_t)wt, (uint32_t)(wt >> 16)};
+            const uint32_t tbit = turn == 0 ? 1u : 0u; // encoder.rs:34-37: the turn plane is 1 where Black is to move
+            uint32_t bits[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const int m = 3 * pxc + c;
-                if (m < 2 * HW) {
-                    const int cell = m >> 1;
-                    uint64_t wb = bb[0], ww = bb[NW];
-#pragma unroll
-                    for (int i = 1; i < NW; ++i) { wb = (cell >> 6) == i ? bb[i] : wb; ww = (cell >> 6) == i ? bb[NW + i] : ww; }
-                    const int isb = (int)((wb >> (cell & 63)) & 1ULL), isw = (int)((ww >> (cell & 63)) & 1ULL);
-                    const int mine = persp == 0 ? isb : isw, theirs = persp == 0 ? isw : isb;
-                    fv[c] = (m & 1) ? (float)theirs : (float)mine;
-                } else {
-                    fv[c] = tplane;
-                }
+                const uint32_t src = (pieces[0] & dec_mask[c][0]) | (pieces[1] & dec_mask[c][1]) | (pieces[2] & dec_mask[c][2]) | (pieces[3] & dec_mask[c][3]);
+                const uint32_t bit = (src >> dec_shift[c]) & 1u;
+                bits[c] = dec_plane[c] ? tbit : bit;
             }
-            f0 = fv[0]; f1 = fv[1]; f2 = fv[2];
+            // f16 1.0 = 0x3C00; k = (f0, f1, f2, 1) on lane-half 0, zeros on half 1 and in the remaining 12 k slots
+            union { uint32_t u[4]; half8 v; } Bq;
+            Bq.u[0] = h == 0 ? (bits[0] * 0x3C00u) | (bits[1] * 0x3C000000u) : 0u;
+            Bq.u[1] = h == 0 ? (bits[2] * 0x3C00u) | 0x3C000000u : 0u;
+            Bq.u[2] = 0u;
+            Bq.u[3] = 0u;
+            bh = Bq.v;
+            bl = bh; // (unused: the inputs are exact in f16)
         }
-        // ---- conv_in 1x1 3->128 + bias + lrelu as one 16-deep k-step: k = (f0, f1, f2, 1, 0...) on lane-half 0 ----
         f32x16 x[4];
         if (ABL & 4) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) x[m][i] = f0 + 0.01f * (float)(i + 16 * m);
+                for (int i = 0; i < 16; ++i) x[m][i] = (FROM_F32 ? in.f[0] : (float)in.turn) + 0.01f * (float)(i + 16 * m);
         } else {
-            float v[8];
-            v[0] = h == 0 ? f0 : 0.0f; v[1] = h == 0 ? f1 : 0.0f; v[2] = h == 0 ? f2 : 0.0f; v[3] = h == 0 ? 1.0f : 0.0f;
-            v[4] = 0.0f; v[5] = 0.0f; v[6] = 0.0f; v[7] = 0.0f;
-            half8 bh, bl;
-            split8(v, bh, bl);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
 #pragma unroll
