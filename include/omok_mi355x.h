@@ -54,7 +54,7 @@ typedef struct {
     int32_t max_batch_k; /* largest evaluate_batch_size that will be used (<= 64) */
     int32_t device;      /* HIP device ordinal */
     int32_t net_mode;    /* OMOK_NET_* */
-    int32_t reserved;
+    int32_t max_tree_waves; /* 0, or the largest `waves` omok_execute_shared will be called with (<= 16): sizes the net batch */
     uint64_t seed;       /* RNG seed; the Philox key of episode i is seed + i * 0x9E3779B97F4A7C15 (omok_set_episode) */
     int64_t game_offset; /* global id of game 0 (multi-GPU sharding: rank * games) */
 } omok_config;
@@ -118,6 +118,13 @@ int omok_set_episode(omok_engine* e, uint64_t episode);
  * side-to-move agents of all live games: rounds of `batch_size` simulations per tree, one net
  * forward per round, ordered scatter; simulations round up to a multiple of batch_size. */
 int omok_execute(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha);
+/* MCTSExecutor::run (alpha-zero/src/mcts_executor.rs:29-255; the executor of gui/src/agent.rs and benchmark/src/agent.rs) on an
+ * engine with games = 1: ONE tree searched by `waves` wavefronts.  The reference runs its ceil(count / batch_size) rounds as
+ * rayon tasks on one shared tree (relaxed atomics on n / w, the children lock in expand(), a duplicate expansion returns None
+ * and drops the simulation, :171-178); here `waves` rounds run concurrently as the wavefronts of one workgroup, their requests
+ * are evaluated as one batch and scattered by the same wavefronts.  waves = 1 is the sequential schedule: identical, bit for
+ * bit, to omok_execute.  With waves > 1 the result depends on the interleaving, as it does in the reference. */
+int omok_execute_shared(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha, int32_t waves);
 /* Agent::sample_action for every live game (agent.rs:83-137) with the trainer's mode rule
  * (trainer.rs:138-146): Boltzmann(temperature) while the game's ply < threshold, else Best.
  * Records the transition (env before the move, pi) like trainer.rs:150-173.

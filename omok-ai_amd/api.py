@@ -27,11 +27,11 @@ class Engine:
     """Opaque engine handle (omok_create / omok_destroy)."""
 
     def __init__(self, board_size=15, games=1, max_nodes=2048, max_tables=1024, max_batch_k=16, device=0,
-                 net_mode=B.NET_F16X3, seed=0, game_offset=0):
+                 net_mode=B.NET_F16X3, seed=0, game_offset=0, max_tree_waves=0):
         self.n, self.hw, self.games = board_size, board_size * board_size, games
         self.max_nodes = max_nodes
         self.max_batch_k = max_batch_k
-        cfg = B.Config(board_size, games, max_nodes, max_tables, max_batch_k, device, net_mode, 0, seed, game_offset)
+        cfg = B.Config(board_size, games, max_nodes, max_tables, max_batch_k, device, net_mode, max_tree_waves, seed, game_offset)
         h = C.c_void_p()
         rc = B.lib().omok_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -223,6 +223,10 @@ class SelfPlay:
 
     def execute(self, count, batch_size, epsilon=0.25, alpha=0.03):
         self._chk(B.lib().omok_execute(self.h, count, batch_size, epsilon, alpha))
+
+    def execute_shared(self, count, batch_size, epsilon=0.25, alpha=0.03, waves=8):
+        """MCTSExecutor::run: one tree (games = 1) searched by `waves` wavefronts"""
+        self._chk(B.lib().omok_execute_shared(self.h, count, batch_size, epsilon, alpha, waves))
 
     def sample_actions(self, temperature=1.0, threshold=30):
         a = np.zeros(self.games, dtype=np.int32)

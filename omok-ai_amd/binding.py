@@ -19,7 +19,7 @@ STAT_NAMES = ["sims", "evals", "ply_games", "finished", "ms_tree", "ms_trunk", "
 # every symbol include/omok_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "omok_create", "omok_destroy", "omok_last_error", "omok_net_num_tensors", "omok_net_tensor_size", "omok_net_load",
-    "omok_net_commit", "omok_net_load_file", "omok_net_save_file", "omok_evaluate_pv", "omok_evaluate_logits", "omok_env_play", "omok_env_place_stone", "omok_encode_nn_input", "omok_selfplay_reset", "omok_set_episode", "omok_execute",
+    "omok_net_commit", "omok_net_load_file", "omok_net_save_file", "omok_evaluate_pv", "omok_evaluate_logits", "omok_env_play", "omok_env_place_stone", "omok_encode_nn_input", "omok_selfplay_reset", "omok_set_episode", "omok_execute", "omok_execute_shared",
     "omok_compute_policy", "omok_play_actions", "omok_set_actions", "omok_root_children",
     "omok_sample_actions", "omok_advance", "omok_selfplay_run", "omok_round_generate", "omok_round_inputs",
     "omok_round_eval", "omok_round_outputs", "omok_round_inject", "omok_round_scatter", "omok_mirror_generate",
@@ -31,7 +31,7 @@ SYMBOLS = [
 
 class Config(C.Structure):
     _fields_ = [("board_size", C.c_int32), ("games", C.c_int32), ("max_nodes", C.c_int32), ("max_tables", C.c_int32),
-                ("max_batch_k", C.c_int32), ("device", C.c_int32), ("net_mode", C.c_int32), ("reserved", C.c_int32),
+                ("max_batch_k", C.c_int32), ("device", C.c_int32), ("net_mode", C.c_int32), ("max_tree_waves", C.c_int32),
                 ("seed", C.c_uint64), ("game_offset", C.c_int64)]
 
 
@@ -82,6 +82,7 @@ def lib():
     L.omok_set_actions.argtypes = [H, ip]
     L.omok_root_children.argtypes = [H, C.c_int32, C.c_int32, ip, C.POINTER(C.c_uint32), fp, fp, C.c_int32]
     L.omok_execute.argtypes = [H, C.c_int32, C.c_int32, C.c_float, C.c_float]
+    L.omok_execute_shared.argtypes = [H, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32]
     L.omok_sample_actions.argtypes = [H, C.c_float, C.c_int32, ip]
     L.omok_advance.argtypes = [H]
     L.omok_selfplay_run.argtypes = [H, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,

@@ -104,6 +104,12 @@ struct RoundArgs {
 void launch_reset(int n, const Store& S, const float* root_policy_dev /*ROWP*/, hipStream_t st);
 void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st);
 void launch_scan(int n, const Store& S, int side, int K, hipStream_t st);
+// one tree searched by `waves` waves (MCTSExecutor::run): sh_req [waves][KMAX] u16, sh_cnt [2 * KMAX] u32 (counts | bases)
+void launch_round_shared(int n, const Store& S, const RoundArgs& a, int rounds_total, int group, int waves, uint16_t* sh_req, uint32_t* sh_cnt,
+                         hipStream_t st);
+void launch_scatter_shared(int n, const Store& S, int side, const float* p_dev, const float* v_dev, int max_count, int waves, const uint16_t* sh_req,
+                           const uint32_t* sh_cnt, hipStream_t st);
+constexpr int MAX_TREE_WAVES = 16; // one workgroup of 1024 threads
 void launch_scatter(int n, const Store& S, int side, const float* p_dev, const float* v_dev, int max_count, hipStream_t st);
 void launch_sample(int n, const Store& S, int side, int ply, float temperature, int threshold, uint64_t seed,
                    int64_t game_offset, int32_t* actions_dev, hipStream_t st);

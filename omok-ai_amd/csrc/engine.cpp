@@ -90,6 +90,8 @@ struct omok_engine {
     int32_t* d_actions = nullptr;
     uint32_t* d_error = nullptr; // [0] error bits, [1] alive count
     unsigned long long* d_evals = nullptr;
+    uint16_t* d_sh_req = nullptr;       // [MAX_TREE_WAVES][KMAX] requests of the waves of a shared-tree round group
+    uint32_t* d_sh_cnt = nullptr;       // [2 * KMAX] their counts | first-request offsets
     uint32_t* d_flags = nullptr;        // [0] illegal external moves, [1] live games without a move (omok_play_actions)
     float* d_pi = nullptr;              // [G][HW] omok_compute_policy
     uint8_t* d_has = nullptr;           // [G]
@@ -231,7 +233,9 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     S.games = cfg->games;
     const size_t T = (size_t)e->T, cn = (size_t)cfg->max_nodes, ct = (size_t)cfg->max_tables, rp = (size_t)e->rowp;
     const size_t G = (size_t)cfg->games, HW = (size_t)e->hw;
-    const size_t max_b = G * (size_t)cfg->max_batch_k;
+    if (cfg->max_tree_waves < 0 || cfg->max_tree_waves > MAX_TREE_WAVES)
+        { omok_destroy(e); return fail(nullptr, OMOK_ERR_INVALID, "max_tree_waves must be in [0, %d]", MAX_TREE_WAVES); }
+    const size_t max_b = std::max(G, (size_t)cfg->max_tree_waves) * (size_t)cfg->max_batch_k;
     int rc = 0;
     rc |= dalloc(e, &S.hdr, T * cn);
     rc |= dalloc(e, &S.board, T * cn * 2 * e->nw);
@@ -256,6 +260,8 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     rc |= dalloc(e, &e->d_actions, G);
     rc |= dalloc(e, &e->d_error, 4);
     rc |= dalloc(e, &e->d_evals, 2);
+    rc |= dalloc(e, &e->d_sh_req, (size_t)MAX_TREE_WAVES * KMAX);
+    rc |= dalloc(e, &e->d_sh_cnt, 2 * (size_t)KMAX);
     rc |= dalloc(e, &e->d_flags, 4);
     rc |= dalloc(e, &e->d_pi, G * HW);
     rc |= dalloc(e, &e->d_has, G);
@@ -616,6 +622,41 @@ extern "C" int omok_execute(omok_engine* e, int32_t count, int32_t batch_size, f
     if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
     const int rounds = enqueue_execute(e, count, batch_size, epsilon, alpha, (int)alive);
     e->sims += (double)rounds * batch_size * alive;
+    if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
+    return tree_error(e, bits);
+}
+
+// MCTSExecutor::run (alpha-zero/src/mcts_executor.rs:29-255): ONE tree, rounds as concurrent tasks.  `waves` rounds run at a time
+// on the shared tree of game 0 (one workgroup of `waves` wavefronts); their requests form one net batch.
+extern "C" int omok_execute_shared(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha, int32_t waves) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (need_net(e) || need_reset(e)) return OMOK_ERR_STATE;
+    if (check_exec_args(e, count, batch_size, epsilon, alpha)) return OMOK_ERR_INVALID;
+    if (e->cfg.games != 1) return fail(e, OMOK_ERR_INVALID, "omok_execute_shared searches ONE tree: create the engine with games = 1 (got %d)", e->cfg.games);
+    if (waves < 1 || waves > MAX_TREE_WAVES || waves * batch_size > e->net.max_b)
+        return fail(e, OMOK_ERR_INVALID, "waves must be in [1, max_tree_waves = %d] (and waves * batch_size <= %d)", e->cfg.max_tree_waves, e->net.max_b);
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    uint32_t bits = 0, alive = 0;
+    if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
+    const int side = e->ply & 1;
+    RoundArgs a{side, 0, 0, e->ply, epsilon, alpha, e->key, e->cfg.game_offset};
+    e->prof.begin(PC_ROUND, e->st);
+    launch_round(e->n, e->S, a, e->st); // K = 0, round 0: the root's Dirichlet noise only (mcts_executor.rs:38-68)
+    e->prof.end(e->st);
+    int exec_count = count / batch_size; // :70-74
+    if (exec_count * batch_size != count) exec_count += 1;
+    a.K = batch_size;
+    for (int group = 0; group * waves < exec_count; ++group) {
+        e->prof.begin(PC_ROUND, e->st);
+        launch_round_shared(e->n, e->S, a, exec_count, group, waves, e->d_sh_req, e->d_sh_cnt, e->st);
+        k_add_evals<<<1, 64, 0, e->st>>>(e->S.d_count, e->d_evals);
+        e->prof.end(e->st);
+        net_forward_requests(e->net, e->S, waves * batch_size, e->st, &e->prof);
+        e->prof.begin(PC_TREE_OTHER, e->st);
+        launch_scatter_shared(e->n, e->S, side, e->net.p, e->net.v, waves * batch_size, waves, e->d_sh_req, e->d_sh_cnt, e->st);
+        e->prof.end(e->st);
+    }
+    e->sims += (double)exec_count * batch_size * alive;
     if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
     return tree_error(e, bits);
 }

@@ -503,6 +503,220 @@ __global__ __launch_bounds__(64) void k_round(Store S, RoundArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// ONE TREE SEARCHED BY MANY WAVES: MCTSExecutor::run (alpha-zero/src/mcts_executor.rs:29-255), the executor of the GUI and of
+// the checkpoint-vs-checkpoint match.  The reference runs ceil(count / batch_size) rounds of `batch_size` simulations as rayon
+// tasks on ONE shared tree: relaxed atomics on n / w (node.rs:86-88), the children lock in expand() -- a second thread that
+// picked the same action gets None and drops its simulation (mcts_executor.rs:171-178) -- and its own evaluate_pv per round.
+// Here: W waves of ONE workgroup (one CU: its waves share the vector L1, so workgroup-scope fences order their global
+// accesses) run W rounds concurrently; their requests are evaluated as one batch and scattered by the same W waves.  That is
+// one of the schedules the reference's thread pool can produce (W threads that reach evaluate_pv together), and with W = 1 it
+// is the sequential schedule of omok_execute, bit for bit.  Results for W > 1 depend on the interleaving, as in the reference.
+// ---------------------------------------------------------------------------------------------
+__device__ inline void wave_fence() { // orders this wave's global accesses against the other waves of the workgroup
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ inline void tree_lock(int* lock) { // the allocator Mutex + children write lock of mcts/src/lib.rs:43-45, node.rs:67
+    if (LANE == 0)
+        while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+    wave_fence();
+}
+__device__ inline void tree_unlock(int* lock) {
+    wave_fence();
+    if (LANE == 0) atomicExch(lock, 0);
+}
+
+template <int N>
+__device__ inline void backup_shared(const Tree<N>& T, int x, float v) { // node.rs:83-99 with fetch_add (n first, then w)
+    constexpr int ROWP = Geo<N>::ROWP;
+    const volatile NodeHdr* hdr = T.hdr;
+    while (x != 0) {
+        const uint16_t parent = hdr[x].parent;
+        const size_t slot = (size_t)hdr[parent].table * ROWP + hdr[x].action;
+        if (LANE == 0) { atomicAdd(&T.cn[slot], 1u); atomicAdd(&T.cw[slot], v); }
+        v = -v;
+        x = parent;
+    }
+    if (LANE == 0) { atomicAdd(&T.ts->root_n, 1u); atomicAdd(&T.ts->root_w, v); }
+}
+
+// Node::expand under the tree lock; returns the node index, -1 on arena overflow, -2 if another wave expanded the action first
+template <int N>
+__device__ inline int add_child_shared(const Store& S, const Tree<N>& T, int* lock, int parent, int action, const uint64_t* bb,
+                                       int status, int turn) {
+    using G = Geo<N>;
+    const int lane = LANE;
+    volatile NodeHdr* hdr = T.hdr;
+    volatile TreeState* ts = T.ts;
+    volatile uint8_t* corder = T.corder;
+    tree_lock(lock);
+    int result;
+    const uint16_t nch = hdr[parent].nch, legal = hdr[parent].legal;
+    int tab = hdr[parent].table;
+    const uint32_t n_nodes = ts->n_nodes, n_tables = ts->n_tables;
+    if (tab != NONE16 && corder[(size_t)tab * G::ROWP + action] != NONE8) {
+        result = -2; // children.iter().any(|child| child.action == Some(action)) -> None (node.rs:69-71)
+    } else if (n_nodes >= (uint32_t)S.cap_nodes || (tab == NONE16 && n_tables >= (uint32_t)S.cap_tables)) {
+        if (lane == 0) ts->error = ts->error | 1u;
+        result = -1;
+    } else {
+        if (tab == NONE16) {
+            tab = (int)n_tables;
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) corder[(size_t)tab * G::ROWP + j * 64 + lane] = NONE8;
+            if (lane == 0) { T.owner[tab] = (uint16_t)parent; hdr[parent].table = (uint16_t)tab; ts->n_tables = n_tables + 1u; }
+        }
+        const int idx = (int)n_nodes;
+        const size_t slot = (size_t)tab * G::ROWP + action;
+        if (lane == 0) {
+            NodeHdr c;
+            c.parent = (uint16_t)parent; c.table = NONE16; c.legal = (uint16_t)(legal - 1); c.nch = 0;
+            c.action = (uint8_t)action; c.status = (uint8_t)status; c.turn = (uint8_t)turn; c.has_policy = 0; c.pad = 0;
+            T.hdr[idx] = c;
+            T.cidx[slot] = (uint16_t)idx;
+            T.cn[slot] = 0u;
+            T.cw[slot] = 0.0f;
+        }
+        if (lane < 2 * G::NW) {
+            uint64_t w = bb[0];
+#pragma unroll
+            for (int i = 1; i < 2 * G::NW; ++i) w = lane == i ? bb[i] : w;
+            T.board[(size_t)idx * (2 * G::NW) + lane] = w;
+        }
+        wave_fence(); // the child is complete before it becomes reachable
+        if (lane == 0) { corder[slot] = (uint8_t)nch; hdr[parent].nch = (uint16_t)(nch + 1); ts->n_nodes = n_nodes + 1u; }
+        result = idx;
+    }
+    tree_unlock(lock);
+    return result;
+}
+
+template <int N>
+__device__ void run_sim_shared(const Store& S, const Tree<N>& T, int* lock, const RoundArgs& A, uint32_t sim_index, uint32_t tree_global,
+                               uint16_t* my_req, uint32_t& n_req) {
+    using G = Geo<N>;
+    constexpr int ROWP = G::ROWP, NW = G::NW;
+    const int lane = LANE;
+    const volatile NodeHdr* hdr = T.hdr;
+    const volatile uint32_t* cn = T.cn;
+    const volatile float* cw = T.cw;
+    const volatile uint8_t* corder = T.corder;
+    const volatile uint16_t* cidx = T.cidx;
+    int node = 0;
+    uint32_t node_n = ((const volatile TreeState*)T.ts)->root_n;
+    uint16_t h_nch = hdr[0].nch, h_legal = hdr[0].legal, h_table = hdr[0].table;
+    uint8_t h_has = hdr[0].has_policy;
+    // ---- select_leaf (node.rs:43-58), PUCT on whatever n / w the other waves have published so far ----
+    while (h_nch == h_legal && h_nch != 0) {
+        const uint32_t pn = node_n > 1u ? node_n : 1u;
+        const float sq = __fsqrt_rn((float)pn);
+        const size_t tb = (size_t)h_table * ROWP;
+        const float ph = __fdiv_rn(1.0f, (float)h_legal);
+        unsigned long long best = 0ULL;
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const int a = j * 64 + lane;
+            const uint8_t ord = corder[tb + a];
+            if (ord != NONE8) {
+                const uint32_t n = cn[tb + a];
+                const float w = cw[tb + a];
+                const float p = h_has ? T.pol[(size_t)node * ROWP + a] : ph;
+                const float q = __fdiv_rn(w, (float)n + F32_EPS);
+                const float bias = __fdiv_rn(sq, (float)(1u + n));
+                const float score = q + (1.0f * p) * bias;
+                const unsigned long long v = ((unsigned long long)total_key_biased(score) << 32) | ((unsigned long long)ord << 16) | (unsigned long long)a;
+                best = v > best ? v : best;
+            }
+        }
+        best = wave_max_u64(best);
+        const int a_best = (int)(best & 0xFFFFu);
+        node_n = cn[tb + a_best];
+        node = (int)cidx[tb + a_best];
+        h_nch = hdr[node].nch; h_legal = hdr[node].legal; h_table = hdr[node].table; h_has = hdr[node].has_policy;
+    }
+    const int h_status = hdr[node].status, h_turn = hdr[node].turn;
+    if (h_status != ST_IN_PROGRESS) { // pme / mcts_executor.rs:92-97
+        backup_shared<N>(T, node, h_status >= ST_BLACK_WIN ? 1.0f : 0.0f);
+        return;
+    }
+    uint64_t bb[2 * NW];
+#pragma unroll
+    for (int i = 0; i < 2 * NW; ++i) bb[i] = T.board[(size_t)node * (2 * NW) + i]; // a node's board never changes once published
+    unsigned long long cand[G::IT];
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        bool c = a < G::HW && !(((bb[j] | bb[NW + j]) >> lane) & 1ULL);
+        if (c && h_table != NONE16) c = corder[(size_t)h_table * ROWP + a] == NONE8;
+        cand[j] = __ballot(c);
+        total += __popcll(cand[j]);
+    }
+    if (total == 0) return;
+    const U4 o = philox(A.seed, sim_index, (uint32_t)A.ply, tree_global, RNG_EXPAND);
+    int r = (int)__umulhi(o.x, (uint32_t)total);
+    int action = 0;
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int c = __popcll(cand[j]);
+        if (!found) {
+            if (r < c) { action = j * 64 + nth_set_bit(cand[j], r); found = true; }
+            else r -= c;
+        }
+    }
+    const int status = place_and_status<N>(bb, h_turn, h_legal, action);
+    const int child = add_child_shared<N>(S, T, lock, node, action, bb, status, 1 - h_turn);
+    if (child < 0) return; // None: "already expanded by other thread" (mcts_executor.rs:171-178), or the arena is full
+    if (status != ST_IN_PROGRESS) backup_shared<N>(T, child, status == ST_DRAW ? 0.0f : 1.0f);
+    else { if (lane == 0) my_req[n_req] = (uint16_t)child; n_req += 1u; }
+}
+
+// W waves (one workgroup) x one round each: wave w runs round `group * W + w` of the execute call
+template <int N>
+__global__ __launch_bounds__(1024) void k_round_shared(Store S, RoundArgs A, int rounds_total, int group, uint16_t* __restrict__ sh_req,
+                                                       uint32_t* __restrict__ sh_cnt) {
+    __shared__ int s_lock;
+    if (threadIdx.x == 0) s_lock = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    const int t = A.side * S.games; // game 0
+    const Tree<N> T(S, t);
+    const uint32_t tree_global = (uint32_t)(A.game_offset * 2 + A.side);
+    const int round = group * W + wave;
+    uint32_t n_req = 0;
+    if (S.gs[0].alive && round < rounds_total)
+        for (int i = 0; i < A.K; ++i) run_sim_shared<N>(S, T, &s_lock, A, (uint32_t)(round * A.K + i), tree_global, sh_req + (size_t)wave * KMAX, n_req);
+    if (LANE == 0) sh_cnt[wave] = n_req;
+}
+
+// request list of the W rounds in round order, then simulation order (one wave)
+__global__ __launch_bounds__(64) void k_scan_shared(Store S, int side, int W, const uint16_t* __restrict__ sh_req, uint32_t* __restrict__ sh_cnt) {
+    const int lane = threadIdx.x;
+    uint32_t base = 0;
+    for (int w = 0; w < W; ++w) {
+        const uint32_t c = sh_cnt[w];
+        if ((uint32_t)lane < c) {
+            S.req_ref[base + lane] = ((uint32_t)(side * S.games) << 16) | sh_req[(size_t)w * KMAX + lane];
+            S.req_aux[base + lane] = 0xFFFFFFFFu;
+        }
+        if (lane == 0) sh_cnt[KMAX + w] = base; // first request of round w
+        base += c;
+    }
+    if (lane == 0) S.d_count[0] = (int32_t)base;
+}
+
+// the scatter halves of the W rounds (mcts_executor.rs:206-250): every wave backs its own requests up, fetch_add like propagate
+template <int N>
+__global__ __launch_bounds__(1024) void k_scatter_shared(Store S, int side, const float* __restrict__ V, const uint16_t* __restrict__ sh_req,
+                                                         const uint32_t* __restrict__ sh_cnt) {
+    const int wave = threadIdx.x >> 6;
+    const Tree<N> T(S, side * S.games);
+    const uint32_t c = sh_cnt[wave], base = sh_cnt[KMAX + wave];
+    for (uint32_t r = 0; r < c; ++r) backup_shared<N>(T, sh_req[(size_t)wave * KMAX + r], -V[base + r]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_scan: dense, order-preserving request list over the live trees of one side
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_scan(Store S, int side) {
@@ -1334,6 +1548,19 @@ void launch_reset(int n, const Store& S, const float* rp, hipStream_t st) {
 }
 void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st) {
     DISPATCH_N(n, (k_round<9><<<S.games, 64, 0, st>>>(S, a)), (k_round<15><<<S.games, 64, 0, st>>>(S, a)));
+}
+void launch_round_shared(int n, const Store& S, const RoundArgs& a, int rounds_total, int group, int waves, uint16_t* sh_req, uint32_t* sh_cnt,
+                         hipStream_t st) {
+    DISPATCH_N(n, (k_round_shared<9><<<1, waves * 64, 0, st>>>(S, a, rounds_total, group, sh_req, sh_cnt)),
+               (k_round_shared<15><<<1, waves * 64, 0, st>>>(S, a, rounds_total, group, sh_req, sh_cnt)));
+    k_scan_shared<<<1, 64, 0, st>>>(S, a.side, waves, sh_req, sh_cnt);
+}
+void launch_scatter_shared(int n, const Store& S, int side, const float* p, const float* v, int max_count, int waves, const uint16_t* sh_req,
+                           const uint32_t* sh_cnt, hipStream_t st) {
+    const int grid = max_count > 0 ? max_count : 1;
+    DISPATCH_N(n, (k_scatter_policy<9><<<grid, 64, 0, st>>>(S, p, max_count)), (k_scatter_policy<15><<<grid, 64, 0, st>>>(S, p, max_count)));
+    DISPATCH_N(n, (k_scatter_shared<9><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt)),
+               (k_scatter_shared<15><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt)));
 }
 void launch_scan(int n, const Store& S, int side, int K, hipStream_t st) {
     k_scan<<<1, 1024, 0, st>>>(S, side);

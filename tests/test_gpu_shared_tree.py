@@ -1,0 +1,111 @@
+"""One tree searched by many wavefronts (omok_execute_shared = MCTSExecutor::run, alpha-zero/src/mcts_executor.rs:29-255;
+SURVEY 8f rank 4).  The reference's version is nondeterministic by design (rayon tasks racing on one tree), so parity is:
+  - waves = 1 is the sequential schedule: identical to omok_execute bit for bit, ply after ply;
+  - waves > 1: every structural invariant of the tree holds, visit counts are conserved (node n >= sum of its children's n),
+    nothing is lost or duplicated in the arena, every non-terminal node got its evaluation, and the search still concentrates
+    on the same moves as the sequential one (loose statistical bound, printed)."""
+import numpy as np
+import pytest
+
+import omok_ai_amd as oa
+from test_oracle_selfplay import check_tree_invariants
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(n, k, seed, waves, max_nodes=4096):
+    eng = oa.Engine(board_size=n, games=1, max_nodes=max_nodes, max_tables=max_nodes // 2, max_batch_k=k, seed=seed, max_tree_waves=waves)
+    eng.load_random_weights(0)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    return eng, sp
+
+
+@pytest.mark.parametrize("n,count,k", [(9, 100, 8), (15, 100, 16)])
+def test_one_wave_is_the_sequential_executor(n, count, k):
+    a_eng, a = _engine(n, k, 5, 0)
+    b_eng, b = _engine(n, k, 5, 1)
+    for ply in range(10):
+        a.execute(count, k)
+        b.execute_shared(count, k, waves=1)
+        for side in (0, 1):
+            ai, af = a.tree_dump(0, side)
+            bi, bf = b.tree_dump(0, side)
+            assert np.array_equal(ai, bi) and np.array_equal(af.view(np.uint32), bf.view(np.uint32)), f"ply {ply} side {side}"
+            assert a.tree_root(0, side) == b.tree_root(0, side)
+        assert np.array_equal(a.sample_actions(1.0, 4), b.sample_actions(1.0, 4))
+        a.advance()
+        b.advance()
+        if a.alive_count == 0:
+            break
+    assert a_eng.stats()["sims"] == b_eng.stats()["sims"]
+    a_eng.close()
+    b_eng.close()
+
+
+@pytest.mark.parametrize("n,count,k,waves", [(9, 400, 8, 8), (9, 256, 4, 16), (15, 800, 16, 16)])
+def test_many_waves_keep_the_tree_consistent(n, count, k, waves):
+    eng, sp = _engine(n, k, 11, waves, max_nodes=8192)
+    hw = n * n
+    plies = 0
+    while sp.alive_count > 0 and plies < 12:
+        side = sp.ply & 1
+        before = eng.stats()
+        n0 = sp.tree_root(0, side)[2]
+        sp.execute_shared(count, k, waves=waves)
+        after = eng.stats()
+        ints, floats = sp.tree_dump(0, side)
+        root_n, root_w, n_nodes, n_tables = sp.tree_root(0, side)
+        check_tree_invariants(ints, floats, root_n, hw)
+        assert len(ints) == n_nodes
+        parent, nch, nvis, status = ints[:, 0], ints[:, 5], ints[:, 6], ints[:, 2]
+        sims = after["sims"] - before["sims"]
+        evals = after["evals"] - before["evals"]
+        assert sims == -(-count // k) * k
+        csum = np.zeros(n_nodes, dtype=np.int64)
+        np.add.at(csum, parent[1:], nvis[1:])
+        visits = np.concatenate([[root_n], nvis[1:]]).astype(np.int64)
+        assert np.all(visits >= csum), "a node was visited less often than its children together"
+        new_nodes = n_nodes - n0
+        assert new_nodes <= sims        # at most one expansion per simulation (duplicate picks are dropped)
+        assert evals <= new_nodes       # requests are new nodes; terminal children are not evaluated
+        pending = np.flatnonzero(((ints[:, 7] >> 16) == 0) & (status == 0))
+        assert len(pending) == 0, "a non-terminal node was left without its evaluation"
+        a, cn, cw, cp = sp.root_children(0, side)
+        assert len(set(a.tolist())) == len(a) == nch[0]   # no slot of the root's table was claimed twice
+        acts = sp.sample_actions(1.0, 30)
+        assert 0 <= acts[0] < hw
+        sp.advance()
+        plies += 1
+    assert plies >= 6
+    eng.close()
+
+
+def test_many_waves_search_like_the_sequential_search_of_the_same_granularity():
+    """8 waves x K = 8 put 64 simulations between two scatters, like the sequential executor with batch_size 64 (same RNG
+    indices: round q * 8 + w, simulation i <-> round q, simulation 8 w + i); the only difference is that concurrent waves
+    may pick the same untried action (the loser's simulation is dropped, mcts_executor.rs:171-178).  The root visit
+    distributions must therefore be close: much closer than two sequential searches with different batch sizes are."""
+    n, count = 9, 384
+
+    def visits(seed, k, waves):
+        eng, sp = _engine(n, k, seed, waves)
+        if waves:
+            sp.execute_shared(count, k, waves=waves)
+        else:
+            sp.execute(count, k)
+        pi, has = sp.compute_policy()
+        st = eng.stats()
+        eng.close()
+        assert has[0]
+        return pi[0].astype(np.float64), st
+
+    tv_same, tv_other = [], []
+    for seed in range(6):
+        par, st = visits(seed, 8, 8)
+        seq64, _ = visits(seed, 64, 0)
+        seq8, _ = visits(seed, 8, 0)
+        tv_same.append(0.5 * np.abs(par - seq64).sum())
+        tv_other.append(0.5 * np.abs(seq8 - seq64).sum())
+    print(f"TV(8 waves x K=8 vs sequential K=64) = {np.mean(tv_same):.3f}   TV(sequential K=8 vs K=64) = {np.mean(tv_other):.3f}")
+    assert np.mean(tv_same) < 0.12 and np.mean(tv_same) < np.mean(tv_other)
