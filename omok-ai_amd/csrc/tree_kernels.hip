@@ -156,18 +156,23 @@ __device__ inline int nth_set_bit(unsigned long long m, int r) {
     for (int i = 0; i < r; ++i) m &= m - 1;
     return __ffsll((long long)m) - 1;
 }
+// (Both helpers touch EVERY word with a computed mask: a chain of selects on the word index is turned back into an indexed
+//  access by the compiler, which then keeps the bitboards in scratch memory -- 120 B per lane, ~6 KB of HBM writes per
+//  simulation in k_round, the rocprofv3 WRITE_SIZE of round 1.)
 template <int NW>
 __device__ inline int get_bit(const uint64_t* w, int c) {
-    uint64_t word = w[0];
+    const int wi = c >> 6, sh = c & 63;
+    uint32_t r = 0;
 #pragma unroll
-    for (int i = 1; i < NW; ++i) word = (c >> 6) == i ? w[i] : word;
-    return (int)((word >> (c & 63)) & 1);
+    for (int i = 0; i < NW; ++i) r |= (uint32_t)((w[i] >> sh) & 1ULL) & (wi == i ? 1u : 0u);
+    return (int)r;
 }
 template <int NW>
 __device__ inline void set_bit(uint64_t* w, int c) {
+    const int wi = c >> 6;
+    const uint64_t bit = 1ULL << (c & 63);
 #pragma unroll
-    for (int i = 0; i < NW; ++i)
-        if ((c >> 6) == i) w[i] |= 1ULL << (c & 63);
+    for (int i = 0; i < NW; ++i) w[i] |= wi == i ? bit : 0ULL;
 }
 
 // sequential f32 sum of s[0..n) in ascending order (Rust iter().sum::<f32>()), by every lane

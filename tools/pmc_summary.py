@@ -1,13 +1,41 @@
-"""Per-kernel sums of the rocprofv3 counter_collection.csv files under a directory (tools/pmc_net.sh)."""
-import collections, csv, glob, sys
-root = sys.argv[1]
+"""Per-kernel sums of the rocprofv3 counter_collection.csv files under a directory (tools/collect_profiles.sh).
+
+usage: python tools/pmc_summary.py <dir with pmc passes> [--json out.json --board 15 --rows R --sims S --rounds N]
+Text: one line per (kernel, counter).  --json: the HBM bytes bench.py's `roofline*.traffic` uses, per net row / per simulation,
+with the corrections MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE is tallied at 64 B per 128-B request: x2 for wide
+coalesced reads; WRITE_SIZE exact for 16-B-per-lane stores), in bytes (the counters are KiB)."""
+import argparse, collections, csv, glob, json
+
+ap = argparse.ArgumentParser()
+ap.add_argument("root")
+ap.add_argument("--json")
+ap.add_argument("--board", type=int, default=15)
+ap.add_argument("--rows", type=float, default=0.0, help="net rows evaluated during the profiled command (bench.py nn evals)")
+ap.add_argument("--sims", type=float, default=0.0, help="simulations run during the profiled command")
+a = ap.parse_args()
 agg = collections.defaultdict(float)
 n = collections.defaultdict(int)
-for f in sorted(glob.glob(f"{root}/**/*counter_collection.csv", recursive=True)):
+for f in sorted(glob.glob(f"{a.root}/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void omok::", "")[:36]
+        k = r["Kernel_Name"].split("(")[0].replace("void omok::", "").replace("omok::", "")[:40]
         agg[(k, r["Counter_Name"])] += float(r["Counter_Value"])
         n[(k, r["Counter_Name"])] += 1
 for (k, c), v in sorted(agg.items()):
-    if any(t in k for t in ("fc0", "trunk", "gemm")):
-        print(f"{k:38s} {c:32s} {v:14.5g}  ({n[(k, c)]} dispatch rows)")
+    print(f"{k:42s} {c:32s} {v:14.5g}  ({n[(k, c)]} dispatch rows)")
+if a.json:
+    def tot(prefixes, counter):
+        return sum(v for (k, c), v in agg.items() if c == counter and any(k.startswith(p) for p in prefixes))
+    out = {"board": a.board, "rows": a.rows, "sims": a.sims, "unit": "bytes", "source": a.root,
+           "method": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE [KiB] x 1024; raw (x1) fetch kept beside it"}
+    for name, pre in (("k_trunk", ["k_trunk"]), ("k_fc0_mx", ["k_fc0_mx", "k_splitk_finish"]),
+                      ("tree", ["k_round", "k_scan", "k_fill", "k_scatter", "k_add_evals"])):
+        f, w = tot(pre, "FETCH_SIZE") * 1024.0, tot(pre, "WRITE_SIZE") * 1024.0
+        denom = a.sims if name == "tree" else a.rows
+        key = "tree_hbm_bytes_per_sim" if name == "tree" else f"{name}_hbm_bytes_per_row"
+        if denom > 0 and (f > 0 or w > 0):
+            out[key] = (2.0 * f + w) / denom
+            out[key + "_fetch_raw_x1"] = (f + w) / denom
+            out[key.replace("hbm_bytes", "fetch_bytes_x2")] = 2.0 * f / denom
+            out[key.replace("hbm_bytes", "write_bytes")] = w / denom
+    json.dump({str(a.board): out}, open(a.json, "w"), indent=1)
+    print(json.dumps(out, indent=1))
