@@ -77,7 +77,7 @@ def self_launch(args):
     touched the GPU yet (torch.cuda.device_count() does not initialise it on this image)."""
     import torch
     backend = os.environ.get("OMOK_BENCH_BACKEND", "nccl")
-    have = torch.cuda.device_count() if backend == "nccl" else args.gpus
+    have = torch.cuda.device_count() if backend == "nccl" else args.gpus  # (gloo rehearsal: ranks may share a GPU)
     if have < args.gpus:
         msg = f"--gpus {args.gpus}: {args.gpus} GPUs needed, {have} visible on this host; nothing was run"
         print(json.dumps({"error": msg, "n_gpus": args.gpus, "gpus_visible": have, "value": None}), flush=True)
@@ -253,13 +253,16 @@ def main():
     import torch.distributed as dist
 
     backend = os.environ.get("OMOK_BENCH_BACKEND", "nccl")
-    use_cuda = backend == "nccl"
-    device = f"cuda:{local_rank}" if use_cuda else "cpu"
+    mock = "OMOK_BENCH_ENGINE" in os.environ
+    use_cuda = not mock  # the engine's device; with the gloo backend (rehearsals on a 1-GPU box) the collectives run on CPU tensors
+    ndev = torch.cuda.device_count() if use_cuda else 0
+    gpu = local_rank % ndev if ndev else 0  # (a gloo rehearsal may put several ranks on one GPU; RCCL runs never do)
+    device = f"cuda:{gpu}" if backend == "nccl" else "cpu"
     if use_cuda:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(gpu)
     if world > 1:
-        if use_cuda:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
         else:
             dist.init_process_group(backend)
 
@@ -271,7 +274,7 @@ def main():
     max_nodes = args.max_nodes or min(16384, 4 * args.sims + 1024)
     max_tables = args.max_tables or max(256, max_nodes // 4)
     eng = oa.Engine(board_size=n, games=games, max_nodes=max_nodes, max_tables=max_tables, max_batch_k=k,
-                    device=local_rank, net_mode=B.NET_F16X3 if args.net_mode == "f16x3" else B.NET_F32,
+                    device=gpu, net_mode=B.NET_F16X3 if args.net_mode == "f16x3" else B.NET_F32,
                     seed=args.seed, game_offset=oa.dist.game_offset(rank, games))
     eng.load_random_weights(0)
     sp = oa.SelfPlay(eng)
@@ -286,7 +289,7 @@ def main():
             torch.cuda.synchronize()
 
     rec = sp.replay_record_bytes()
-    gather_buf = torch.empty(games * n * n * rec, dtype=torch.uint8, device=device) if args.gather else None
+    gather_buf = torch.empty(games * n * n * rec, dtype=torch.uint8, device=f"cuda:{gpu}" if use_cuda else "cpu") if args.gather else None
     gathered = {"records": 0, "bytes": 0, "seconds": 0.0}
 
     def episode(max_plies):
@@ -296,7 +299,7 @@ def main():
             t1 = time.perf_counter()
             cnt = sp.pack_tensor(gather_buf, rec) if hasattr(sp, "pack_tensor") else sp.replay_pack_into(gather_buf.data_ptr(), gather_buf.numel() // rec)
             live = gather_buf[: cnt * rec].view(cnt, rec)
-            allrec, counts = oa.dist.gather_replay(live)  # counts exchange + exact-size all-gather-v
+            allrec, counts = oa.dist.gather_replay(live if backend == "nccl" or not use_cuda else live.cpu())  # counts exchange + exact-size all-gather-v
             if use_cuda:
                 torch.cuda.synchronize()
             gathered["last_counts"] = counts
@@ -418,7 +421,7 @@ def main():
     if use_cuda and world == 1 and complete:
         if args.precision_rows > 0 and room(25):
             try:
-                out["precision"] = precision_check(args, args.precision_rows, local_rank)
+                out["precision"] = precision_check(args, args.precision_rows, gpu)
             except Exception as ex:
                 out["precision"] = {"error": repr(ex)}
             extras = True
