@@ -354,12 +354,14 @@ def main():
     def mfma_roofline(kernel, flop_row, note):
         sec = k_ms[kernel] * 1e-3
         ach = rows * flop_row / sec / 1e12 if sec > 0 else 0.0
-        per_row = pmc.get(kernel + "_hbm_bytes_per_row") or PMC_HBM_BYTES_PER_ROW.get(n, {}).get(kernel)
+        per_row = pmc.get(kernel + "_hbm_bytes_per_row_calibrated") or pmc.get(kernel + "_hbm_bytes_per_row") or PMC_HBM_BYTES_PER_ROW.get(n, {}).get(kernel)
+        per_row_x2 = pmc.get(kernel + "_hbm_bytes_per_row")
         alg_row = {"k_trunk": 2 * 8 * ((hw + 63) // 64) + 16 + 384.0 * hw, "k_fc0_mx": 384.0 * hw + 2048}[kernel]
         return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / F16_DENSE_PEAK_TFLOPS, "traffic": per_row * rows / launches if per_row else None,
-                "traffic_unit": "HBM bytes per (average) launch: per-row bytes of the committed rocprofv3 --pmc pass "
-                                "(FETCH_SIZE x 2 + WRITE_SIZE, profiles/README.md) x rows per launch",
+                "traffic_uncalibrated_x2": per_row_x2 * rows / launches if per_row_x2 else None,
+                "traffic_unit": "HBM bytes per (average) launch: per-row bytes of the committed rocprofv3 --pmc pass (profiles/pmc_bytes.json: "
+                                "FETCH_SIZE x 2 + WRITE_SIZE; fc0 calibrated for its 64-B residual requests, the flat x2 figure beside it) x rows per launch",
                 "algorithmic_bytes_per_launch": alg_row * rows / launches + ({"k_trunk": 110e3, "k_fc0_mx": 128.0 * hw * 512 * 3}[kernel]),
                 "avg_launch_ms": k_ms[kernel] / launches, "rows_per_launch": rows / launches, "share_of_kernel_time": k_ms[kernel] / max(sum(k_ms.values()), 1e-9),
                 "note": note}
