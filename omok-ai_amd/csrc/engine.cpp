@@ -588,7 +588,7 @@ static void enqueue_round(omok_engine* e, int round, int K, float eps, float alp
     k_add_evals<<<1, 64, 0, e->st>>>(e->S.d_count, e->d_evals);
     e->prof.end(e->st);
     if (eval_and_scatter) {
-        net_forward_requests(e->net, e->S, alive * K, e->st, &e->prof);
+        net_forward_requests(e->net, e->S, alive * K, e->st, &e->prof, side);
         e->prof.begin(PC_TREE_OTHER, e->st);
         launch_scatter(e->n, e->S, side, e->net.p, e->net.v, alive * K, e->st);
         e->prof.end(e->st);
@@ -911,7 +911,7 @@ extern "C" int omok_round_eval(omok_engine* e) {
     if (need_net(e)) return OMOK_ERR_STATE;
     if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
     if (e->round_reqs == 0) return OMOK_OK;
-    net_forward_requests(e->net, e->S, e->round_cap, e->st, &e->prof);
+    net_forward_requests(e->net, e->S, e->round_cap, e->st, &e->prof, e->ply & 1);
     return sync_and_check(e, "round_eval") ? OMOK_ERR_HIP : OMOK_OK;
 }
 extern "C" int omok_round_outputs(omok_engine* e, float* p, float* v) {

@@ -38,6 +38,12 @@ struct Net {
     size_t part_rows = 0;     // capacity of the split-K partial slab `part` in rows (x 512 floats)
     float* part = nullptr;    // split-K fp32 partials of fc0 for small batches
     int32_t* d_chunk = nullptr; // [64][4] live row count of every row chunk of a forward (see forward_chunked)
+    // sibling path of the trunk (N = 15): runs of sibling requests, remaining single rows, counters, per-workgroup base scratch
+    void* d_groups = nullptr;
+    int32_t* d_singles = nullptr;
+    void* d_sib_rows = nullptr; // (request row, run) of the rows inside runs
+    int32_t* d_gcnt = nullptr;  // [0] runs, [1] rows outside runs, [2] rows inside runs
+    float* sib_h = nullptr;     // [run][3 blocks][225][32] the base passes' depthwise inputs
     int mx_sw = 0;            // fc0 weights: fp8 copies are w * 2^mx_sw (hi) and (w - f16(w)) * 2^(mx_sw + 11) (lo)
     size_t bytes = 0;         // device bytes held
 };
@@ -67,7 +73,9 @@ inline int64_t net_tensor_size(int n, int idx) {
 // net_kernels.hip
 // Forward of the `count` samples described by S.req_ref/req_aux (count read from S.d_count on the
 // device; grids are sized for max_count).  Results in net.p / net.v.
-void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, struct Prof* prof);
+// sibling_side >= 0: the rows are the requests of a search round of that side's trees (S.ts / S.req_node describe them): runs of
+// sibling requests take the incremental trunk path.  -1: plain rows (mirror evaluations, shared-tree rounds).
+void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, struct Prof* prof, int sibling_side = -1);
 // Forward of explicit f32 inputs already in net.in_f32 ([count][3HW]); count is a host value
 // and must also be stored in S.d_count[0] by the caller.
 void net_forward_inputs(Net& net, const Store& S, int count, hipStream_t st, struct Prof* prof);

@@ -51,6 +51,7 @@ __device__ inline float lrelu(float x) {
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ inline void nt_store(const uint4& v, uint4* p) { __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, (u32x4*)p); }
+__device__ inline uint4 nt_load(const uint4* p) { const u32x4 v = __builtin_nontemporal_load((const u32x4*)p); return make_uint4(v[0], v[1], v[2], v[3]); }
 typedef short short2v __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x6 __attribute__((ext_vector_type(6)));
 typedef float f32x16v __attribute__((ext_vector_type(16)));
@@ -243,12 +244,19 @@ struct TrunkGeo {
 #ifndef TRUNK_PRIO
 #define TRUNK_PRIO 0
 #endif
-template <int N, bool FROM_F32, int ABL = 0> // ABL: timing-only ablations (1 = no depthwise exchange, 2 = no operand epilogue, 4 = no conv_in, 8 = epilogue without the global stores)
+template <int N, bool FROM_F32, int ABL = 0> // ABL: timing-only ablations (1 = no depthwise exchange, 2 = no operand epilogue, 4 = no conv_in, 8 = epilogue without the global stores);
+                                             // 16 = BASE mode of the sibling path (not an ablation): see k_group / k_sib_children below
 __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_t* __restrict__ req_ref, const uint32_t* __restrict__ req_aux,
                                                                     const uint64_t* __restrict__ board, const NodeHdr* __restrict__ hdr,
                                                                     const int32_t* __restrict__ d_count, int cap_nodes, const float* __restrict__ in_f32,
                                                                     const uint4* __restrict__ wt, const float* __restrict__ side,
-                                                                    uint4* __restrict__ a_out, size_t row_u4, int max_count) {
+                                                                    uint4* __restrict__ a_out, size_t row_u4, int max_count,
+                                                                    const int32_t* __restrict__ row_list, const int32_t* __restrict__ d_nrows,
+                                                                    const uint2* __restrict__ groups, float* __restrict__ hscr) {
+    // row_list != NULL: the kernel evaluates the request rows row_list[0 .. d_nrows[0]) (the rows outside the sibling runs).
+    // BASE: sample i is the BASE position of sibling run groups[i] -- the parent's board with the children's side to move; its
+    // operand row goes to a_out[i] (the base-row buffer) and the depthwise inputs of its three blocks to hscr[i][blk][pixel][32].
+    constexpr bool BASE = (ABL & 16) != 0;
     using TG = TrunkGeo<N>;
     constexpr int HW = TG::HW, NW = Geo<N>::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -267,8 +275,11 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
     for (int i = tid; i < TR_SIDE_FLOATS; i += blockDim.x) ((float*)lside)[i] = side[i];
     for (int i = tid; i < TG::SPW * (TG::GRID_BYTES / 4); i += blockDim.x) ((float*)(smem + TR_WBYTES))[i] = 0.0f;
     __syncthreads();
-    int count = d_count[0];
+    int count = (row_list || BASE) ? d_nrows[0] : d_count[0];
     if (count > max_count) count = max_count;
+    auto rowof = [&](int i) { return BASE ? i : (row_list ? (int)row_list[i] : i); };                 // output row (and request row) of sample i
+    auto refof = [&](int i) { return BASE ? req_ref[groups[i].x] : req_ref[rowof(i)]; };              // BASE: the run's first child
+    auto auxof = [&](int i) { return BASE ? 0xFFFFFFFFu : req_aux[rowof(i)]; };
     // depthwise work items are dealt to lanes in the order of the ds_read_b128 lane groups ({0-3,12-15,20-27},
     // {4-11,16-19,28-31} per half): each group then holds two strips 8 pixels apart = 16 distinct 16-B slots of the
     // 256-B bank row (halo-grid row stride 36 floats); lane order gave a 2-way conflict on every window read
@@ -326,8 +337,10 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
             in.f[0] = f[0]; in.f[1] = f[1]; in.f[2] = f[2];
         } else {
             const size_t tn = (size_t)(ref >> 16) * (size_t)cap_nodes + (size_t)(ref & 0xFFFFu);
+            size_t tb = tn;
+            if (BASE) tb = (size_t)(ref >> 16) * (size_t)cap_nodes + (size_t)(((const uint32_t*)hdr)[tn * 4] & 0xFFFFu); // NodeHdr::parent: the board without the child's stone
 #pragma unroll
-            for (int i = 0; i < 2 * NW; ++i) in.bb[i] = board[tn * (2 * NW) + i];
+            for (int i = 0; i < 2 * NW; ++i) in.bb[i] = board[tb * (2 * NW) + i];
             in.turn = (int)((((const uint32_t*)hdr)[tn * 4 + 2] >> 16) & 0xFFu); // NodeHdr::turn (byte 10) through a dword: scalar load
         }
         return in;
@@ -344,15 +357,17 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
     const int b_first = (int)blockIdx.x * TG::SPW + slot;
     const int b_stride = (int)gridDim.x * TG::SPW;
     uint32_t ref_n = 0, aux_n = 0xFFFFFFFFu;
-    if (!FROM_F32 && b_first < count) { ref_n = req_ref[b_first]; aux_n = req_aux[b_first]; }
-    SampleIn in = load_in(b_first < count ? b_first : 0, ref_n, aux_n);
+    if (!FROM_F32 && b_first < count) { ref_n = refof(b_first); aux_n = auxof(b_first); }
+    SampleIn in = load_in(b_first < count ? rowof(b_first) : 0, ref_n, aux_n);
 
     for (int b0 = (int)blockIdx.x * TG::SPW; b0 < count; b0 += b_stride) { // uniform trip count over the workgroup (barriers inside)
-        const int b = b0 + slot;
-        const bool active = b < count; // a slot without a sample in the last pass runs along (for the barriers) and stores nothing
-        const int b_next = b + b_stride;
-        const bool has_next = b_next < count;
-        if (!FROM_F32 && has_next) { ref_n = req_ref[b_next]; aux_n = req_aux[b_next]; } // used at the end of this sample
+        const int bi = b0 + slot;
+        const bool active = bi < count; // a slot without a sample in the last pass runs along (for the barriers) and stores nothing
+        const int b = active ? rowof(bi) : 0;
+        const int bi_next = bi + b_stride;
+        const bool has_next = bi_next < count;
+        const int b_next = has_next ? rowof(bi_next) : 0;
+        if (!FROM_F32 && has_next) { ref_n = refof(bi_next); aux_n = auxof(bi_next); } // used at the end of this sample
         // ---- conv_in 1x1 3->128 + bias + lrelu as one 16-deep k-step: k = (f0, f1, f2, 1, 0...) on lane-half 0, where f0..f2 are
         //      the pixel's three input floats in the flat encoder.rs layout ----
         half8 bh, bl;
@@ -474,6 +489,13 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                 }
             }
             lds_barrier(); // B2: h of the whole sample is in the halo grid
+            if (BASE && active) { // the base's depthwise input of this block -> scratch: the children's halo rings read it (225 pixels x 8 pieces of 16 B)
+                for (int i = stid; i < HW * 8; i += TG::THREADS) {
+                    const int p = i >> 3, piece = i & 7;
+                    *(uint4*)(hscr + ((size_t)b * 3 + blk) * (HW * NM) + p * NM + piece * 4) =
+                        *(const uint4*)(grid + ((p / N + 1) * (N + 2) + (p % N + 1)) * GRID_STRIDE + piece * 4);
+                }
+            }
             // depthwise 3x3 SAME (zero halo), no bias.  Work item = (board row, 4-pixel strip, 4-channel
             // group): one 3x6 window of b128 loads serves 4 output pixels; taps in (dy,dx) order.
             f32x4 dout[TG::DW_ITER][TG::SW];
@@ -563,7 +585,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                 LRELU16(x[m]);
             }
         }
-        in = load_in(has_next ? b_next : (active ? b : 0), ref_n, aux_n); // next sample's inputs first (see load_in)
+        in = load_in(has_next ? b_next : b, ref_n, aux_n); // next sample's inputs first (see load_in)
         // ---- fc0 operand row (k_fc0_mx): per (tile, channel half q) one 6-KiB block: f16 hi pieces [pxl 32][piece
         //      (2j+h) 8][16 B] with j = 2*(m&1)+s, then fp8 residual (x - hi)*2^(SA+11) pieces [pxl 32][piece (2h+e) 4][16 B]
         //      (the fp8 copy of hi is derived inside k_fc0_mx).  One K=64 super-step of fc0 = one pixel of one block. ----
@@ -575,7 +597,10 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
         //      (Lanes past the last pixel skip the LDS write; the read-back side then stores the clamped pixel's data into
         //      the pad slots of the row: no branch around the global stores, so the compiler counts them exactly.)
         if (!(ABL & 2)) {
-            uint4* row = a_out + (size_t)b * row_u4;
+            // BASE: the row is stored into EVERY child row of the run (the rows fc0 reads must exist; k_sib_children then overwrites
+            // each child's 7x7 window): `row` = the first child's row, the others follow at the row stride
+            uint4* row = a_out + (size_t)(BASE ? (active ? groups[bi].x : 0u) : (uint32_t)b) * row_u4;
+            const int copies = BASE ? (active ? (int)groups[bi].y : 0) : 1;
             const float sc_lo_inv = __uint_as_float((uint32_t)(127 - MX_SA - 11) << 23); // fp8 = (x - hi) / 2^-(SA+11)
             uint4* stage_w = (uint4*)(grid + gi * GRID_STRIDE);          // this lane's pixel row (8 slots of 16 B)
             uint32_t p8l[2][8];
@@ -628,7 +653,13 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const uint4 v = *(const uint4*)(grid + st_gi[i] * GRID_STRIDE + 4 * (lane & 7));
-                    if (!(ABL & 8)) { if (st_ok[i] && active) nt_store(v, &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + (8 * i + (lane >> 3)) * 8 + (lane & 7)]); }
+                    if (!(ABL & 8)) {
+                        if (st_ok[i] && active) {
+                            uint4* dst = &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + (8 * i + (lane >> 3)) * 8 + (lane & 7)];
+                            if (BASE) for (int c = 0; c < copies; ++c) nt_store(v, dst + (size_t)c * row_u4);
+                            else nt_store(v, dst);
+                        }
+                    }
                     else if (v.x == 0x12345678u && v.y == 0x9abcdef0u) row[lane] = v; // timing only: keep the staging alive
                 }
             }
@@ -649,9 +680,428 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
             for (int i = 0; i < 4; ++i) {
                 const uint4 v = *(const uint4*)(grid + st_gi[i] * GRID_STRIDE + 4 * (lane & 7));
                 const int q = (lane >> 2) & 1;
-                if (!(ABL & 8)) { if (st_ok[i] && active) nt_store(v, &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (8 * i + (lane >> 3)) * 4 + (lane & 3)]); }
+                if (!(ABL & 8)) {
+                    if (st_ok[i] && active) {
+                        uint4* dst = &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (8 * i + (lane >> 3)) * 4 + (lane & 3)];
+                        if (BASE) for (int c = 0; c < copies; ++c) nt_store(v, dst + (size_t)c * row_u4);
+                        else nt_store(v, dst);
+                    }
+                }
                 else if (v.x == 0x12345678u && v.y == 0x9abcdef0u) row[lane] = v;
             }
+        }
+    }
+}
+
+// ===============================================================================================
+// OMOK_NET_F16X3: trunk for SIBLING requests (N = 15): k_group, k_trunk<.., BASE>, k_sib_children
+// ===============================================================================================
+// The K requests a tree contributes to a round are, almost always, children of ONE leaf (tree_kernels.hip: between two backups
+// the PUCT descent reaches the same leaf, and a round has no backups except terminal ones; measured: 99.6 % of the request rows
+// of configs[1] sit in runs of >= 4 siblings, 90 % of the runs are full K = 16).  Siblings are positions that differ in one
+// stone, and the trunk is local: 1x1 convolutions plus three 3x3 depthwise stages.  A child's trunk activations therefore equal
+// those of a shared BASE position (the parent's board with the child's side to move) everywhere outside the 7x7 window around
+// the pixel its stone changes (the flat encoder.rs layout puts the stone's float into pixel (2a + 1) / 3).  Per round:
+//   k_group          runs of siblings in the request list (first row, length >= SIB_MIN), the rows inside runs, the other rows
+//   k_trunk<BASE>    the whole trunk once per run for the base position; its fc0 operand row is stored into EVERY child row of
+//                    the run (the rows fc0 reads must exist: 86 KB per request, the HBM-write floor of this path), the depthwise
+//                    inputs (h grids) of its three blocks go to a scratch
+//   k_sib_children   per child ONE 7x7 window (49 pixels = two 32-pixel MFMA tiles = a wave pair; four children per workgroup
+//                    pass): conv_in and the three blocks on the window only, the depthwise halo ring taken from the base's h
+//                    grid of the same block; the window's 49 pixel entries overwrite the base's in the child's row
+//   k_trunk<rows>    the rows outside runs, as before
+// Every pixel goes through the same operations in the same order as in k_trunk (MFMA columns are independent, the depthwise taps
+// accumulate in (dy, dx) order, operand-row entries are per pixel), so the rows are BIT-IDENTICAL to a full evaluation; the MFMA
+// work per child falls from 8 tiles to 2 + 8 / (run length).
+constexpr int SIB_MIN = 3;                       // runs shorter than this go to k_trunk (a base pass would not pay)
+constexpr int SIB_WIN = 7, SIB_GW = SIB_WIN + 2; // window side, child grid side (window + halo ring)
+constexpr int SIB_CGRID_ROWS = SIB_GW * SIB_GW + 1;
+constexpr int SIB_CGRID_BYTES = SIB_CGRID_ROWS * GRID_STRIDE * 4; // 11808
+constexpr int SIB_HB_FLOATS = 225 * NM;          // one base h grid in the scratch: [pixel][32]
+
+// cnt[0] runs, cnt[1] rows outside runs, cnt[2] rows inside runs.  sib_rows[i] = descriptor of a row inside a run: (request row, run
+// index, node record index t * cap_nodes + node, turn | action << 8); a run's rows are adjacent.
+__global__ __launch_bounds__(64) void k_group(Store S, int side, uint2* __restrict__ groups, int32_t* __restrict__ singles, uint4* __restrict__ sib_rows,
+                                              int32_t* __restrict__ cnt) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!S.gs[g].alive) return;
+    const int t = side * S.games + g;
+    const TreeState ts = S.ts[t];
+    const int n = (int)ts.n_req;
+    if (n == 0) return;
+    int parent = -1 - lane; // distinct for the lanes beyond the list
+    uint32_t tn = 0, ta = 0;
+    if (lane < n) {
+        tn = (uint32_t)t * (uint32_t)S.cap_nodes + S.req_node[(size_t)t * KMAX + lane];
+        const NodeHdr hd = S.hdr[tn];
+        parent = hd.parent;
+        ta = (uint32_t)hd.turn | ((uint32_t)hd.action << 8);
+    }
+    const int prev = __shfl_up(parent, 1, 64);
+    const bool start = lane < n && (lane == 0 || parent != prev);
+    const unsigned long long starts = __ballot(start);
+    // the run a lane belongs to: its start = highest start bit at or below the lane; its end = the next start bit above (or n)
+    const unsigned long long below = starts & ((lane == 63 ? 0ULL : (1ULL << (lane + 1))) - 1ULL);
+    const int rs = below ? 63 - __clzll((long long)below) : 0;
+    const unsigned long long above = starts & ~((1ULL << rs) | ((1ULL << rs) - 1ULL));
+    const int re = above ? __ffsll((long long)above) - 1 : n;
+    const int len = re - rs;
+    int gslot = 0, rbase = 0;
+    if (start && len >= SIB_MIN) {
+        gslot = atomicAdd(&cnt[0], 1);
+        rbase = atomicAdd(&cnt[2], len);
+        groups[gslot] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)len);
+    }
+    gslot = __shfl(gslot, rs, 64);
+    rbase = __shfl(rbase, rs, 64);
+    if (lane < n) {
+        if (len >= SIB_MIN) sib_rows[rbase + (lane - rs)] = make_uint4(ts.req_base + (uint32_t)lane, (uint32_t)gslot, tn, ta);
+        else singles[atomicAdd(&cnt[1], 1)] = (int32_t)(ts.req_base + (uint32_t)lane);
+    }
+}
+
+__global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict__ board, const uint4* __restrict__ wt, const float* __restrict__ side,
+                                                      uint4* __restrict__ a_out, size_t row_u4, const uint4* __restrict__ sib_rows,
+                                                      const int32_t* __restrict__ d_cnt, const float* __restrict__ hscr) {
+    constexpr int N = 15;
+    using TG = TrunkGeo<N>;
+    constexpr int HW = TG::HW, NW = Geo<N>::NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const half8* ldsW = (const half8*)smem;
+    float* grid = (float*)(smem + TR_WBYTES);                                       // four child grids
+    const float* lside = (const float*)(smem + TR_WBYTES + 4 * SIB_CGRID_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+    for (int i = tid; i < TR_WBYTES / 16; i += blockDim.x) ((uint4*)smem)[i] = wt[i];
+    for (int i = tid; i < TR_SIDE_FLOATS; i += blockDim.x) ((float*)lside)[i] = side[i];
+    for (int i = tid; i < SIB_CGRID_BYTES; i += blockDim.x) grid[i] = 0.0f; // (4 grids x 11808 / 4 floats)
+    __syncthreads();
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    const int nsib = d_cnt[2];
+    const half8* convW = (const half8*)(wt + TR_WBYTES / 16);
+    half8 cwh[4], cwl[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        cwh[m] = convW[m * 64 + lane];
+        cwl[m] = convW[(4 + m) * 64 + lane];
+    }
+    // wave pair = child, wave parity = window tile
+    const int pair = wv >> 1, wt2 = wv & 1, ptid = tid & 127;
+    const int c_w = 32 * wt2 + l31;            // window pixel of this lane, row-major in the 7x7 window
+    const bool c_valid = c_w < SIB_WIN * SIB_WIN;
+    const int c_wc = c_valid ? c_w : SIB_WIN * SIB_WIN - 1;
+    const int c_wy = c_wc / SIB_WIN, c_wx = c_wc % SIB_WIN;
+    const int c_gi = (c_wy + 1) * SIB_GW + (c_wx + 1);
+    float* cgrid = grid + pair * (SIB_CGRID_BYTES / 4);
+
+    // the shared per-tile arithmetic (k_trunk's, verbatim): operands are the tile's residual stream x and the LDS weights
+    auto L0_tile = [&](const f32x16 (&x)[4], int blk, f32x16& acc) {
+        const half8* W = ldsW + (size_t)blk * TR_FRAGS_PER_BLOCK * 64;
+        const float* b0 = lside + blk * TR_SIDE_PER_BLOCK + 9 * NM;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *(const f32x4*)(b0 + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[4 * g + i] = bv[i];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = x[ks >> 1][8 * (ks & 1) + j];
+            half8 bh, bl;
+            split8(v, bh, bl);
+            const half8 ah = W[(0 + ks) * 64 + lane], al = W[(8 + ks) * 64 + lane];
+            MFMA3(ah, al, bh, bl, acc);
+        }
+    };
+    auto L1L2_tile = [&](f32x16 (&x)[4], int blk, const float* d) {
+        const half8* W = ldsW + (size_t)blk * TR_FRAGS_PER_BLOCK * 64;
+        const float* sd = lside + blk * TR_SIDE_PER_BLOCK;
+        const float *b1 = sd + 10 * NM, *b2 = b1 + NM;
+        f32x16 accg;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *(const f32x4*)(b1 + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accg[4 * g + i] = bv[i];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 bh, bl;
+            split8(d + 8 * ks, bh, bl);
+            const half8 ah = W[(16 + ks) * 64 + lane], al = W[(18 + ks) * 64 + lane];
+            MFMA3(ah, al, bh, bl, accg);
+        }
+        float gv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gv[i] = accg[i];
+        LRELU16(gv);
+        half8 gh[2], gl[2];
+        split8(gv, gh[0], gl[0]);
+        split8(gv + 8, gh[1], gl[1]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4*)(b2 + 32 * m + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[m][4 * g + i] += bv[i];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const half8 ah = W[(20 + m * 2 + ks) * 64 + lane], al = W[(28 + m * 2 + ks) * 64 + lane];
+                MFMA3(ah, al, gh[ks], gl[ks], x[m]);
+            }
+            LRELU16(x[m]);
+        }
+    };
+    auto conv_in_tile = [&](f32x16 (&x)[4], uint32_t b0, uint32_t b1, uint32_t b2) { // the pixel's three input bits
+        union { uint32_t u[4]; half8 v; } Bq;
+        Bq.u[0] = h == 0 ? (b0 * 0x3C00u) | (b1 * 0x3C000000u) : 0u;
+        Bq.u[1] = h == 0 ? (b2 * 0x3C00u) | 0x3C000000u : 0u;
+        Bq.u[2] = 0u;
+        Bq.u[3] = 0u;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[m][i] = 0.0f;
+            x[m] = MFMA16(cwh[m], Bq.v, x[m]);
+            x[m] = MFMA16(cwl[m], Bq.v, x[m]);
+            LRELU16(x[m]);
+        }
+    };
+    // the three input bits of board pixel px (flat encoder.rs layout, Player mode) from the position's words in LDS: wsrc[0..3]
+    // black, [4..7] white (one u64 each), turn = side to move
+    auto input_bits = [&](const uint64_t* wsrc, int turn, int px, uint32_t (&bits)[3]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int m = 3 * px + c;
+            if (m >= 2 * HW) { bits[c] = turn == 0 ? 1u : 0u; continue; }   // encoder.rs:34-37
+            const int cell = m >> 1;
+            const bool want_black = ((m & 1) == 0) == (turn == 0);           // even slot = the side to move's stones (encoder.rs:24-27)
+            const uint64_t w = wsrc[(want_black ? 0 : NW) + (cell >> 6)];
+            bits[c] = (uint32_t)((w >> (cell & 63)) & 1ULL);
+        }
+    };
+    // operand-row entries of the tile's pixels (k_trunk's epilogue): channel half q of the lane's pixel staged at `stage_w`, then
+    // the pixel `rp` whose 8 pieces lanes 8i..8i+7 read back from `rd_rows[i]` is stored at its place in `row`
+    auto store_rows = [&](const f32x16 (&x)[4], uint4* row, bool lane_valid, float* stage_row, const int (&rd_gi)[4], const int (&rd_px)[4],
+                          const bool (&rd_ok)[4], float* gbase) {
+        uint4* stage_w = (uint4*)stage_row;
+        u32x6 lo6[2];
+        uint32_t esc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float res[32], amax_v = 0.0f, amax_l = 0.0f;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    union { uint32_t u[4]; uint4 v; } H;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float v0 = x[2 * q + mm][8 * sx + 2 * jj], v1 = x[2 * q + mm][8 * sx + 2 * jj + 1];
+                        const uint32_t ph = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v0, v1}, half2v));
+                        H.u[jj] = ph;
+                        float l0, l1;
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ph), "v"(v0));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph), "v"(v1));
+                        const int slot = 16 * mm + 8 * sx + 2 * jj;
+                        res[slot] = l0; res[slot + 1] = l1;
+                        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax_v) : "v"(v0), "v"(v1));
+                        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax_l) : "v"(l0), "v"(l1));
+                    }
+                    if (lane_valid) stage_w[(mm * 2 + sx) * 2 + h] = H.v;
+                }
+            int eh = (int)((__float_as_uint(amax_v) >> 23) & 0xFFu) - 2, el = (int)((__float_as_uint(amax_l) >> 23) & 0xFFu) - 2;
+            eh = eh < 1 ? 1 : eh;
+            el = el < 1 ? 1 : el;
+            esc[q] = (uint32_t)eh | ((uint32_t)el << 8);
+            f32x16v ev, od;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ev[i] = res[2 * i]; od[i] = res[2 * i + 1]; }
+            lo6[q] = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, __uint_as_float((uint32_t)el << 23));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 v = *(const uint4*)(gbase + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
+                if (rd_ok[i]) nt_store(v, &row[(size_t)((rd_px[i] >> 5) * 2 + q) * OP_BLK_U4 + (rd_px[i] & 31) * 8 + (lane & 7)]);
+            }
+        }
+        if (lane_valid) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                stage_w[q * 4 + h] = make_uint4(lo6[q][0], lo6[q][1], lo6[q][2], lo6[q][3]);
+                ((uint2*)(stage_w + q * 4 + 2))[h] = make_uint2(lo6[q][4], lo6[q][5]);
+                ((uint16_t*)(stage_w + q * 4 + 3))[h] = (uint16_t)esc[q];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = *(const uint4*)(gbase + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
+            const int q = (lane >> 2) & 1;
+            if (rd_ok[i]) nt_store(v, &row[(size_t)((rd_px[i] >> 5) * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (rd_px[i] & 31) * 4 + (lane & 3)]);
+        }
+    };
+
+    // A child's descriptor and board words are fetched ONE PASS AHEAD (a dependent pair of loads: their latency runs under the
+    // current pass), its halo ring ONE BLOCK ahead.
+    f32x16 x[4];
+    auto fetch_desc = [&](int e0) { // descriptor of this pair's child in the pass that starts at entry e0
+        const int ei = e0 + pair;
+        return sib_rows[ei < nsib ? ei : (e0 < nsib ? e0 : 0)];
+    };
+    auto fetch_word = [&](const uint4& ent) { // lanes 0..7: the child's board words
+        uint64_t word = 0ULL;
+        if (lane < 2 * NW) word = board[(size_t)ent.z * (2 * NW) + lane];
+        return word;
+    };
+    auto window_of = [&](const uint4& ent, int& wy0, int& wx0) {
+        const int action = (int)((ent.w >> 8) & 0xFFu);   // NodeHdr::action: the child's stone
+        const int pc = (2 * action + 1) / 3;              // the pixel its float lands in
+        wy0 = pc / N - SIB_WIN / 2;
+        wx0 = pc % N - SIB_WIN / 2;
+        wy0 = wy0 < 0 ? 0 : (wy0 > N - SIB_WIN ? N - SIB_WIN : wy0);
+        wx0 = wx0 < 0 ? 0 : (wx0 > N - SIB_WIN ? N - SIB_WIN : wx0);
+    };
+    auto ring_fetch = [&](const float* hb, int blk, int wy0, int wx0, uint4 (&ring)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = ptid + 128 * u, cell = e >> 3, piece = e & 7; // ring cell 0..31: top row 9, bottom row 9, left 7, right 7
+            int gy, gx;
+            if (cell < 9) { gy = 0; gx = cell; }
+            else if (cell < 18) { gy = SIB_GW - 1; gx = cell - 9; }
+            else if (cell < 25) { gy = cell - 17; gx = 0; }
+            else { gy = cell - 24; gx = SIB_GW - 1; }
+            const int by = wy0 + gy - 1, bx = wx0 + gx - 1;
+            ring[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (by >= 0 && by < N && bx >= 0 && bx < N) ring[u] = *(const uint4*)(hb + (size_t)blk * SIB_HB_FLOATS + (by * N + bx) * NM + piece * 4);
+        }
+    };
+    int ring_off[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = ptid + 128 * u, cell = e >> 3, piece = e & 7;
+        const int gy = cell < 9 ? 0 : cell < 18 ? SIB_GW - 1 : cell < 25 ? cell - 17 : cell - 24;
+        const int gx = cell < 9 ? cell : cell < 18 ? cell - 9 : cell < 25 ? 0 : SIB_GW - 1;
+        ring_off[u] = (gy * SIB_GW + gx) * GRID_STRIDE + piece * 4;
+    }
+    const int pass_stride = (int)gridDim.x * 4;
+    uint4 ent_c = fetch_desc((int)blockIdx.x * 4), ent_n = fetch_desc((int)blockIdx.x * 4 + pass_stride);
+    uint64_t word_c = fetch_word(ent_c);
+    uint4 ring[2];
+    {
+        int wy0, wx0;
+        window_of(ent_c, wy0, wx0);
+        ring_fetch(hscr + (size_t)ent_c.y * 3 * SIB_HB_FLOATS, 0, wy0, wx0, ring);
+    }
+    for (int e0 = (int)blockIdx.x * 4; e0 < nsib; e0 += pass_stride) { // four children per pass; uniform over the workgroup
+        {
+            const bool act = e0 + pair < nsib;
+            const uint4 ent = ent_c;
+            const int crow = (int)ent.x;
+            const float* hb = hscr + (size_t)ent.y * 3 * SIB_HB_FLOATS;
+            const int turn = (int)(ent.w & 0xFFu);
+            int wy0, wx0;
+            window_of(ent, wy0, wx0);
+            const int q = (wy0 + c_wy) * N + (wx0 + c_wx);                                      // this lane's board pixel
+            uint4* crow_p = a_out + (size_t)crow * row_u4;
+            uint64_t* cw = (uint64_t*)(cgrid + (SIB_CGRID_ROWS - 1) * GRID_STRIDE) + wt2 * 8; // the child's 8 board words: the grid's pad row, one copy per wave
+            if (lane < 2 * NW) cw[lane] = word_c;
+            // the next pass's board words (its descriptor arrived a pass ago) and the descriptor of the pass after that
+            const uint64_t word_n = fetch_word(ent_n);
+            const uint4 ent_nn = fetch_desc(e0 + 2 * pass_stride);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            uint32_t bits[3];
+            input_bits(cw, turn, q, bits);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            conv_in_tile(x, bits[0], bits[1], bits[2]);
+#pragma unroll 1
+            for (int blk = 0; blk < 3; ++blk) {
+                const float* dwt = lside + blk * TR_SIDE_PER_BLOCK;
+                f32x16 acc;
+                L0_tile(x, blk, acc);
+                float d[16];
+                if (c_valid) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 o;
+                        const f32x2 r0 = lrelu2(acc[4 * g], acc[4 * g + 1]), r1 = lrelu2(acc[4 * g + 2], acc[4 * g + 3]);
+                        o[0] = r0[0]; o[1] = r0[1]; o[2] = r1[0]; o[3] = r1[1];
+                        *(f32x4*)(cgrid + c_gi * GRID_STRIDE + 8 * g + 4 * h) = o;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) *(uint4*)(cgrid + ring_off[u]) = ring[u]; // halo ring <- the base's h of this block (zero outside the board)
+                lds_barrier(); // B2
+                if (blk < 2) ring_fetch(hb, blk + 1, wy0, wx0, ring);
+                // depthwise over the 7x7 window: (row, strip of 4 | 3 pixels, 4-channel group) = 112 items for the pair's 128 threads
+                f32x4 dout[TG::SW];
+                const int item = ptid < 7 * 2 * 8 ? ptid : 0;
+                const int cg = item & 7, strip = item >> 3;
+                const int y = strip >> 1, x0 = (strip & 1) * TG::SW;
+                {
+                    const float* gp = cgrid + (y * SIB_GW + x0) * GRID_STRIDE + 4 * cg;
+                    f32x4 win[3][TG::SW + 2];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < TG::SW + 2; ++dx) win[dy][dx] = *(const f32x4*)(gp + (dy * SIB_GW + dx) * GRID_STRIDE);
+                    f32x4 w9[9];
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) w9[tap] = *(const f32x4*)(dwt + tap * NM + 4 * cg);
+#pragma unroll
+                    for (int p = 0; p < TG::SW; ++p) {
+                        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int tap = 0; tap < 9; ++tap) {
+                            const f32x4 hv = win[tap / 3][p + tap % 3];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] += hv[c] * w9[tap][c];
+                        }
+                        dout[p] = o;
+                    }
+                }
+                lds_barrier(); // B3
+                if (ptid < 7 * 2 * 8) {
+#pragma unroll
+                    for (int p = 0; p < TG::SW; ++p)
+                        if (x0 + p < SIB_WIN) *(f32x4*)(cgrid + ((y + 1) * SIB_GW + x0 + p + 1) * GRID_STRIDE + 4 * cg) = dout[p];
+                }
+                lds_barrier(); // B4
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 dv = *(const f32x4*)(cgrid + c_gi * GRID_STRIDE + 8 * g + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d[4 * g + i] = dv[i];
+                }
+                L1L2_tile(x, blk, d);
+            }
+            { // the window's 49 pixel entries over the copied base row
+                int rd_gi[4], rd_px[4];
+                bool rd_ok[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int w = 32 * wt2 + 8 * i + (lane >> 3);
+                    const int wc = w < SIB_WIN * SIB_WIN ? w : SIB_WIN * SIB_WIN - 1;
+                    rd_gi[i] = (wc / SIB_WIN + 1) * SIB_GW + (wc % SIB_WIN + 1);
+                    rd_px[i] = (wy0 + wc / SIB_WIN) * N + (wx0 + wc % SIB_WIN);
+                    rd_ok[i] = w < SIB_WIN * SIB_WIN && act;
+                }
+                // the next pass's first halo ring before this pass's stores queue up behind it
+                {
+                    int ny0, nx0;
+                    window_of(ent_n, ny0, nx0);
+                    ring_fetch(hscr + (size_t)ent_n.y * 3 * SIB_HB_FLOATS, 0, ny0, nx0, ring);
+                }
+                store_rows(x, crow_p, c_valid, cgrid + c_gi * GRID_STRIDE, rd_gi, rd_px, rd_ok, cgrid);
+            }
+            ent_c = ent_n;
+            ent_n = ent_nn;
+            word_c = word_n;
+            lds_barrier(); // the staging rows are free again (the next pass writes the pad row / grid)
         }
     }
 }
@@ -1371,6 +1821,13 @@ size_t net_alloc(Net& net) {
         ok = ok && A(&net.a_fc0, mb * row_u4 * 16 + 2 * OP_BLK_U4 * 16); // + slack: the prefetch of the super-step past the last one reads one block beyond the row
         ok = ok && A(&net.h0, mb * 32 * 64 * 2);       // h0 and h1 rows (2 KiB each)
         ok = ok && A((void**)&net.s0, sizeof(float) * mb * heads_mt(net.hw) * 32); // logits
+        if (net.n == 15) { // sibling path of the trunk (k_group / k_trunk_sib): run lists and the per-workgroup base scratch
+            ok = ok && A((void**)&net.d_groups, sizeof(uint2) * (mb / SIB_MIN + 1));
+            ok = ok && A((void**)&net.d_singles, sizeof(int32_t) * mb);
+            ok = ok && A((void**)&net.d_gcnt, sizeof(int32_t) * 4);
+            ok = ok && A((void**)&net.d_sib_rows, sizeof(uint4) * mb);
+            ok = ok && A((void**)&net.sib_h, sizeof(float) * (mb / SIB_MIN + 1) * 3 * SIB_HB_FLOATS);
+        }
         net.part_rows = mb * 3 > 32768 ? mb * 3 : 32768;                                // split-K partials: rows x split ways (2 KiB each)
         ok = ok && A((void**)&net.part, sizeof(float) * net.part_rows * NF);
     }
@@ -1382,7 +1839,8 @@ size_t net_alloc(Net& net) {
 void net_free(Net& net) {
     void** ptrs[] = {(void**)&net.p, (void**)&net.v, (void**)&net.vpre, (void**)&net.in_f32, (void**)&net.sx, (void**)&net.sh, (void**)&net.sd,
                      (void**)&net.sg, (void**)&net.s0, (void**)&net.s1, &net.wt_trunk, (void**)&net.wt_first, &net.wt_fc0,
-                     &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part, (void**)&net.d_chunk};
+                     &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part, (void**)&net.d_chunk, (void**)&net.d_groups,
+                     (void**)&net.d_singles, (void**)&net.d_gcnt, (void**)&net.sib_h, (void**)&net.d_sib_rows};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     for (int i = 0; i < NET_TENSORS; ++i) { if (net.w[i]) hipFree(net.w[i]); net.w[i] = nullptr; }
 }
@@ -1527,7 +1985,7 @@ int net_commit(Net& net, hipStream_t st) {
 }
 
 template <int N, bool FROM_F32, int ABL = 0>
-static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st) {
+static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st, const int32_t* row_list = nullptr, const int32_t* d_nrows = nullptr) {
     using TG = TrunkGeo<N>;
     static bool attr_done[64] = {}; // per device: the attribute belongs to the device's copy of the code object
     auto kern = k_trunk<N, FROM_F32, ABL>;
@@ -1537,7 +1995,8 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
     }
     const int wgs = (max_count + TG::SPW - 1) / TG::SPW;
     const int grid = wgs < 256 ? wgs : 256;
-    kern<<<grid, TG::WG_THREADS, TG::LDS_BYTES, st>>>(S.req_ref, S.req_aux, S.board, S.hdr, S.d_count, S.cap_nodes, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4, max_count);
+    kern<<<grid, TG::WG_THREADS, TG::LDS_BYTES, st>>>(S.req_ref, S.req_aux, S.board, S.hdr, S.d_count, S.cap_nodes, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first,
+                                                       (uint4*)net.a_fc0, net.row_u4, max_count, row_list, d_nrows, (const uint2*)net.d_groups, net.sib_h);
 }
 
 template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
@@ -1556,11 +2015,29 @@ static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_
                                   out_row_u4, out_logits, S.d_count, max_count);
 }
 
-static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof) {
+static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_count, hipStream_t st) {
+    constexpr int LDS = TR_WBYTES + 4 * SIB_CGRID_BYTES + TR_SIDE_FLOATS * 4;
+    static bool attr_done[64] = {};
+    if (!attr_done[net.device & 63]) {
+        hipFuncSetAttribute((const void*)k_sib_children, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_done[net.device & 63] = true;
+    }
+    hipMemsetAsync(net.d_gcnt, 0, 16, st);
+    k_group<<<S.games, 64, 0, st>>>(S, side, (uint2*)net.d_groups, net.d_singles, (uint4*)net.d_sib_rows, net.d_gcnt);
+    const int max_groups = max_count / SIB_MIN + 1;
+    launch_trunk<15, false, 16>(net, S, max_groups, st, nullptr, net.d_gcnt);                 // base positions of the runs
+    k_sib_children<<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
+                                           (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h);
+    launch_trunk<15, false>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1);            // the rows outside the runs
+}
+
+static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1) {
     const int hw = net.hw;
     const int ks0 = hw * 8;
+    static const int use_sib = getenv("OMOK_TRUNK_SIB") ? atoi(getenv("OMOK_TRUNK_SIB")) : 1; // 0: every row through k_trunk
     if (prof) prof->begin(PC_TRUNK, st);
-    if (net.n == 9) { if (from_f32) launch_trunk<9, true>(net, S, max_count, st); else launch_trunk<9, false>(net, S, max_count, st); }
+    if (net.n == 15 && !from_f32 && sib_side >= 0 && use_sib && net.d_groups) launch_trunk_siblings(net, S, sib_side, max_count, st);
+    else if (net.n == 9) { if (from_f32) launch_trunk<9, true>(net, S, max_count, st); else launch_trunk<9, false>(net, S, max_count, st); }
     else {
         static const int abl = getenv("OMOK_ABL_TRUNK") ? atoi(getenv("OMOK_ABL_TRUNK")) : 0; // timing experiments only
         if (from_f32 && abl == 1) launch_trunk<15, true, 1>(net, S, max_count, st);
@@ -1648,10 +2125,10 @@ __global__ void k_chunk_counts(const int32_t* __restrict__ d_count, int max_coun
     out[i * 4] = v < 0 ? 0 : (v > chunk ? chunk : v);
 }
 
-static void forward_chunked(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof) {
+static void forward_chunked(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1) {
     static const int chunk_max = getenv("OMOK_NET_CHUNK") ? atoi(getenv("OMOK_NET_CHUNK")) : NET_CHUNK_DEFAULT;
     if (chunk_max <= 0 || max_count <= chunk_max) {
-        forward_f16x3(net, S, max_count, from_f32, st, prof);
+        forward_f16x3(net, S, max_count, from_f32, st, prof, sib_side);
         return;
     }
     int n_chunks = (max_count + chunk_max - 1) / chunk_max;
@@ -1675,14 +2152,14 @@ static void forward_chunked(Net& net, const Store& S, int max_count, bool from_f
     }
 }
 
-void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, Prof* prof) {
+void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, Prof* prof, int sibling_side) {
     if (max_count <= 0) return;
     if (max_count > net.max_b) max_count = net.max_b;
     if (net.mode == OMOK_NET_F32) {
         launch_encode_requests(net.n, S, net.in_f32, max_count, st);
         forward_f32(net, S, max_count, st, prof);
     } else {
-        forward_chunked(net, S, max_count, false, st, prof);
+        forward_chunked(net, S, max_count, false, st, prof, sibling_side);
     }
 }
 
