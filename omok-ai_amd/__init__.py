@@ -5,4 +5,5 @@ include/omok_mi355x.h); this package is the thin Python host mirror of the refer
 from . import weights  # noqa: F401
 from . import binding  # noqa: F401
 from . import dist  # noqa: F401
+from . import precision  # noqa: F401
 from .api import Engine, Environment, SelfPlay  # noqa: F401

@@ -1,0 +1,35 @@
+"""Precision of the product net path (split-operand MFMA, fp6 correction terms in fc0) against the OMOK_NET_F32 kernels of the
+same library on the same GPU, for a given set of weights and input rows.  The contract (BASELINE.json north_star) is 1e-3 on
+the outputs of AgentModel::evaluate_pv (alpha-zero/src/agent_model.rs:116-134): p after softmax, v after tanh.  fc0's
+correction terms carry 4 significant bits (block-scaled fp6), i.e. products are good to ~2^-16: with random-init weights the
+outputs agree to 1e-4 .. 7e-4, with trained weights the value head has been seen at 1.05e-3 (N = 9, 200 Adadelta steps).  A
+caller that needs the bound unconditionally runs this check after every weight update (`Trainer` does and logs it) and can fall
+back to `net_mode = OMOK_NET_F32`."""
+import numpy as np
+
+from . import api
+from . import binding as B
+
+
+def measure(tensors, n, inputs, device=0, batch_k=16):
+    """dict(max_dp, max_dv, max_dlogit, max_dvpre, logit_abs_max, rows) for float32 `inputs` [R, 3 * n * n] (encoder.rs layout)."""
+    x = np.ascontiguousarray(inputs, dtype=np.float32).reshape(len(inputs), -1)
+    out = {}
+    res = []
+    for mode in (B.NET_F16X3, B.NET_F32):
+        eng = api.Engine(board_size=n, games=64, max_nodes=8, max_tables=4, max_batch_k=batch_k, device=device, net_mode=mode)
+        eng.load_weights(tensors)
+        p, v = eng.evaluate_pv(x)
+        lg, vp = eng.evaluate_logits(x)
+        eng.close()
+        res.append((p.reshape(len(x), -1), v.reshape(-1), lg, vp))
+    (p, v, lg, vp), (p32, v32, lg32, vp32) = res
+    out["rows"] = int(len(x))
+    out["max_dp"] = float(np.abs(p - p32).max())
+    out["max_dv"] = float(np.abs(v - v32).max())
+    out["max_dlogit"] = float(np.abs(lg - lg32).max())
+    out["max_dvpre"] = float(np.abs(vp - vp32).max())
+    out["logit_abs_max"] = float(np.abs(lg32).max())
+    out["logit_std"] = float(lg32.std())
+    out["within_contract"] = bool(out["max_dp"] < 1e-3 and out["max_dv"] < 1e-3)
+    return out

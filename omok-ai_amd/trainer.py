@@ -34,12 +34,14 @@ class Parameters:  # src/config.rs:83-110
 
 
 class Trainer:
-    def __init__(self, params=None, board_size=15, seed=0, save_dir="saves", max_nodes=None, max_tables=None):
+    def __init__(self, params=None, board_size=15, seed=0, save_dir="saves", max_nodes=None, max_tables=None, precision_rows=256):
         self.p = params or Parameters()
         self.n = board_size
         self.rank, self.local_rank, self.world = dist.shard_info()
         self.device = f"cuda:{self.local_rank}"
         self.save_dir = save_dir
+        self.precision_rows = precision_rows
+        self.last_precision = None
         sims = -(-self.p.evaluate_count // self.p.evaluate_batch_size) * self.p.evaluate_batch_size
         max_nodes = max_nodes or min(16384, 4 * sims + 1024)
         self.engine = api.Engine(board_size=board_size, games=self.p.episode_count, max_nodes=max_nodes,
@@ -86,6 +88,15 @@ class Trainer:
             v_loss, p_loss, loss = self.phase.run(records, p.parameter_update_count, p.parameter_update_batch_size,
                                                   seed=self.iteration * 7919 + self.rank)
             self.phase.push_to(self.engine)
+            if self.precision_rows > 0:  # the split-precision forward is checked against the fp32 kernels after every weight update
+                from . import precision
+                x, _, _ = T.decode_records(records[: self.precision_rows], self.n)
+                chk = precision.measure(self.phase.net.tensors(), self.n, x.reshape(x.shape[0], -1).cpu().numpy(), device=self.local_rank,
+                                        batch_k=p.evaluate_batch_size)
+                self.last_precision = chk
+                if not chk["within_contract"]:
+                    log(f"[iter={self.iteration}] WARNING: net outputs differ from the fp32 kernels by |dp| {chk['max_dp']:.2e} |dv| {chk['max_dv']:.2e} "
+                        f"(contract 1e-3): evaluate with net_mode=OMOK_NET_F32 if the bound must hold")
             if self.rank == 0:  # Trainer::save (:605-626)
                 os.makedirs(self.save_dir, exist_ok=True)
                 self.engine.save(os.path.join(self.save_dir, p.model_name))
