@@ -27,7 +27,7 @@ if a.json:
         return sum(v for (k, c), v in agg.items() if c == counter and any(k.startswith(p) for p in prefixes))
     out = {"board": a.board, "rows": a.rows, "sims": a.sims, "unit": "bytes", "source": a.root,
            "method": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE [KiB] x 1024; raw (x1) fetch kept beside it"}
-    for name, pre in (("k_trunk", ["k_trunk"]), ("k_fc0_mx", ["k_fc0_mx", "k_splitk_finish"]),
+    for name, pre in (("k_trunk", ["k_trunk", "k_sib_children", "k_group"]), ("k_fc0_mx", ["k_fc0_mx", "k_splitk_finish"]),
                       ("tree", ["k_round", "k_scan", "k_fill", "k_scatter", "k_add_evals"])):
         f, w = tot(pre, "FETCH_SIZE") * 1024.0, tot(pre, "WRITE_SIZE") * 1024.0
         denom = a.sims if name == "tree" else a.rows
