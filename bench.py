@@ -348,7 +348,10 @@ def main():
         ach = rows * flop_row / sec / 1e12 if sec > 0 else 0.0
         per_row = pmc.get(kernel + "_hbm_bytes_per_row_calibrated") or pmc.get(kernel + "_hbm_bytes_per_row") or PMC_HBM_BYTES_PER_ROW.get(n, {}).get(kernel)
         per_row_x2 = pmc.get(kernel + "_hbm_bytes_per_row")
-        alg_row = {"k_trunk": 2 * 8 * ((hw + 63) // 64) + 16 + 384.0 * hw, "k_fc0_mx": 384.0 * hw + 2048}[kernel]
+        # trunk: the 384-B-per-pixel operand row it writes; at N = 15 (sibling path) also the child's 49 window pixels written a second time
+        # and a sixteenth of the base pass's three h grids
+        alg_row = {"k_trunk": 2 * 8 * ((hw + 63) // 64) + 16 + 384.0 * hw + (49 * 384.0 + 3 * hw * 128.0 / 16 if n == 15 else 0.0),
+                   "k_fc0_mx": 384.0 * hw + 2048}[kernel]
         return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / F16_DENSE_PEAK_TFLOPS, "traffic": per_row * rows / launches if per_row else None,
                 "traffic_uncalibrated_x2": per_row_x2 * rows / launches if per_row_x2 else None,
