@@ -39,6 +39,10 @@ extern "C" {
 
 #define OMOK_NET_F16X3 0 /* split-operand MFMA (hi+lo: f16 main term, f16 / block-scaled fp6 correction terms, fp32 accumulate) */
 #define OMOK_NET_F32 1   /* plain fp32 VALU kernels (debug / A-B reference on the GPU) */
+#define OMOK_NET_F16X3_ROWS 2 /* OMOK_NET_F16X3 with every request row evaluated on its own: at board_size 15 the search rounds of
+                                 OMOK_NET_F16X3 evaluate sibling requests as one base position + per-child differences, so a
+                                 row's p / v carry rounding that depends on its siblings (~5e-5, inside the 1e-3 contract); _ROWS switches
+                                 that off (results bit-identical to omok_evaluate_pv of the same position), at ~1.7x the net time */
 
 #define OMOK_MAX_ARENA 16384 /* largest max_nodes / max_tables: node and table indices are 16-bit, and the re-rooting kernel keeps
                                3 B per node + 2 B per table of scratch in LDS (82 KiB at the maximum, inside gfx950's 160 KiB) */

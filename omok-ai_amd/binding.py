@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OMOK_MI355X_LIB") or os.path.join(_HERE, "libomok_mi355x.so")
 
 OK = 0
-NET_F16X3, NET_F32 = 0, 1
+NET_F16X3, NET_F32, NET_F16X3_ROWS = 0, 1, 2
 MODE_PLAYER, MODE_OPPONENT = 0, 1
 STAT_NAMES = ["sims", "evals", "ply_games", "finished", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply",
               "fc0_launches", "fc0_rows", "tree_bytes", "round_launches", "ms_round", "peak_nodes", "peak_tables"]

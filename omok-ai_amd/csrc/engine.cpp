@@ -199,7 +199,8 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     if (cfg->max_nodes < 2 || cfg->max_nodes > OMOK_MAX_ARENA || cfg->max_tables < 1 || cfg->max_tables > OMOK_MAX_ARENA)
         return fail(nullptr, OMOK_ERR_INVALID, "max_nodes must be in [2, %d] and max_tables in [1, %d]", OMOK_MAX_ARENA, OMOK_MAX_ARENA);
     if (cfg->max_batch_k < 1 || cfg->max_batch_k > KMAX) return fail(nullptr, OMOK_ERR_INVALID, "max_batch_k must be in [1, 64]");
-    if (cfg->net_mode != OMOK_NET_F16X3 && cfg->net_mode != OMOK_NET_F32) return fail(nullptr, OMOK_ERR_INVALID, "bad net_mode");
+    if (cfg->net_mode != OMOK_NET_F16X3 && cfg->net_mode != OMOK_NET_F32 && cfg->net_mode != OMOK_NET_F16X3_ROWS)
+        return fail(nullptr, OMOK_ERR_INVALID, "bad net_mode");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, OMOK_ERR_HIP, "no HIP device available: this library has no CPU path");
@@ -286,7 +287,8 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     e->net.n = e->n;
     e->net.hw = e->hw;
     e->net.rowp = e->rowp;
-    e->net.mode = cfg->net_mode;
+    e->net.mode = cfg->net_mode == OMOK_NET_F16X3_ROWS ? OMOK_NET_F16X3 : cfg->net_mode;
+    e->net.siblings = cfg->net_mode == OMOK_NET_F16X3;
     e->net.max_b = (int)max_b;
     for (int i = 0; i < NET_TENSORS; ++i) e->net.wsize[i] = net_tensor_size(e->n, i);
     if (net_alloc(e->net) == 0) {

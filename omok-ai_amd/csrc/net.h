@@ -12,6 +12,7 @@ constexpr int NF = 512; // FC_0_SIZE / FC_1_SIZE (:29-30)
 
 struct Net {
     int n = 0, hw = 0, rowp = 0, mode = 0;
+    bool siblings = true; // search rounds may take the sibling path of the trunk / fc0 (false: OMOK_NET_F16X3_ROWS)
     int device = 0;   // HIP device ordinal (keys the per-device launch caches)
     int max_b = 0;
     bool committed = false;
@@ -42,8 +43,16 @@ struct Net {
     void* d_groups = nullptr;
     int32_t* d_singles = nullptr;
     void* d_sib_rows = nullptr; // (request row, run) of the rows inside runs
-    int32_t* d_gcnt = nullptr;  // [0] runs, [1] rows outside runs, [2] rows inside runs
+    int32_t* d_gcnt = nullptr;  // [0] runs, [1] rows outside runs, [2] rows inside runs, [3] full rows (runs + singles), [4] fc0 window tiles,
+                                // [8 + b] children whose window is bin b (SIB_CNT_INTS in all)
     float* sib_h = nullptr;     // [run][3 blocks][225][32] the base passes' depthwise inputs
+    // difference path: a child's fc0 input = its run's base row + a 7x7-window difference row
+    uint32_t* d_sib_slot = nullptr;  // per row inside a run: window bin << 24 | rank inside the bin
+    int32_t* d_bin_start = nullptr;  // first slot of every bin (bins padded to whole 128-sample tiles); [81] = the single rows
+    int32_t* d_tile_info = nullptr;  // per fc0 window tile: bin | live slots << 8
+    void* d_slot_desc = nullptr;     // per slot: (request row, full-row index of its base / of itself)
+    void* d_rows = nullptr;          // [slot][2 q][49 window pixels] f16 parts, then residual parts: the difference rows
+    size_t d_slots = 0;              // slots allocated
     int mx_sw = 0;            // fc0 weights: fp8 copies are w * 2^mx_sw (hi) and (w - f16(w)) * 2^(mx_sw + 11) (lo)
     size_t bytes = 0;         // device bytes held
 };

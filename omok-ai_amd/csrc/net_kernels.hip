@@ -252,11 +252,14 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                                                                     const uint4* __restrict__ wt, const float* __restrict__ side,
                                                                     uint4* __restrict__ a_out, size_t row_u4, int max_count,
                                                                     const int32_t* __restrict__ row_list, const int32_t* __restrict__ d_nrows,
-                                                                    const uint2* __restrict__ groups, float* __restrict__ hscr) {
+                                                                    const uint2* __restrict__ groups, float* __restrict__ hscr,
+                                                                    const int32_t* __restrict__ d_out_base) {
     // row_list != NULL: the kernel evaluates the request rows row_list[0 .. d_nrows[0]) (the rows outside the sibling runs).
-    // BASE: sample i is the BASE position of sibling run groups[i] -- the parent's board with the children's side to move; its
-    // operand row goes to a_out[i] (the base-row buffer) and the depthwise inputs of its three blocks to hscr[i][blk][pixel][32].
-    constexpr bool BASE = (ABL & 16) != 0;
+    // BASE: sample i is the BASE position of sibling run groups[i] -- the parent's board with the children's side to move; the
+    // depthwise inputs of its three blocks go to hscr[i][blk][pixel][32] and its operand row into every child row of the run
+    // (copy path) or, DELTA (difference path), once to full row i; with DELTA the rows of a row list go to full rows
+    // d_out_base[0] + i (behind the runs' rows).
+    constexpr bool BASE = (ABL & 16) != 0, DELTA = (ABL & 32) != 0;
     using TG = TrunkGeo<N>;
     constexpr int HW = TG::HW, NW = Geo<N>::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -599,8 +602,11 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
         if (!(ABL & 2)) {
             // BASE: the row is stored into EVERY child row of the run (the rows fc0 reads must exist; k_sib_children then overwrites
             // each child's 7x7 window): `row` = the first child's row, the others follow at the row stride
-            uint4* row = a_out + (size_t)(BASE ? (active ? groups[bi].x : 0u) : (uint32_t)b) * row_u4;
-            const int copies = BASE ? (active ? (int)groups[bi].y : 0) : 1;
+            uint32_t orow = (uint32_t)b;
+            if (BASE) orow = DELTA ? (uint32_t)(active ? bi : 0) : (active ? groups[bi].x : 0u);
+            else if (DELTA && row_list) orow = (uint32_t)(d_out_base[0] + (active ? bi : 0));
+            uint4* row = a_out + (size_t)orow * row_u4;
+            const int copies = (BASE && !DELTA) ? (active ? (int)groups[bi].y : 0) : 1;
             const float sc_lo_inv = __uint_as_float((uint32_t)(127 - MX_SA - 11) << 23); // fp8 = (x - hi) / 2^-(SA+11)
             uint4* stage_w = (uint4*)(grid + gi * GRID_STRIDE);          // this lane's pixel row (8 slots of 16 B)
             uint32_t p8l[2][8];
@@ -656,7 +662,8 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                     if (!(ABL & 8)) {
                         if (st_ok[i] && active) {
                             uint4* dst = &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + (8 * i + (lane >> 3)) * 8 + (lane & 7)];
-                            if (BASE) for (int c = 0; c < copies; ++c) nt_store(v, dst + (size_t)c * row_u4);
+                            if (BASE && !DELTA) for (int c = 0; c < copies; ++c) nt_store(v, dst + (size_t)c * row_u4);
+                            else if (DELTA) *dst = v; // (read again right away: by the children of the run and by fc0)
                             else nt_store(v, dst);
                         }
                     }
@@ -683,7 +690,8 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                 if (!(ABL & 8)) {
                     if (st_ok[i] && active) {
                         uint4* dst = &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (8 * i + (lane >> 3)) * 4 + (lane & 3)];
-                        if (BASE) for (int c = 0; c < copies; ++c) nt_store(v, dst + (size_t)c * row_u4);
+                        if (BASE && !DELTA) for (int c = 0; c < copies; ++c) nt_store(v, dst + (size_t)c * row_u4);
+                        else if (DELTA) *dst = v;
                         else nt_store(v, dst);
                     }
                 }
@@ -718,17 +726,42 @@ constexpr int SIB_WIN = 7, SIB_GW = SIB_WIN + 2; // window side, child grid side
 constexpr int SIB_CGRID_ROWS = SIB_GW * SIB_GW + 1;
 constexpr int SIB_CGRID_BYTES = SIB_CGRID_ROWS * GRID_STRIDE * 4; // 11808
 constexpr int SIB_HB_FLOATS = 225 * NM;          // one base h grid in the scratch: [pixel][32]
+// difference path: window bins (window origin (wy0, wx0) in 0..8 each), the single rows as bin SIB_BINS, counters, difference rows
+constexpr int SIB_ORG = 15 - SIB_WIN + 1, SIB_BINS = SIB_ORG * SIB_ORG; // 9, 81
+constexpr int SIB_CNT_INTS = 8 + SIB_BINS + 7;                            // d_gcnt: 5 counters, pad, bin counts (96 ints)
+constexpr int SIB_WPX = SIB_WIN * SIB_WIN;                                // 49 window pixels = 98 fc0 super-steps
+constexpr int SIB_DROW_U4 = SIB_WPX * 2 * 12;                             // 1176 uint4 = 18816 B: [q][w] 128-B f16 parts, [q][w] 64-B residual parts
+constexpr int SIB_DLO_U4 = SIB_WPX * 2 * 8;                               // 784: first residual part
+
+__device__ inline void sib_window(int action, int& wy0, int& wx0) { // the 7x7 window (clamped to the board) around the pixel the stone's float lands in
+    const int pc = (2 * action + 1) / 3;
+    wy0 = pc / 15 - SIB_WIN / 2;
+    wx0 = pc % 15 - SIB_WIN / 2;
+    wy0 = wy0 < 0 ? 0 : (wy0 > 15 - SIB_WIN ? 15 - SIB_WIN : wy0);
+    wx0 = wx0 < 0 ? 0 : (wx0 > 15 - SIB_WIN ? 15 - SIB_WIN : wx0);
+}
 
 // cnt[0] runs, cnt[1] rows outside runs, cnt[2] rows inside runs.  sib_rows[i] = descriptor of a row inside a run: (request row, run
 // index, node record index t * cap_nodes + node, turn | action << 8); a run's rows are adjacent.
-__global__ __launch_bounds__(64) void k_group(Store S, int side, uint2* __restrict__ groups, int32_t* __restrict__ singles, uint4* __restrict__ sib_rows,
-                                              int32_t* __restrict__ cnt) {
-    const int g = blockIdx.x, lane = threadIdx.x;
-    if (!S.gs[g].alive) return;
-    const int t = side * S.games + g;
-    const TreeState ts = S.ts[t];
-    const int n = (int)ts.n_req;
-    if (n == 0) return;
+// sib_slot[i] (difference path, else NULL) = window bin << 24 | rank of the row among the bin's rows (any order: a row's result does not
+// depend on its slot).
+// One wave per tree, GROUP_TREES trees per workgroup: the workgroup counts in LDS and claims its ranges of the global lists with one
+// atomic per counter (per-row atomics on 3 + 81 addresses serialised in L2: 0.24 ms per round).
+constexpr int GROUP_TREES = 16;
+__global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, uint2* __restrict__ groups, int32_t* __restrict__ singles,
+                                                             uint4* __restrict__ sib_rows, int32_t* __restrict__ cnt, uint32_t* __restrict__ sib_slot) {
+    __shared__ int l_cnt[3 + SIB_BINS], l_base[3 + SIB_BINS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = blockIdx.x * GROUP_TREES + (tid >> 6);
+    if (tid < 3 + SIB_BINS) l_cnt[tid] = 0;
+    __syncthreads();
+    int n = 0;
+    TreeState ts{};
+    const int t = side * S.games + (g < S.games ? g : 0);
+    if (g < S.games && S.gs[g].alive) {
+        ts = S.ts[t];
+        n = (int)ts.n_req;
+    }
     int parent = -1 - lane; // distinct for the lanes beyond the list
     uint32_t tn = 0, ta = 0;
     if (lane < n) {
@@ -746,23 +779,83 @@ __global__ __launch_bounds__(64) void k_group(Store S, int side, uint2* __restri
     const unsigned long long above = starts & ~((1ULL << rs) | ((1ULL << rs) - 1ULL));
     const int re = above ? __ffsll((long long)above) - 1 : n;
     const int len = re - rs;
-    int gslot = 0, rbase = 0;
+    const bool in_run = lane < n && len >= SIB_MIN;
+    int gslot = 0, rbase = 0, bin = 0, rank = 0, sidx = 0;
     if (start && len >= SIB_MIN) {
-        gslot = atomicAdd(&cnt[0], 1);
-        rbase = atomicAdd(&cnt[2], len);
-        groups[gslot] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)len);
+        gslot = atomicAdd(&l_cnt[0], 1);
+        rbase = atomicAdd(&l_cnt[2], len);
     }
     gslot = __shfl(gslot, rs, 64);
     rbase = __shfl(rbase, rs, 64);
-    if (lane < n) {
-        if (len >= SIB_MIN) sib_rows[rbase + (lane - rs)] = make_uint4(ts.req_base + (uint32_t)lane, (uint32_t)gslot, tn, ta);
-        else singles[atomicAdd(&cnt[1], 1)] = (int32_t)(ts.req_base + (uint32_t)lane);
+    if (in_run) {
+        if (sib_slot) {
+            int wy0, wx0;
+            sib_window((int)(ta >> 8), wy0, wx0);
+            bin = wy0 * SIB_ORG + wx0;
+            rank = atomicAdd(&l_cnt[3 + bin], 1);
+        }
+    } else if (lane < n) sidx = atomicAdd(&l_cnt[1], 1);
+    __syncthreads();
+    if (tid < 3 + SIB_BINS && l_cnt[tid] > 0 && (tid < 3 || sib_slot)) l_base[tid] = atomicAdd(&cnt[tid < 3 ? tid : 8 + (tid - 3)], l_cnt[tid]);
+    __syncthreads();
+    if (start && len >= SIB_MIN) groups[l_base[0] + gslot] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)len);
+    if (in_run) {
+        const int ri = l_base[2] + rbase + (lane - rs);
+        sib_rows[ri] = make_uint4(ts.req_base + (uint32_t)lane, (uint32_t)(l_base[0] + gslot), tn, ta);
+        if (sib_slot) sib_slot[ri] = ((uint32_t)bin << 24) | (uint32_t)(l_base[3 + bin] + rank);
+    } else if (lane < n) singles[l_base[1] + sidx] = (int32_t)(ts.req_base + (uint32_t)lane);
+}
+
+// Difference path: slots.  Every bin's rows get consecutive slots, bins padded to whole 128-sample fc0 tiles (a tile's super-steps are
+// its bin's window); the single rows follow as bin SIB_BINS (no window: their tiles only run the epilogue on their own full row).
+__global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, int32_t* __restrict__ bin_start, int32_t* __restrict__ tile_info,
+                                                    uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles) {
+    __shared__ int tile0[SIB_BINS + 2];
+    const int tid = threadIdx.x;
+    const int c = tid < SIB_BINS ? cnt[8 + tid] : (tid == SIB_BINS ? cnt[1] : 0);
+    if (tid == 0) {
+        int t = 0;
+        for (int b = 0; b <= SIB_BINS; ++b) {
+            tile0[b] = t;
+            const int cb = b < SIB_BINS ? cnt[8 + b] : cnt[1];
+            t += (cb + GT_BS - 1) / GT_BS;
+        }
+        tile0[SIB_BINS + 1] = t;
+        cnt[3] = cnt[0] + cnt[1];
+        cnt[4] = t;
+    }
+    __syncthreads();
+    if (tid <= SIB_BINS) {
+        bin_start[tid] = tile0[tid] * GT_BS;
+        for (int t = 0; t * GT_BS < c; ++t) tile_info[tile0[tid] + t] = tid | ((c - t * GT_BS < GT_BS ? c - t * GT_BS : GT_BS) << 8);
+    }
+    const int nsing = cnt[1], nruns = cnt[0], s0 = tile0[SIB_BINS] * GT_BS;
+    for (int i = tid; i < nsing; i += blockDim.x) slot_desc[s0 + i] = make_uint2((uint32_t)singles[i], (uint32_t)(nruns + i));
+}
+
+// full-row partial sums of fc0 -> one fp32 row per full row (in place, into split 0), in split order
+__global__ __launch_bounds__(256) void k_facc_reduce(float* __restrict__ part, int nsplit, size_t cap_rows, const int32_t* __restrict__ d_nrows) {
+    const size_t total = (size_t)d_nrows[0] * (NF / 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 a = *(const f32x4*)(part + i * 4);
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const f32x4 b = *(const f32x4*)(part + (size_t)sp * cap_rows * NF + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += b[j];
+        }
+        *(f32x4*)(part + i * 4) = a;
     }
 }
 
+// DELTA (difference path): a_out holds the FULL rows (one per run, written by k_trunk<BASE | DELTA>); the child's window entries are
+// stored as DIFFERENCES to the base's entries (dequantised: f16 hi + fp6 residual * 2^scale, exactly what fc0 will multiply), in the
+// same entry format, into the child's slot row of d_rows: fc0(child) = fc0(base row) + W[window] * difference row.
+template <bool DELTA>
 __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict__ board, const uint4* __restrict__ wt, const float* __restrict__ side,
                                                       uint4* __restrict__ a_out, size_t row_u4, const uint4* __restrict__ sib_rows,
-                                                      const int32_t* __restrict__ d_cnt, const float* __restrict__ hscr) {
+                                                      const int32_t* __restrict__ d_cnt, const float* __restrict__ hscr,
+                                                      const uint32_t* __restrict__ sib_slot, const int32_t* __restrict__ bin_start,
+                                                      uint4* __restrict__ d_rows, uint2* __restrict__ slot_desc) {
     constexpr int N = 15;
     using TG = TrunkGeo<N>;
     constexpr int HW = TG::HW, NW = Geo<N>::NW;
@@ -777,8 +870,22 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
     for (int i = tid; i < TR_WBYTES / 16; i += blockDim.x) ((uint4*)smem)[i] = wt[i];
     for (int i = tid; i < TR_SIDE_FLOATS; i += blockDim.x) ((float*)lside)[i] = side[i];
     for (int i = tid; i < SIB_CGRID_BYTES; i += blockDim.x) grid[i] = 0.0f; // (4 grids x 11808 / 4 floats)
+    // A child = a wave pair, and everything a pair writes in LDS is its own (child grid, staging rows, board words): the barriers below
+    // are PAIR barriers (a flag per wave in LDS, the LDS executes a wave's accesses in order), not workgroup barriers.  The four pairs
+    // then need not march in step -- they are started a quarter of a pass apart, so that the two waves of a SIMD (pairs p and p + 2) are
+    // half a pass apart: one is in its matrix phases while the other reads windows or waits for memory.
+    volatile int* pbar = (volatile int*)(smem + TR_WBYTES + 4 * SIB_CGRID_BYTES + TR_SIDE_FLOATS * 4);
+    if (tid < 8) pbar[tid] = 0;
     __syncthreads();
-    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    int pbar_k = 0;
+    auto lds_barrier = [&]() {
+        ++pbar_k;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) pbar[wv] = pbar_k;
+        while (__builtin_amdgcn_readfirstlane(pbar[wv ^ 1]) < pbar_k) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    for (int i = 0; i < 2 * (wv >> 1); ++i) __builtin_amdgcn_s_sleep(94); // (64 clocks per unit: ~6 us per pair index)
     const int nsib = d_cnt[2];
     const half8* convW = (const half8*)(wt + TR_WBYTES / 16);
     half8 cwh[4], cwl[4];
@@ -927,7 +1034,10 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint4 v = *(const uint4*)(gbase + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
-                if (rd_ok[i]) nt_store(v, &row[(size_t)((rd_px[i] >> 5) * 2 + q) * OP_BLK_U4 + (rd_px[i] & 31) * 8 + (lane & 7)]);
+                if (rd_ok[i]) { // (DELTA: rd_px = the window pixel index, row = the slot's difference row)
+                    if (DELTA) nt_store(v, &row[(q * SIB_WPX + rd_px[i]) * 8 + (lane & 7)]);
+                    else nt_store(v, &row[(size_t)((rd_px[i] >> 5) * 2 + q) * OP_BLK_U4 + (rd_px[i] & 31) * 8 + (lane & 7)]);
+                }
             }
         }
         if (lane_valid) {
@@ -942,30 +1052,25 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
         for (int i = 0; i < 4; ++i) {
             const uint4 v = *(const uint4*)(gbase + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
             const int q = (lane >> 2) & 1;
-            if (rd_ok[i]) nt_store(v, &row[(size_t)((rd_px[i] >> 5) * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (rd_px[i] & 31) * 4 + (lane & 3)]);
+            if (rd_ok[i]) {
+                if (DELTA) nt_store(v, &row[SIB_DLO_U4 + (q * SIB_WPX + rd_px[i]) * 4 + (lane & 3)]);
+                else nt_store(v, &row[(size_t)((rd_px[i] >> 5) * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (rd_px[i] & 31) * 4 + (lane & 3)]);
+            }
         }
     };
 
     // A child's descriptor and board words are fetched ONE PASS AHEAD (a dependent pair of loads: their latency runs under the
     // current pass), its halo ring ONE BLOCK ahead.
     f32x16 x[4];
-    auto fetch_desc = [&](int e0) { // descriptor of this pair's child in the pass that starts at entry e0
-        const int ei = e0 + pair;
-        return sib_rows[ei < nsib ? ei : (e0 < nsib ? e0 : 0)];
-    };
+    auto entry_of = [&](int e0) { const int ei = e0 + pair; return ei < nsib ? ei : (e0 < nsib ? e0 : 0); }; // this pair's child in the pass at e0
+    auto fetch_desc = [&](int e0) { return sib_rows[entry_of(e0)]; };
+    auto fetch_slot = [&](int e0) { return DELTA ? sib_slot[entry_of(e0)] : 0u; };
     auto fetch_word = [&](const uint4& ent) { // lanes 0..7: the child's board words
         uint64_t word = 0ULL;
         if (lane < 2 * NW) word = board[(size_t)ent.z * (2 * NW) + lane];
         return word;
     };
-    auto window_of = [&](const uint4& ent, int& wy0, int& wx0) {
-        const int action = (int)((ent.w >> 8) & 0xFFu);   // NodeHdr::action: the child's stone
-        const int pc = (2 * action + 1) / 3;              // the pixel its float lands in
-        wy0 = pc / N - SIB_WIN / 2;
-        wx0 = pc % N - SIB_WIN / 2;
-        wy0 = wy0 < 0 ? 0 : (wy0 > N - SIB_WIN ? N - SIB_WIN : wy0);
-        wx0 = wx0 < 0 ? 0 : (wx0 > N - SIB_WIN ? N - SIB_WIN : wx0);
-    };
+    auto window_of = [&](const uint4& ent, int& wy0, int& wx0) { sib_window((int)((ent.w >> 8) & 0xFFu), wy0, wx0); }; // NodeHdr::action: the child's stone
     auto ring_fetch = [&](const float* hb, int blk, int wy0, int wx0, uint4 (&ring)[2]) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -988,121 +1093,174 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
         const int gx = cell < 9 ? cell : cell < 18 ? cell - 9 : cell < 25 ? 0 : SIB_GW - 1;
         ring_off[u] = (gy * SIB_GW + gx) * GRID_STRIDE + piece * 4;
     }
+    // DELTA: the base's operand entries of this lane's pixel (its own 4 f16 pieces and residual half per channel half q), fetched
+    // behind the last depthwise and subtracted from the finished residual stream
+    uint4 bs_hi[2][4], bs_lo[2];
+    uint2 bs_lt[2];
+    uint32_t bs_sc[2];
+    auto base_fetch = [&](const uint4* frow, int px) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint4* bp = frow + (size_t)((px >> 5) * 2 + q) * OP_BLK_U4;
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) bs_hi[q][p4] = bp[(px & 31) * 8 + p4 * 2 + h];
+            const uint4* lp = bp + OP_LO_U4 + (px & 31) * 4;
+            bs_lo[q] = lp[h];
+            bs_lt[q] = ((const uint2*)(lp + 2))[h];
+            bs_sc[q] = ((const uint16_t*)(lp + 3))[h];
+        }
+    };
+    auto base_subtract = [&](f32x16 (&x)[4]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const u32x6 r = {bs_lo[q].x, bs_lo[q].y, bs_lo[q].z, bs_lo[q].w, bs_lt[q].x, bs_lt[q].y};
+            union { half32 v; uint32_t u[16]; } L; // residuals * 2^(scale - 127), element = slot 16 mm + reg (tools/probe/fp6_decode_probe.hip)
+            L.v = __builtin_amdgcn_cvt_scalef32_pk32_f16_fp6(r, __uint_as_float((bs_sc[q] >> 8) << 23));
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    const uint4 hq = bs_hi[q][mm * 2 + sx];
+                    const uint32_t hu[4] = {hq.x, hq.y, hq.z, hq.w};
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        float v0 = x[2 * q + mm][8 * sx + 2 * jj], v1 = x[2 * q + mm][8 * sx + 2 * jj + 1];
+                        const uint32_t ph = hu[jj], pl = L.u[8 * mm + 4 * sx + jj];
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(v0) : "v"(ph));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v1) : "v"(ph));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(v0) : "v"(pl));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v1) : "v"(pl));
+                        x[2 * q + mm][8 * sx + 2 * jj] = v0;
+                        x[2 * q + mm][8 * sx + 2 * jj + 1] = v1;
+                    }
+                }
+        }
+    };
+    uint4 ring[2];
+    int wy0 = 0, wx0 = 0; // the current child's window
+    const float* hb = hscr;
+    // L0 -> child grid (+ halo ring) -> depthwise over the window -> d
+    auto block_front = [&](int blk, float (&d)[16], bool fetch_next_ring) {
+        const float* dwt = lside + blk * TR_SIDE_PER_BLOCK;
+        f32x16 acc;
+        L0_tile(x, blk, acc);
+        if (c_valid) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+                const f32x2 r0 = lrelu2(acc[4 * g], acc[4 * g + 1]), r1 = lrelu2(acc[4 * g + 2], acc[4 * g + 3]);
+                o[0] = r0[0]; o[1] = r0[1]; o[2] = r1[0]; o[3] = r1[1];
+                *(f32x4*)(cgrid + c_gi * GRID_STRIDE + 8 * g + 4 * h) = o;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *(uint4*)(cgrid + ring_off[u]) = ring[u]; // halo ring <- the base's h of this block (zero outside the board)
+        lds_barrier(); // B2
+        if (fetch_next_ring) ring_fetch(hb, blk + 1, wy0, wx0, ring);
+        // depthwise over the 7x7 window: (row, strip of 4 | 3 pixels, 4-channel group) = 112 items for the pair's 128 threads
+        f32x4 dout[TG::SW];
+        const int item = ptid < 7 * 2 * 8 ? ptid : 0;
+        const int cg = item & 7, strip = item >> 3;
+        const int y = strip >> 1, x0 = (strip & 1) * TG::SW;
+        {
+            const float* gp = cgrid + (y * SIB_GW + x0) * GRID_STRIDE + 4 * cg;
+            f32x4 win[3][TG::SW + 2];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < TG::SW + 2; ++dx) win[dy][dx] = *(const f32x4*)(gp + (dy * SIB_GW + dx) * GRID_STRIDE);
+            f32x4 w9[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) w9[tap] = *(const f32x4*)(dwt + tap * NM + 4 * cg);
+#pragma unroll
+            for (int p = 0; p < TG::SW; ++p) {
+                f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const f32x4 hv = win[tap / 3][p + tap % 3];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] += hv[c] * w9[tap][c];
+                }
+                dout[p] = o;
+            }
+        }
+        lds_barrier(); // B3
+        if (ptid < 7 * 2 * 8) {
+#pragma unroll
+            for (int p = 0; p < TG::SW; ++p)
+                if (x0 + p < SIB_WIN) *(f32x4*)(cgrid + ((y + 1) * SIB_GW + x0 + p + 1) * GRID_STRIDE + 4 * cg) = dout[p];
+        }
+        lds_barrier(); // B4
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 dv = *(const f32x4*)(cgrid + c_gi * GRID_STRIDE + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[4 * g + i] = dv[i];
+        }
+    };
     const int pass_stride = (int)gridDim.x * 4;
     uint4 ent_c = fetch_desc((int)blockIdx.x * 4), ent_n = fetch_desc((int)blockIdx.x * 4 + pass_stride);
+    uint32_t slot_c = fetch_slot((int)blockIdx.x * 4), slot_n = fetch_slot((int)blockIdx.x * 4 + pass_stride);
     uint64_t word_c = fetch_word(ent_c);
-    uint4 ring[2];
-    {
-        int wy0, wx0;
-        window_of(ent_c, wy0, wx0);
-        ring_fetch(hscr + (size_t)ent_c.y * 3 * SIB_HB_FLOATS, 0, wy0, wx0, ring);
-    }
+    window_of(ent_c, wy0, wx0);
+    ring_fetch(hscr + (size_t)ent_c.y * 3 * SIB_HB_FLOATS, 0, wy0, wx0, ring);
     for (int e0 = (int)blockIdx.x * 4; e0 < nsib; e0 += pass_stride) { // four children per pass; uniform over the workgroup
-        {
-            const bool act = e0 + pair < nsib;
-            const uint4 ent = ent_c;
-            const int crow = (int)ent.x;
-            const float* hb = hscr + (size_t)ent.y * 3 * SIB_HB_FLOATS;
-            const int turn = (int)(ent.w & 0xFFu);
-            int wy0, wx0;
-            window_of(ent, wy0, wx0);
-            const int q = (wy0 + c_wy) * N + (wx0 + c_wx);                                      // this lane's board pixel
-            uint4* crow_p = a_out + (size_t)crow * row_u4;
-            uint64_t* cw = (uint64_t*)(cgrid + (SIB_CGRID_ROWS - 1) * GRID_STRIDE) + wt2 * 8; // the child's 8 board words: the grid's pad row, one copy per wave
-            if (lane < 2 * NW) cw[lane] = word_c;
-            // the next pass's board words (its descriptor arrived a pass ago) and the descriptor of the pass after that
-            const uint64_t word_n = fetch_word(ent_n);
-            const uint4 ent_nn = fetch_desc(e0 + 2 * pass_stride);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            uint32_t bits[3];
-            input_bits(cw, turn, q, bits);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            conv_in_tile(x, bits[0], bits[1], bits[2]);
+        const bool act = e0 + pair < nsib;
+        const uint4 ent = ent_c;
+        const int crow = (int)ent.x;
+        hb = hscr + (size_t)ent.y * 3 * SIB_HB_FLOATS;
+        const int turn = (int)(ent.w & 0xFFu);
+        window_of(ent, wy0, wx0);
+        const int q = (wy0 + c_wy) * N + (wx0 + c_wx);                                      // this lane's board pixel
+        int slot = 0;
+        if (DELTA) slot = bin_start[slot_c >> 24] + (int)(slot_c & 0xFFFFFFu);
+        uint4* crow_p = DELTA ? d_rows + (size_t)slot * SIB_DROW_U4 : a_out + (size_t)crow * row_u4;
+        uint64_t* cw = (uint64_t*)(cgrid + (SIB_CGRID_ROWS - 1) * GRID_STRIDE) + wt2 * 8; // the child's 8 board words: the grid's pad row, one copy per wave
+        if (lane < 2 * NW) cw[lane] = word_c;
+        // the next pass's board words (its descriptor arrived a pass ago) and the descriptor of the pass after that
+        const uint64_t word_n = fetch_word(ent_n);
+        const uint4 ent_nn = fetch_desc(e0 + 2 * pass_stride);
+        const uint32_t slot_nn = fetch_slot(e0 + 2 * pass_stride);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        uint32_t bits[3];
+        input_bits(cw, turn, q, bits);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        conv_in_tile(x, bits[0], bits[1], bits[2]);
+        float d[16];
 #pragma unroll 1
-            for (int blk = 0; blk < 3; ++blk) {
-                const float* dwt = lside + blk * TR_SIDE_PER_BLOCK;
-                f32x16 acc;
-                L0_tile(x, blk, acc);
-                float d[16];
-                if (c_valid) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 o;
-                        const f32x2 r0 = lrelu2(acc[4 * g], acc[4 * g + 1]), r1 = lrelu2(acc[4 * g + 2], acc[4 * g + 3]);
-                        o[0] = r0[0]; o[1] = r0[1]; o[2] = r1[0]; o[3] = r1[1];
-                        *(f32x4*)(cgrid + c_gi * GRID_STRIDE + 8 * g + 4 * h) = o;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) *(uint4*)(cgrid + ring_off[u]) = ring[u]; // halo ring <- the base's h of this block (zero outside the board)
-                lds_barrier(); // B2
-                if (blk < 2) ring_fetch(hb, blk + 1, wy0, wx0, ring);
-                // depthwise over the 7x7 window: (row, strip of 4 | 3 pixels, 4-channel group) = 112 items for the pair's 128 threads
-                f32x4 dout[TG::SW];
-                const int item = ptid < 7 * 2 * 8 ? ptid : 0;
-                const int cg = item & 7, strip = item >> 3;
-                const int y = strip >> 1, x0 = (strip & 1) * TG::SW;
-                {
-                    const float* gp = cgrid + (y * SIB_GW + x0) * GRID_STRIDE + 4 * cg;
-                    f32x4 win[3][TG::SW + 2];
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < TG::SW + 2; ++dx) win[dy][dx] = *(const f32x4*)(gp + (dy * SIB_GW + dx) * GRID_STRIDE);
-                    f32x4 w9[9];
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) w9[tap] = *(const f32x4*)(dwt + tap * NM + 4 * cg);
-#pragma unroll
-                    for (int p = 0; p < TG::SW; ++p) {
-                        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                        for (int tap = 0; tap < 9; ++tap) {
-                            const f32x4 hv = win[tap / 3][p + tap % 3];
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) o[c] += hv[c] * w9[tap][c];
-                        }
-                        dout[p] = o;
-                    }
-                }
-                lds_barrier(); // B3
-                if (ptid < 7 * 2 * 8) {
-#pragma unroll
-                    for (int p = 0; p < TG::SW; ++p)
-                        if (x0 + p < SIB_WIN) *(f32x4*)(cgrid + ((y + 1) * SIB_GW + x0 + p + 1) * GRID_STRIDE + 4 * cg) = dout[p];
-                }
-                lds_barrier(); // B4
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 dv = *(const f32x4*)(cgrid + c_gi * GRID_STRIDE + 8 * g + 4 * h);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) d[4 * g + i] = dv[i];
-                }
-                L1L2_tile(x, blk, d);
-            }
-            { // the window's 49 pixel entries over the copied base row
-                int rd_gi[4], rd_px[4];
-                bool rd_ok[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int w = 32 * wt2 + 8 * i + (lane >> 3);
-                    const int wc = w < SIB_WIN * SIB_WIN ? w : SIB_WIN * SIB_WIN - 1;
-                    rd_gi[i] = (wc / SIB_WIN + 1) * SIB_GW + (wc % SIB_WIN + 1);
-                    rd_px[i] = (wy0 + wc / SIB_WIN) * N + (wx0 + wc % SIB_WIN);
-                    rd_ok[i] = w < SIB_WIN * SIB_WIN && act;
-                }
-                // the next pass's first halo ring before this pass's stores queue up behind it
-                {
-                    int ny0, nx0;
-                    window_of(ent_n, ny0, nx0);
-                    ring_fetch(hscr + (size_t)ent_n.y * 3 * SIB_HB_FLOATS, 0, ny0, nx0, ring);
-                }
-                store_rows(x, crow_p, c_valid, cgrid + c_gi * GRID_STRIDE, rd_gi, rd_px, rd_ok, cgrid);
-            }
-            ent_c = ent_n;
-            ent_n = ent_nn;
-            word_c = word_n;
-            lds_barrier(); // the staging rows are free again (the next pass writes the pad row / grid)
+        for (int blk = 0; blk < 2; ++blk) {
+            block_front(blk, d, true);
+            L1L2_tile(x, blk, d);
         }
+        block_front(2, d, false);
+        if (DELTA) base_fetch(a_out + (size_t)ent.y * row_u4, q);
+        L1L2_tile(x, 2, d);
+        { // the window's 49 pixel entries: over the copied base row, or (DELTA) as differences into the slot's row
+            int rd_gi[4], rd_px[4];
+            bool rd_ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int w = 32 * wt2 + 8 * i + (lane >> 3);
+                const int wc = w < SIB_WPX ? w : SIB_WPX - 1;
+                rd_gi[i] = (wc / SIB_WIN + 1) * SIB_GW + (wc % SIB_WIN + 1);
+                rd_px[i] = DELTA ? wc : (wy0 + wc / SIB_WIN) * N + (wx0 + wc % SIB_WIN);
+                rd_ok[i] = w < SIB_WPX && act;
+            }
+            if (DELTA) {
+                base_subtract(x);
+                if (act && wt2 == 0 && lane == 0) slot_desc[slot] = make_uint2((uint32_t)crow, ent.y);
+            }
+            // the next pass's first halo ring before this pass's stores queue up behind it
+            window_of(ent_n, wy0, wx0);
+            ring_fetch(hscr + (size_t)ent_n.y * 3 * SIB_HB_FLOATS, 0, wy0, wx0, ring);
+            store_rows(x, crow_p, c_valid, cgrid + c_gi * GRID_STRIDE, rd_gi, rd_px, rd_ok, cgrid);
+        }
+        ent_c = ent_n;
+        ent_n = ent_nn;
+        slot_c = slot_n;
+        slot_n = slot_nn;
+        word_c = word_n;
+        lds_barrier(); // the staging rows are free again (the next pass writes the pad row / grid)
     }
 }
 
@@ -1191,42 +1349,68 @@ __device__ inline v8i f16x32_to_fp6(const half8& p0, const half8& p1, const half
    : (SEL_B) == 2 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((A), (B), (ACC), 2, 2, (SEL_A), (int)(SA), 2, (int)(SB))  \
                   : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((A), (B), (ACC), 2, 2, (SEL_A), (int)(SA), 3, (int)(SB)))
 constexpr bool STAGGER = false; // (skewing the waves by s_nops after the barrier: 3.52 -> 3.88 ms, the delay costs more than it saves)
-template <int EPI, int DBG = 0> // DBG: timing-only ablations (1 = no weight DMA, 2 = no sample DMA, 4 = no fp8 derivation, 8 = no vmcnt waits)
+// WIN (difference path of the sibling rounds, N = 15): workgroup = one tile of 128 SLOTS whose rows share a 7x7 window (tile_info: bin |
+// live slots << 8; d_count = the path's counters, [4] = tiles).  `act` holds the slots' difference rows (SIB_DROW_U4: 98 super-steps =
+// 49 window pixels x 2 channel halves), the weight stages of super-step (w, q) are those of the window pixel's board pixel, and the
+// epilogue adds the fp32 fc0 row of the slot's FULL row (facc: the run's base position; slot_desc = (request row, full row)).  Tiles
+// of the single rows (bin SIB_BINS) have no super-steps at all.
+template <int EPI, int DBG = 0, bool WIN = false> // DBG: timing-only ablations (1 = no weight DMA, 2 = no sample DMA, 4 = no fp8 derivation, 8 = no vmcnt waits)
 __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksup,
                                                 size_t act_row_u4, int full_tiles, int last_cnt, MxScales sc,
                                                 const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
-                                                float* __restrict__ out_part, const int32_t* __restrict__ d_count, int max_count) {
+                                                float* __restrict__ out_part, const int32_t* __restrict__ d_count, int max_count,
+                                                const int32_t* __restrict__ tile_info, const uint2* __restrict__ slot_desc,
+                                                const float* __restrict__ facc) {
     // Static LDS objects, one per weight-ring slot: hipcc orders a ds_read after an LDS-DMA write by object (alias
     // scopes of distinct LDS variables), and with one dynamic array it drains ALL outstanding DMA (vmcnt(0)) before
     // the first LDS read of every stage.  With separate objects it waits exactly for the last DMA into the slot read.
     __shared__ uint4 ldsA[2 * MXS_U4];        // [2]{ f16 [128 samples][8 pieces] | fp8 [128 samples][4 pieces] }
     __shared__ uint4 ldsW0[MXS_U4], ldsW1[MXS_U4], ldsW2[MXS_U4], ldsW3[MXS_U4]; // [4 i][6 frag][64] each
     auto ring = [&](int slot) -> uint4* { return slot == 0 ? ldsW0 : slot == 1 ? ldsW1 : slot == 2 ? ldsW2 : ldsW3; };
-    int count = d_count[0];
-    if (count > max_count) count = max_count;
     const int b0 = blockIdx.x * GT_BS;
-    if (b0 >= count) return;
+    int count, win_oy = 0, win_ox = 0;
+    if (WIN) {
+        if ((int)blockIdx.x >= d_count[4]) return;
+        const int ti = tile_info[blockIdx.x], bin = ti & 0xFF;
+        count = b0 + (ti >> 8);
+        ksup = bin < SIB_BINS ? 2 * SIB_WPX : 0;
+        win_oy = bin / SIB_ORG;
+        win_ox = bin % SIB_ORG;
+    } else {
+        count = d_count[0];
+        if (count > max_count) count = max_count;
+        if (b0 >= count) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // 0..3 = m-tile inside a group
     const int h = lane >> 5;
     const int ubeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksup : 0;
 
     auto uoff = [&](int u) { // (block, pixel) of super-step u inside a sample row, packed as block * 32 + pixel
+        if (WIN) return u < 2 * SIB_WPX ? u : 2 * SIB_WPX - 1; // difference rows: super-step u = 2 w + q itself (prefetches past the end re-read the last)
         const int full = full_tiles * 64;
         int tile, q, pl;
         if (u < full) { tile = u >> 6; q = (u >> 5) & 1; pl = u & 31; }
         else { const int r = u - full; tile = full_tiles; q = r / last_cnt; pl = r % last_cnt; }
         return (tile * 2 + q) * 32 + pl;
     };
+    // absolute super-step (= weight stage group) of this workgroup's local super-step ul
+    auto ustep = [&](int ul) {
+        if (!WIN) return ubeg + ul;
+        const int u = ul < 2 * SIB_WPX ? ul : 2 * SIB_WPX - 1;
+        const int w = u >> 1, qq = u & 1, wy = w / SIB_WIN, wx = w - wy * SIB_WIN;
+        const int px = (win_oy + wy) * 15 + win_ox + wx;
+        return px < full_tiles * 32 ? (px >> 5) * 64 + qq * 32 + (px & 31) : full_tiles * 64 + qq * last_cnt + (px - full_tiles * 32);
+    };
     // a wave stages exactly the 6 weight fragments it consumes (m-tile `wave` of the stage's group): the weight ring is
     // wave-private, ordered by this wave's own vmcnt, and needs no workgroup barrier
-    const uint4* wsrc = wp + (size_t)ubeg * 4 * MXS_U4 + (size_t)(wave * 6) * 64; // wave-uniform; lanes add lane * 16 B
+    const uint4* wsrc = wp + (size_t)(wave * 6) * 64; // wave-uniform; lanes add lane * 16 B
     const uint32_t w_voff = lane * 16;
     int w_dma_off = wave * 6 * 64, w_rd_off = wave * 6 * 64 + lane;
     asm volatile("" : "+s"(w_dma_off));
     asm volatile("" : "+v"(w_rd_off));
-    auto issue_w1 = [&](int stage_local, int slot, int k) { // fragment k of this wave's 6
-        if (!(DBG & 1)) dma16s(wsrc + (size_t)stage_local * MXS_U4 + k * 64, w_voff, ring(slot) + w_dma_off + k * 64);
+    auto issue_w1 = [&](int uabs, int g, int slot, int k) { // fragment k of this wave's 6, stage g of absolute super-step uabs
+        if (!(DBG & 1)) dma16s(wsrc + ((size_t)uabs * 4 + g) * MXS_U4 + k * 64, w_voff, ring(slot) + w_dma_off + k * 64);
     };
     // Sample operands of a super-step: per sample 128 B of f16 pieces (2j+h) and 64 B of fp8 residual pieces (2h+e)
     // (two regions of the row's dense (tile, q) block).  The DMA reads them with ADJACENT LANES ON ADJACENT 16-B PIECES of one sample (8
@@ -1252,6 +1436,10 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     auto issue_a1 = [&](int uo, int buf, int k) {
         const int dst = k < 4 ? (wave * 4 + k) * 64 : 1024 + (wave * 2 + (k - 4)) * 64;
         const int blk = uo >> 5, pl = uo & 31; // f16 part: 8 uint4 per pixel; fp8 part: 4 per pixel behind the 32 x 8
+        if (WIN) {
+            const int e = (uo & 1) * SIB_WPX + (uo >> 1); // difference row: [q][w] f16 parts, then [q][w] residual parts
+            if (!(DBG & 2)) dma16s<A_NT>(abase + (k < 4 ? e * 8 : SIB_DLO_U4 + e * 4), a_voff[k], ldsA + buf * MXS_U4 + dst);
+        } else
         if (!(DBG & 2)) dma16s<A_NT>(abase + blk * OP_BLK_U4 + (k < 4 ? pl * 8 : OP_LO_U4 + pl * 4), a_voff[k], ldsA + buf * MXS_U4 + dst);
     };
     // LDS read offsets (uint4 units) of this lane's pieces inside sample tile 0; tile c adds 256 / 128
@@ -1291,17 +1479,17 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     uint4 wc[6];     // this wave's weight fragments of the current stage
     { // prologue, in the issue order of the steady state's last four stages: sample operands of super-step 0, weight stages
       // 0..2, the first two pieces of super-step 1, weight stage 3  (per wave: 8 + 24 DMA instructions)
-        const int uo = uoff(ubeg), uo1 = uoff(ubeg + 1);
+        const int uo = uoff(ubeg), uo1 = uoff(ubeg + 1), us0 = ustep(0);
 #pragma unroll
         for (int k = 0; k < 6; ++k) issue_a1(uo, 0, k);
 #pragma unroll
         for (int st = 0; st < 3; ++st)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) issue_w1(st, st, k);
+            for (int k = 0; k < 6; ++k) issue_w1(us0, st, st, k);
         issue_a1(uo1, 1, 0);
         issue_a1(uo1, 1, 1);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) issue_w1(3, 3, k);
+        for (int k = 0; k < 6; ++k) issue_w1(us0, 3, 3, k);
         asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); // A(0) and W(0) landed
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1333,6 +1521,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     for (int ul = 0; ul < ksup; ++ul) {
         const int ub = ul & 1;
         const int uo_next = uoff(ubeg + ul + 1), uo_next2 = uoff(ubeg + ul + 2);
+        const int us_next = ustep(ul + 1); // stage q + 4 = (ul + 1, g)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             half8 ah[4];
@@ -1361,12 +1550,12 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
             auto dma_piece = [&](int d) { // sample pieces run two super-steps ahead: A(ul+1) pieces 2..5 at g = 0, 1; A(ul+2) pieces 0, 1 at
                 // g = 3, behind the barrier (its buffer held A(ul), which every wave finished reading before that barrier)
                 if (g == 2) {
-                    if (d < 6) issue_w1(ul * 4 + g + 4, g, d);
+                    if (d < 6) issue_w1(us_next, g, g, d);
                 } else if (d < 2) {
                     if (g == 3) issue_a1(uo_next2, ub, d);
                     else issue_a1(uo_next, ub ^ 1, 2 + 2 * g + d);
                 } else {
-                    issue_w1(ul * 4 + g + 4, g, d - 2);
+                    issue_w1(us_next, g, g, d - 2);
                 }
             };
 #pragma unroll
@@ -1439,8 +1628,14 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     // ---- epilogue (accumulator g = m-tile 4g + wave) ----
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int sample = b0 + 32 * c + (lane & 31);
+        int sample = b0 + 32 * c + (lane & 31);
         if (sample >= count) continue;
+        const float* fa = nullptr;
+        if (WIN) { // slot -> (request row, full row)
+            const uint2 dsc = slot_desc[sample];
+            sample = (int)dsc.x;
+            fa = facc + (size_t)dsc.y * NF;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int mt = 4 * g + wave;
@@ -1457,8 +1652,10 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const f32x4 bv = *(const f32x4*)(bias + 32 * mt + 8 * q4 + 4 * h);
+                    f32x4 fv = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (WIN) fv = *(const f32x4*)(fa + 32 * mt + 8 * q4 + 4 * h);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) y[4 * q4 + q] = acc[g][c][4 * q4 + q] + bv[q];
+                    for (int q = 0; q < 4; ++q) y[4 * q4 + q] = WIN ? (acc[g][c][4 * q4 + q] + fv[q]) + bv[q] : acc[g][c][4 * q4 + q] + bv[q];
                 }
 #pragma unroll
                 for (int sx = 0; sx < 2; ++sx) {
@@ -1824,11 +2021,18 @@ size_t net_alloc(Net& net) {
         if (net.n == 15) { // sibling path of the trunk (k_group / k_trunk_sib): run lists and the per-workgroup base scratch
             ok = ok && A((void**)&net.d_groups, sizeof(uint2) * (mb / SIB_MIN + 1));
             ok = ok && A((void**)&net.d_singles, sizeof(int32_t) * mb);
-            ok = ok && A((void**)&net.d_gcnt, sizeof(int32_t) * 4);
+            ok = ok && A((void**)&net.d_gcnt, sizeof(int32_t) * SIB_CNT_INTS);
             ok = ok && A((void**)&net.d_sib_rows, sizeof(uint4) * mb);
             ok = ok && A((void**)&net.sib_h, sizeof(float) * (mb / SIB_MIN + 1) * 3 * SIB_HB_FLOATS);
+            // difference path: slots (bins padded to whole tiles), their difference rows
+            net.d_slots = mb + (size_t)(SIB_BINS + 1) * GT_BS;
+            ok = ok && A((void**)&net.d_sib_slot, sizeof(uint32_t) * mb);
+            ok = ok && A((void**)&net.d_bin_start, sizeof(int32_t) * 96);
+            ok = ok && A((void**)&net.d_tile_info, sizeof(int32_t) * (net.d_slots / GT_BS));
+            ok = ok && A(&net.d_slot_desc, sizeof(uint2) * net.d_slots);
+            ok = ok && A(&net.d_rows, net.d_slots * (size_t)SIB_DROW_U4 * 16);
         }
-        net.part_rows = mb * 3 > 32768 ? mb * 3 : 32768;                                // split-K partials: rows x split ways (2 KiB each)
+        net.part_rows = mb * 8 > 32768 ? mb * 8 : 32768;                                // split-K partials: rows x split ways (2 KiB each)
         ok = ok && A((void**)&net.part, sizeof(float) * net.part_rows * NF);
     }
     if (!ok) { net_free(net); return 0; }
@@ -1840,7 +2044,8 @@ void net_free(Net& net) {
     void** ptrs[] = {(void**)&net.p, (void**)&net.v, (void**)&net.vpre, (void**)&net.in_f32, (void**)&net.sx, (void**)&net.sh, (void**)&net.sd,
                      (void**)&net.sg, (void**)&net.s0, (void**)&net.s1, &net.wt_trunk, (void**)&net.wt_first, &net.wt_fc0,
                      &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part, (void**)&net.d_chunk, (void**)&net.d_groups,
-                     (void**)&net.d_singles, (void**)&net.d_gcnt, (void**)&net.sib_h, (void**)&net.d_sib_rows};
+                     (void**)&net.d_singles, (void**)&net.d_gcnt, (void**)&net.sib_h, (void**)&net.d_sib_rows, (void**)&net.d_sib_slot,
+                     (void**)&net.d_bin_start, (void**)&net.d_tile_info, &net.d_slot_desc, &net.d_rows};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     for (int i = 0; i < NET_TENSORS; ++i) { if (net.w[i]) hipFree(net.w[i]); net.w[i] = nullptr; }
 }
@@ -1985,7 +2190,8 @@ int net_commit(Net& net, hipStream_t st) {
 }
 
 template <int N, bool FROM_F32, int ABL = 0>
-static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st, const int32_t* row_list = nullptr, const int32_t* d_nrows = nullptr) {
+static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st, const int32_t* row_list = nullptr, const int32_t* d_nrows = nullptr,
+                         const int32_t* d_out_base = nullptr) {
     using TG = TrunkGeo<N>;
     static bool attr_done[64] = {}; // per device: the attribute belongs to the device's copy of the code object
     auto kern = k_trunk<N, FROM_F32, ABL>;
@@ -1996,7 +2202,7 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
     const int wgs = (max_count + TG::SPW - 1) / TG::SPW;
     const int grid = wgs < 256 ? wgs : 256;
     kern<<<grid, TG::WG_THREADS, TG::LDS_BYTES, st>>>(S.req_ref, S.req_aux, S.board, S.hdr, S.d_count, S.cap_nodes, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first,
-                                                       (uint4*)net.a_fc0, net.row_u4, max_count, row_list, d_nrows, (const uint2*)net.d_groups, net.sib_h);
+                                                       (uint4*)net.a_fc0, net.row_u4, max_count, row_list, d_nrows, (const uint2*)net.d_groups, net.sib_h, d_out_base);
 }
 
 template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
@@ -2015,28 +2221,75 @@ static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_
                                   out_row_u4, out_logits, S.d_count, max_count);
 }
 
-static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_count, hipStream_t st) {
-    constexpr int LDS = TR_WBYTES + 4 * SIB_CGRID_BYTES + TR_SIDE_FLOATS * 4;
+// delta = false: copy path (the base row is stored into every child row, the children overwrite their windows; fc0 unchanged).
+// delta = true: difference path (full rows for the runs' bases and the single rows, difference rows for the children; fc0 = launch_fc0_delta).
+static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_count, hipStream_t st, bool delta) {
+    constexpr int LDS = TR_WBYTES + 4 * SIB_CGRID_BYTES + TR_SIDE_FLOATS * 4 + 32; // (+ the pair-barrier flags)
+    static_assert(LDS <= 160 * 1024, "k_sib_children LDS");
     static bool attr_done[64] = {};
     if (!attr_done[net.device & 63]) {
-        hipFuncSetAttribute((const void*)k_sib_children, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute((const void*)k_sib_children<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute((const void*)k_sib_children<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done[net.device & 63] = true;
     }
-    hipMemsetAsync(net.d_gcnt, 0, 16, st);
-    k_group<<<S.games, 64, 0, st>>>(S, side, (uint2*)net.d_groups, net.d_singles, (uint4*)net.d_sib_rows, net.d_gcnt);
+    hipMemsetAsync(net.d_gcnt, 0, sizeof(int32_t) * SIB_CNT_INTS, st);
+    k_group<<<(S.games + GROUP_TREES - 1) / GROUP_TREES, 64 * GROUP_TREES, 0, st>>>(S, side, (uint2*)net.d_groups, net.d_singles, (uint4*)net.d_sib_rows, net.d_gcnt,
+                                                                                     delta ? net.d_sib_slot : nullptr);
     const int max_groups = max_count / SIB_MIN + 1;
-    launch_trunk<15, false, 16>(net, S, max_groups, st, nullptr, net.d_gcnt);                 // base positions of the runs
-    k_sib_children<<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
-                                           (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h);
-    launch_trunk<15, false>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1);            // the rows outside the runs
+    if (!delta) {
+        launch_trunk<15, false, 16>(net, S, max_groups, st, nullptr, net.d_gcnt);                 // base positions of the runs
+        k_sib_children<false><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
+                                                      (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, nullptr, nullptr, nullptr, nullptr);
+        launch_trunk<15, false>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1);            // the rows outside the runs
+        return;
+    }
+    k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles);
+    launch_trunk<15, false, 48>(net, S, max_groups, st, nullptr, net.d_gcnt);                              // base positions -> full rows [0, runs)
+    launch_trunk<15, false, 32>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1, net.d_gcnt);         // single rows -> full rows [runs, runs + singles)
+    k_sib_children<true><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
+                                                 (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, net.d_sib_slot, net.d_bin_start,
+                                                 (uint4*)net.d_rows, (uint2*)net.d_slot_desc);
+}
+
+// fc0 of a sibling round on the difference path: fp32 fc0 rows of the full rows (split-K over blockIdx.y: there are ~16x fewer full rows
+// than requests), then one window tile per 128 slots: 98 of the 450 super-steps, + the slot's full row, bias, LeakyReLU, hi|lo.
+static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const float* bias_fc0, uint4* h0, hipStream_t st) {
+    const int hw = net.hw, nsup = hw * 2;
+    const int tiles_max = (max_count + GT_BS - 1) / GT_BS;
+    const size_t cap_rows = (size_t)tiles_max * GT_BS;
+    static int n_cu_dev[64] = {};
+    int& n_cu = n_cu_dev[net.device & 63];
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDeviceProperties(&prop, net.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    // the live count of full rows is only known on the device; the split is chosen for the typical round (runs of ~14 rows)
+    const int tiles_exp = (max_count / 12 + 64 + GT_BS - 1) / GT_BS;
+    int nsplit = 1;
+    double best = 1e30;
+    for (int d = 1; d <= 8; ++d) {
+        if (nsup % d || (size_t)d * cap_rows > net.part_rows) continue;
+        const double cost = (double)((tiles_exp * d + n_cu - 1) / n_cu) / d * (d > 1 ? 1.04 : 1.0);
+        if (cost < best - 1e-9) { best = cost; nsplit = d; }
+    }
+    k_fc0_mx<EPI_PARTIAL><<<dim3(tiles_max, nsplit), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup / nsplit, net.row_u4, hw / 32,
+                                                                    (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, cap_rows, net.part, net.d_gcnt + 3,
+                                                                    max_count, nullptr, nullptr, nullptr);
+    k_facc_reduce<<<512, 256, 0, st>>>(net.part, nsplit, cap_rows, net.d_gcnt + 3);
+    const int wtiles_max = tiles_max + SIB_BINS + 1;
+    k_fc0_mx<EPI_SPLIT, 0, true><<<dim3(wtiles_max, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
+                                                                       (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr, net.d_gcnt, max_count,
+                                                                       net.d_tile_info, (const uint2*)net.d_slot_desc, net.part);
 }
 
 static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1) {
     const int hw = net.hw;
     const int ks0 = hw * 8;
-    static const int use_sib = getenv("OMOK_TRUNK_SIB") ? atoi(getenv("OMOK_TRUNK_SIB")) : 1; // 0: every row through k_trunk
+    static const int use_sib = getenv("OMOK_TRUNK_SIB") ? atoi(getenv("OMOK_TRUNK_SIB")) : 2; // 0: every row through k_trunk, 1: copy path, 2: difference path
+    const bool sib = net.n == 15 && !from_f32 && sib_side >= 0 && use_sib && net.siblings && net.d_groups;
+    const bool delta = sib && use_sib >= 2;
     if (prof) prof->begin(PC_TRUNK, st);
-    if (net.n == 15 && !from_f32 && sib_side >= 0 && use_sib && net.d_groups) launch_trunk_siblings(net, S, sib_side, max_count, st);
+    if (sib) launch_trunk_siblings(net, S, sib_side, max_count, st, delta);
     else if (net.n == 9) { if (from_f32) launch_trunk<9, true>(net, S, max_count, st); else launch_trunk<9, false>(net, S, max_count, st); }
     else {
         static const int abl = getenv("OMOK_ABL_TRUNK") ? atoi(getenv("OMOK_ABL_TRUNK")) : 0; // timing experiments only
@@ -2057,7 +2310,9 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     uint4* h1 = h0 + mb * 128; // 32 k-steps * 4 uint4 per row
     // fc0.  Small batches (late plies of an episode) cannot fill 256 CUs with 128-sample tiles: split K over
     // blockIdx.y into fp32 partials and finish (sum in split order + bias + LeakyReLU + hi|lo) in a second kernel.
-    {
+    const MxScales sc{127 - net.mx_sw, 127 - (net.mx_sw + 11), 127 - MX_SA, 127 - (MX_SA + 11), ldexpf(1.0f, net.mx_sw), ldexpf(1.0f, MX_SA)};
+    if (delta) launch_fc0_delta(net, max_count, sc, bias_fc0, h0, st);
+    else {
         const int nsup = hw * 2;
         const int tiles128 = (max_count + GT_BS - 1) / GT_BS;
         // Split K over blockIdx.y so that the workgroups fill whole waves of CUs (one workgroup per CU at a time: 144 KiB of
@@ -2081,7 +2336,6 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
                 if (cost < best - 1e-9) { best = cost; nsplit = d; }
             }
         }
-        const MxScales sc{127 - net.mx_sw, 127 - (net.mx_sw + 11), 127 - MX_SA, 127 - (MX_SA + 11), ldexpf(1.0f, net.mx_sw), ldexpf(1.0f, MX_SA)};
         constexpr int LDS = 0; // static LDS objects: (2 + MXS_SLOTS) x 24 KiB
         if (nsplit == 1) {
             static const int dbg = getenv("OMOK_DBG_FC0") ? atoi(getenv("OMOK_DBG_FC0")) : 0; // timing experiments only
@@ -2089,12 +2343,13 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
                       : dbg == 4 ? k_fc0_mx<EPI_SPLIT, 4> : dbg == 7 ? k_fc0_mx<EPI_SPLIT, 7> : dbg == 8 ? k_fc0_mx<EPI_SPLIT, 8> : k_fc0_mx<EPI_SPLIT, 0>;
             kern<<<dim3(tiles128, 1), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4,
                                                       hw / 32, (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr,
-                                                      S.d_count, max_count);
+                                                      S.d_count, max_count, nullptr, nullptr, nullptr);
         } else {
             const size_t cap_rows = (size_t)tiles128 * GT_BS;
             k_fc0_mx<EPI_PARTIAL><<<dim3(tiles128, nsplit), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0,
                                                                             nsup / nsplit, net.row_u4, hw / 32, (hw % 32) ? (hw % 32) : 1, sc,
-                                                                            bias_fc0, nullptr, cap_rows, net.part, S.d_count, max_count);
+                                                                            bias_fc0, nullptr, cap_rows, net.part, S.d_count, max_count, nullptr, nullptr,
+                                                                            nullptr);
             const size_t threads = (size_t)max_count * 64;
             k_splitk_finish<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(net.part, nsplit, cap_rows, bias_fc0, h0, 128, S.d_count,
                                                                                 max_count);

@@ -269,6 +269,63 @@ def test_net_precision_after_training_steps(n):
 
 
 # ---- self-play: tree arithmetic bit-exact ---------------------------------------------------------
+def test_search_round_outputs_on_the_sibling_path():
+    """The p / v a SEARCH ROUND produces at N = 15 (sibling path: base row + window difference rows) against the fp32
+    kernels and against the plain path (evaluate_pv) of the same engine, on the very request rows of the rounds."""
+    n, games, k, count = 15, 40, 16, 96
+    tensors = oa.weights.init_random(n, seed=3)
+    eng = oa.Engine(board_size=n, games=games, max_nodes=1024, max_tables=256, max_batch_k=k, seed=11, net_mode=B.NET_F16X3)
+    eng.load_weights(tensors)
+    ref = oa.Engine(board_size=n, games=games, max_nodes=8, max_tables=4, max_batch_k=k, net_mode=B.NET_F32)
+    ref.load_weights(tensors)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    xs, ps, vs = [], [], []
+    for ply in range(4):
+        for rnd in range(count // k):
+            nreq = sp.round_generate(rnd, k, 0.25, 0.03)
+            x = sp.round_inputs().copy()
+            p, v = sp.round_eval()
+            assert len(x) == nreq and len(p) == nreq
+            xs.append(x); ps.append(np.array(p).reshape(nreq, -1)); vs.append(np.array(v).reshape(-1))
+            sp.round_scatter()
+        sp.sample_actions(1.0, 30)
+        sp.mirror_generate()
+        sp.mirror_eval()
+        sp.mirror_apply()
+    x, p, v = np.concatenate(xs), np.concatenate(ps), np.concatenate(vs)
+    assert len(x) > 4 * games * (count - k)  # (rounds after the first are full: K requests per tree)
+    p32, v32 = ref.evaluate_pv(x)
+    pp, vp = eng.evaluate_pv(x)
+    p32, pp = p32.reshape(len(x), -1), pp.reshape(len(x), -1)
+    dp, dv = np.abs(p - p32).max(), np.abs(v - v32.reshape(-1)).max()
+    dpp, dvp = np.abs(p - pp).max(), np.abs(v - vp.reshape(-1)).max()
+    print(f"sibling rounds, {len(x)} rows: vs fp32 max|dp| {dp:.2e} max|dv| {dv:.2e}; vs plain path max|dp| {dpp:.2e} max|dv| {dvp:.2e}")
+    assert dp < 1e-3 and dv < 1e-3
+    assert dpp < 5e-4 and dvp < 5e-4
+    eng.close()
+    ref.close()
+
+
+def test_rows_mode_is_row_independent_in_search_rounds():
+    """OMOK_NET_F16X3_ROWS: a search round's p / v are bit-identical to evaluate_pv of the same rows (no sibling differences)."""
+    n, games, k = 15, 12, 16
+    eng = oa.Engine(board_size=n, games=games, max_nodes=512, max_tables=128, max_batch_k=k, seed=2, net_mode=B.NET_F16X3_ROWS)
+    eng.load_random_weights(1)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    for rnd in range(4):
+        nreq = sp.round_generate(rnd, k, 0.25, 0.03)
+        x = sp.round_inputs().copy()
+        p, v = sp.round_eval()
+        p, v = np.array(p).reshape(nreq, -1).copy(), np.array(v).reshape(-1).copy()
+        sp.round_scatter()
+        pp, vp = eng.evaluate_pv(x)
+        assert np.array_equal(p.view(np.uint32), pp.reshape(nreq, -1).view(np.uint32))
+        assert np.array_equal(v.view(np.uint32), vp.reshape(-1).view(np.uint32))
+    eng.close()
+
+
 def _compare_trees(sp, osp, games, tag):
     for g in range(games):
         for side in (0, 1):

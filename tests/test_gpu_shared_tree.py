@@ -13,8 +13,9 @@ from test_oracle_selfplay import check_tree_invariants
 pytestmark = pytest.mark.gpu
 
 
-def _engine(n, k, seed, waves, max_nodes=4096):
-    eng = oa.Engine(board_size=n, games=1, max_nodes=max_nodes, max_tables=max_nodes // 2, max_batch_k=k, seed=seed, max_tree_waves=waves)
+def _engine(n, k, seed, waves, max_nodes=4096, net_mode=0):
+    eng = oa.Engine(board_size=n, games=1, max_nodes=max_nodes, max_tables=max_nodes // 2, max_batch_k=k, seed=seed, max_tree_waves=waves,
+                    net_mode=net_mode)
     eng.load_random_weights(0)
     sp = oa.SelfPlay(eng)
     sp.reset()
@@ -23,7 +24,9 @@ def _engine(n, k, seed, waves, max_nodes=4096):
 
 @pytest.mark.parametrize("n,count,k", [(9, 100, 8), (15, 100, 16)])
 def test_one_wave_is_the_sequential_executor(n, count, k):
-    a_eng, a = _engine(n, k, 5, 0)
+    # (row-independent net mode on the sequential side: the shared-tree rounds evaluate every request on its own, and at
+    #  N = 15 the default mode's sibling differences carry ~5e-5 of batch-dependent rounding, enough to flip a PUCT comparison)
+    a_eng, a = _engine(n, k, 5, 0, net_mode=oa.binding.NET_F16X3_ROWS)
     b_eng, b = _engine(n, k, 5, 1)
     for ply in range(10):
         a.execute(count, k)
