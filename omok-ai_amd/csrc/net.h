@@ -53,6 +53,9 @@ struct Net {
     void* d_slot_desc = nullptr;     // per slot: (request row, full-row index of its base / of itself)
     void* d_rows = nullptr;          // [slot][2 q][49 window pixels] f16 parts, then residual parts: the difference rows
     size_t d_slots = 0;              // slots allocated
+    float* part_w = nullptr;         // fp32 partials of the K-split window tiles: [7][part_w_rows][512]
+    size_t part_w_rows = 0;
+    int n_cu = 256;                  // compute units of the device
     int mx_sw = 0;            // fc0 weights: fp8 copies are w * 2^mx_sw (hi) and (w - f16(w)) * 2^(mx_sw + 11) (lo)
     size_t bytes = 0;         // device bytes held
 };

@@ -807,22 +807,56 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
 }
 
 // Difference path: slots.  Every bin's rows get consecutive slots, bins padded to whole 128-sample fc0 tiles (a tile's super-steps are
-// its bin's window); the single rows follow as bin SIB_BINS (no window: their tiles only run the epilogue on their own full row).
+// its bin's window); the single rows are bin SIB_BINS (no window: their tiles only run the epilogue on their own full row).
+// Bins are laid out large to small (corner windows collect 16 board pixels each, edge windows 4, interior ones 1; singles last).
+// All tiles cost the same, so T tiles take ceil(T / CUs) rounds of workgroups: the tiles of the last, partial round are instead
+// split over K (cnt[6] ways, fp32 partials + k_win_finish), so that the round costs 1 / cnt[6] of a full one.  The split set is made of
+// WHOLE bins from the end of the layout (tiles >= cnt[5]): a row's bin -- unlike its slot -- is a function of the position alone, so
+// the summation order of a row never depends on the order in which k_group's atomics handed out the slots.
+__device__ inline int sib_bin_at(int pos) { // layout position -> bin
+    if (pos >= SIB_BINS) return SIB_BINS;
+    if (pos < 4) return (pos >> 1) * (SIB_ORG - 1) * SIB_ORG + (pos & 1) * (SIB_ORG - 1);            // corners
+    pos -= 4;
+    constexpr int E = SIB_ORG - 2; // 7 edge bins per side
+    if (pos < 4 * E) {
+        const int sd = pos / E, i = 1 + pos % E;
+        return sd == 0 ? i : sd == 1 ? (SIB_ORG - 1) * SIB_ORG + i : sd == 2 ? i * SIB_ORG : i * SIB_ORG + SIB_ORG - 1;
+    }
+    pos -= 4 * E;
+    return (1 + pos / E) * SIB_ORG + 1 + pos % E;                                                      // interior
+}
 __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, int32_t* __restrict__ bin_start, int32_t* __restrict__ tile_info,
-                                                    uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles) {
+                                                    uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu) {
     __shared__ int tile0[SIB_BINS + 2];
     const int tid = threadIdx.x;
     const int c = tid < SIB_BINS ? cnt[8 + tid] : (tid == SIB_BINS ? cnt[1] : 0);
     if (tid == 0) {
         int t = 0;
-        for (int b = 0; b <= SIB_BINS; ++b) {
+        for (int pos = 0; pos <= SIB_BINS; ++pos) {
+            const int b = sib_bin_at(pos);
             tile0[b] = t;
             const int cb = b < SIB_BINS ? cnt[8 + b] : cnt[1];
             t += (cb + GT_BS - 1) / GT_BS;
         }
-        tile0[SIB_BINS + 1] = t;
+        const int ntiles = t;
+        int t_split = ntiles - (ntiles < n_cu ? ntiles : ntiles % n_cu); // first tile of the partial round ...
+        int first = ntiles;
+        for (int pos = SIB_BINS; pos >= 0; --pos) {                     // ... moved down to the start of its bin
+            const int b0 = tile0[sib_bin_at(pos)];
+            if (b0 < first) first = b0;
+            if (b0 <= t_split) break;
+        }
+        if (t_split < ntiles) t_split = first;
+        int ways = ntiles > t_split ? n_cu / (ntiles - t_split) : 1;
+        if (ways > 7) ways = 7;
+        if (ways < 2) { ways = 1; t_split = ntiles; }
         cnt[3] = cnt[0] + cnt[1];
-        cnt[4] = t;
+        const int ftiles = (cnt[3] + GT_BS - 1) / GT_BS;          // fc0 of the full rows: K split so that one round of workgroups covers it
+        int fways = ftiles > 0 ? n_cu / ftiles : 1;
+        cnt[7] = fways < 1 ? 1 : (fways > 8 ? 8 : fways);
+        cnt[4] = ntiles;
+        cnt[5] = t_split;
+        cnt[6] = ways;
     }
     __syncthreads();
     if (tid <= SIB_BINS) {
@@ -833,9 +867,45 @@ __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, i
     for (int i = tid; i < nsing; i += blockDim.x) slot_desc[s0 + i] = make_uint2((uint32_t)singles[i], (uint32_t)(nruns + i));
 }
 
+// tiles of the K-split set (see k_bin_prefix): partials in split order + the slot's full row + bias, LeakyReLU, hi|lo operand row
+__global__ __launch_bounds__(256) void k_win_finish(const float* __restrict__ part, size_t cap_rows, const int32_t* __restrict__ cnt,
+                                                    const int32_t* __restrict__ tile_info, const uint2* __restrict__ slot_desc,
+                                                    const float* __restrict__ facc, const float* __restrict__ bias, uint4* __restrict__ out_split,
+                                                    size_t out_row_u4) {
+    const int nt = cnt[4], t0 = cnt[5], ways = cnt[6];
+    if (ways < 2) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // (local slot, mt 16, s 2, h 2)
+    const size_t local = i >> 6;
+    const int tile = t0 + (int)(local / GT_BS);
+    if (tile >= nt || (int)(local % GT_BS) >= (tile_info[tile] >> 8)) return;
+    const uint2 dsc = slot_desc[(size_t)t0 * GT_BS + local];
+    const int piece = (int)(i & 63), mt = piece >> 2, sx = (piece >> 1) & 1, h = piece & 1;
+    const int n0 = 32 * mt + 16 * sx + 4 * h; // j = 0..3 -> n0 + j ; j = 4..7 -> n0 + 8 + (j - 4)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+    for (int sp = 0; sp < ways; ++sp) {
+        const float* p = part + ((size_t)sp * cap_rows + local) * NF + n0;
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
+    }
+    const float* fa = facc + (size_t)dsc.y * NF + n0;
+    const f32x4 fa0 = *(const f32x4*)fa, fa1 = *(const f32x4*)(fa + 8);
+    const f32x4 ba = *(const f32x4*)(bias + n0), bb = *(const f32x4*)(bias + n0 + 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = lrelu((v[j] + fa0[j]) + ba[j]); v[4 + j] = lrelu((v[4 + j] + fa1[j]) + bb[j]); }
+    half8 hi, lo;
+    split8(v, hi, lo);
+    uint4* row = out_split + (size_t)dsc.x * out_row_u4 + (size_t)(2 * mt + sx) * 4;
+    row[h] = *(const uint4*)&hi;
+    row[2 + h] = *(const uint4*)&lo;
+}
+
 // full-row partial sums of fc0 -> one fp32 row per full row (in place, into split 0), in split order
-__global__ __launch_bounds__(256) void k_facc_reduce(float* __restrict__ part, int nsplit, size_t cap_rows, const int32_t* __restrict__ d_nrows) {
+__global__ __launch_bounds__(256) void k_facc_reduce(float* __restrict__ part, size_t cap_rows, const int32_t* __restrict__ d_nrows, const int32_t* __restrict__ d_nsplit) {
     const size_t total = (size_t)d_nrows[0] * (NF / 4);
+    const int nsplit = d_nsplit[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         f32x4 a = *(const f32x4*)(part + i * 4);
         for (int sp = 1; sp < nsplit; ++sp) {
@@ -1062,7 +1132,10 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
     // A child's descriptor and board words are fetched ONE PASS AHEAD (a dependent pair of loads: their latency runs under the
     // current pass), its halo ring ONE BLOCK ahead.
     f32x16 x[4];
-    auto entry_of = [&](int e0) { const int ei = e0 + pair; return ei < nsib ? ei : (e0 < nsib ? e0 : 0); }; // this pair's child in the pass at e0
+    constexpr int pass_stride = 4;
+    const int per_wg = ((nsib + (int)gridDim.x - 1) / (int)gridDim.x + 3) & ~3;
+    const int e_begin = (int)blockIdx.x * per_wg, e_end = e_begin + per_wg < nsib ? e_begin + per_wg : nsib;
+    auto entry_of = [&](int e0) { const int ei = e0 + pair; return ei < e_end ? ei : (e0 < e_end ? e0 : (e_begin < nsib ? e_begin : 0)); }; // this pair's child in the pass at e0
     auto fetch_desc = [&](int e0) { return sib_rows[entry_of(e0)]; };
     auto fetch_slot = [&](int e0) { return DELTA ? sib_slot[entry_of(e0)] : 0u; };
     auto fetch_word = [&](const uint4& ent) { // lanes 0..7: the child's board words
@@ -1198,14 +1271,16 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
             for (int i = 0; i < 4; ++i) d[4 * g + i] = dv[i];
         }
     };
-    const int pass_stride = (int)gridDim.x * 4;
-    uint4 ent_c = fetch_desc((int)blockIdx.x * 4), ent_n = fetch_desc((int)blockIdx.x * 4 + pass_stride);
-    uint32_t slot_c = fetch_slot((int)blockIdx.x * 4), slot_n = fetch_slot((int)blockIdx.x * 4 + pass_stride);
+    // A workgroup takes a CONTIGUOUS range of the rows (a run's children are adjacent: the 16 children of a run are four consecutive
+    // passes of one workgroup, so the base's h grids and operand row come from HBM once and from this XCD's L2 afterwards; dealt
+    // round-robin, a run's children went to four workgroups on four XCDs: 2.9 GB of fetches per round for 0.7 GB of data)
+    uint4 ent_c = fetch_desc(e_begin), ent_n = fetch_desc(e_begin + pass_stride);
+    uint32_t slot_c = fetch_slot(e_begin), slot_n = fetch_slot(e_begin + pass_stride);
     uint64_t word_c = fetch_word(ent_c);
     window_of(ent_c, wy0, wx0);
     ring_fetch(hscr + (size_t)ent_c.y * 3 * SIB_HB_FLOATS, 0, wy0, wx0, ring);
-    for (int e0 = (int)blockIdx.x * 4; e0 < nsib; e0 += pass_stride) { // four children per pass; uniform over the workgroup
-        const bool act = e0 + pair < nsib;
+    for (int e0 = e_begin; e0 < e_end; e0 += pass_stride) { // four children per pass; uniform over the workgroup
+        const bool act = e0 + pair < e_end;
         const uint4 ent = ent_c;
         const int crow = (int)ent.x;
         hb = hscr + (size_t)ent.y * 3 * SIB_HB_FLOATS;
@@ -1367,24 +1442,45 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     __shared__ uint4 ldsA[2 * MXS_U4];        // [2]{ f16 [128 samples][8 pieces] | fp8 [128 samples][4 pieces] }
     __shared__ uint4 ldsW0[MXS_U4], ldsW1[MXS_U4], ldsW2[MXS_U4], ldsW3[MXS_U4]; // [4 i][6 frag][64] each
     auto ring = [&](int slot) -> uint4* { return slot == 0 ? ldsW0 : slot == 1 ? ldsW1 : slot == 2 ? ldsW2 : ldsW3; };
-    const int b0 = blockIdx.x * GT_BS;
-    int count, win_oy = 0, win_ox = 0;
-    if (WIN) {
-        if ((int)blockIdx.x >= d_count[4]) return;
-        const int ti = tile_info[blockIdx.x], bin = ti & 0xFF;
+    int b0 = blockIdx.x * GT_BS;
+    int count, win_oy = 0, win_ox = 0, ubeg = 0, part_row0 = 0;
+    if (WIN) { // EPI_SPLIT: the tiles below the K-split set, whole K; EPI_PARTIAL: tile d_count[5] + blockIdx.x, K split d_count[6] ways over blockIdx.y
+        // Workgroups go to the 8 XCDs round-robin and every XCD has its own L2: XCD x takes a contiguous eighth of the tiles (tiles are
+        // ordered by bin = by weight slice), so the workgroups that share an L2 stream the same 9 MB of weights in step instead of
+        // every L2 streaming every slice (dealt round-robin, 46 % of the weight reads missed L2: 2.5 GB per launch, HBM-bound).
+        const int nt = d_count[4], t_split = d_count[5];
+        const int n_here = EPI == EPI_PARTIAL ? nt - t_split : t_split, eighth = (n_here + 7) >> 3;
+        int tile = ((int)blockIdx.x & 7) * eighth + ((int)blockIdx.x >> 3), ways = 1;
+        if (((int)blockIdx.x >> 3) >= eighth || tile >= n_here) return;
+        if (EPI == EPI_PARTIAL) {
+            tile += t_split;
+            ways = d_count[6];
+            if ((int)blockIdx.y >= ways) return;
+            part_row0 = t_split * GT_BS;
+        }
+        b0 = tile * GT_BS;
+        const int ti = tile_info[tile], bin = ti & 0xFF;
         count = b0 + (ti >> 8);
-        ksup = bin < SIB_BINS ? 2 * SIB_WPX : 0;
+        const int nsup = bin < SIB_BINS ? 2 * SIB_WPX : 0, per = (nsup + ways - 1) / ways;
+        ubeg = (int)blockIdx.y * per;
+        ksup = nsup - ubeg < per ? nsup - ubeg : per;
+        if (ksup < 0) ksup = 0;
         win_oy = bin / SIB_ORG;
         win_ox = bin % SIB_ORG;
     } else {
         count = d_count[0];
         if (count > max_count) count = max_count;
         if (b0 >= count) return;
+        if (EPI == EPI_PARTIAL && tile_info) { // the number of K splits was chosen on the device (tile_info[0]); uneven split
+            const int ways = tile_info[0], nsup = full_tiles * 64 + 2 * last_cnt, per = (nsup + ways - 1) / ways;
+            if ((int)blockIdx.y >= ways) return;
+            ubeg = (int)blockIdx.y * per;
+            ksup = nsup - ubeg < per ? nsup - ubeg : per;
+        } else ubeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksup : 0;
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // 0..3 = m-tile inside a group
     const int h = lane >> 5;
-    const int ubeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksup : 0;
 
     auto uoff = [&](int u) { // (block, pixel) of super-step u inside a sample row, packed as block * 32 + pixel
         if (WIN) return u < 2 * SIB_WPX ? u : 2 * SIB_WPX - 1; // difference rows: super-step u = 2 w + q itself (prefetches past the end re-read the last)
@@ -1397,7 +1493,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     // absolute super-step (= weight stage group) of this workgroup's local super-step ul
     auto ustep = [&](int ul) {
         if (!WIN) return ubeg + ul;
-        const int u = ul < 2 * SIB_WPX ? ul : 2 * SIB_WPX - 1;
+        const int u = ubeg + ul < 2 * SIB_WPX ? ubeg + ul : 2 * SIB_WPX - 1;
         const int w = u >> 1, qq = u & 1, wy = w / SIB_WIN, wx = w - wy * SIB_WIN;
         const int px = (win_oy + wy) * 15 + win_ox + wx;
         return px < full_tiles * 32 ? (px >> 5) * 64 + qq * 32 + (px & 31) : full_tiles * 64 + qq * last_cnt + (px - full_tiles * 32);
@@ -1631,7 +1727,8 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
         int sample = b0 + 32 * c + (lane & 31);
         if (sample >= count) continue;
         const float* fa = nullptr;
-        if (WIN) { // slot -> (request row, full row)
+        if (WIN && EPI == EPI_PARTIAL) sample -= part_row0; // partials are indexed by the slot inside the split set
+        if (WIN && EPI != EPI_PARTIAL) { // slot -> (request row, full row)
             const uint2 dsc = slot_desc[sample];
             sample = (int)dsc.x;
             fa = facc + (size_t)dsc.y * NF;
@@ -2031,6 +2128,10 @@ size_t net_alloc(Net& net) {
             ok = ok && A((void**)&net.d_tile_info, sizeof(int32_t) * (net.d_slots / GT_BS));
             ok = ok && A(&net.d_slot_desc, sizeof(uint2) * net.d_slots);
             ok = ok && A(&net.d_rows, net.d_slots * (size_t)SIB_DROW_U4 * 16);
+            hipDeviceProp_t prop;
+            net.n_cu = (hipGetDeviceProperties(&prop, net.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+            net.part_w_rows = std::min<size_t>((size_t)net.n_cu * GT_BS, net.d_slots); // K-split window tiles: at most one round of workgroups, 7 ways
+            ok = ok && A((void**)&net.part_w, sizeof(float) * net.part_w_rows * 7 * NF);
         }
         net.part_rows = mb * 8 > 32768 ? mb * 8 : 32768;                                // split-K partials: rows x split ways (2 KiB each)
         ok = ok && A((void**)&net.part, sizeof(float) * net.part_rows * NF);
@@ -2045,7 +2146,7 @@ void net_free(Net& net) {
                      (void**)&net.sg, (void**)&net.s0, (void**)&net.s1, &net.wt_trunk, (void**)&net.wt_first, &net.wt_fc0,
                      &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part, (void**)&net.d_chunk, (void**)&net.d_groups,
                      (void**)&net.d_singles, (void**)&net.d_gcnt, (void**)&net.sib_h, (void**)&net.d_sib_rows, (void**)&net.d_sib_slot,
-                     (void**)&net.d_bin_start, (void**)&net.d_tile_info, &net.d_slot_desc, &net.d_rows};
+                     (void**)&net.d_bin_start, (void**)&net.d_tile_info, &net.d_slot_desc, &net.d_rows, (void**)&net.part_w};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     for (int i = 0; i < NET_TENSORS; ++i) { if (net.w[i]) hipFree(net.w[i]); net.w[i] = nullptr; }
 }
@@ -2243,7 +2344,7 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         launch_trunk<15, false>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1);            // the rows outside the runs
         return;
     }
-    k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles);
+    k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu);
     launch_trunk<15, false, 48>(net, S, max_groups, st, nullptr, net.d_gcnt);                              // base positions -> full rows [0, runs)
     launch_trunk<15, false, 32>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1, net.d_gcnt);         // single rows -> full rows [runs, runs + singles)
     k_sib_children<true><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
@@ -2257,34 +2358,27 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
     const int hw = net.hw, nsup = hw * 2;
     const int tiles_max = (max_count + GT_BS - 1) / GT_BS;
     const size_t cap_rows = (size_t)tiles_max * GT_BS;
-    static int n_cu_dev[64] = {};
-    int& n_cu = n_cu_dev[net.device & 63];
-    if (!n_cu) {
-        hipDeviceProp_t prop;
-        n_cu = (hipGetDeviceProperties(&prop, net.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
-    // the live count of full rows is only known on the device; the split is chosen for the typical round (runs of ~14 rows)
-    const int tiles_exp = (max_count / 12 + 64 + GT_BS - 1) / GT_BS;
-    int nsplit = 1;
-    double best = 1e30;
-    for (int d = 1; d <= 8; ++d) {
-        if (nsup % d || (size_t)d * cap_rows > net.part_rows) continue;
-        const double cost = (double)((tiles_exp * d + n_cu - 1) / n_cu) / d * (d > 1 ? 1.04 : 1.0);
-        if (cost < best - 1e-9) { best = cost; nsplit = d; }
-    }
-    k_fc0_mx<EPI_PARTIAL><<<dim3(tiles_max, nsplit), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup / nsplit, net.row_u4, hw / 32,
-                                                                    (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, cap_rows, net.part, net.d_gcnt + 3,
-                                                                    max_count, nullptr, nullptr, nullptr);
-    k_facc_reduce<<<512, 256, 0, st>>>(net.part, nsplit, cap_rows, net.d_gcnt + 3);
-    const int wtiles_max = tiles_max + SIB_BINS + 1;
+    const int n_cu = net.n_cu;
+    // the live count of full rows is only known on the device: k_bin_prefix chose the K split (d_gcnt[7], at most 8 ways)
+    k_fc0_mx<EPI_PARTIAL><<<dim3(tiles_max, 8), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32,
+                                                               (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, cap_rows, net.part, net.d_gcnt + 3,
+                                                               max_count, net.d_gcnt + 7, nullptr, nullptr);
+    k_facc_reduce<<<512, 256, 0, st>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 7);
+    // window tiles: whole rounds of workgroups at full K, the tiles of the last partial round split over K (k_bin_prefix)
+    const int wtiles_max = (tiles_max + SIB_BINS + 1 + 7) / 8 * 8 + 8; // (the XCD-aware tile mapping rounds an eighth of the tiles up)
     k_fc0_mx<EPI_SPLIT, 0, true><<<dim3(wtiles_max, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
                                                                        (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr, net.d_gcnt, max_count,
                                                                        net.d_tile_info, (const uint2*)net.d_slot_desc, net.part);
+    const int stiles = wtiles_max < n_cu + 8 ? wtiles_max : n_cu + 8;
+    k_fc0_mx<EPI_PARTIAL, 0, true><<<dim3(stiles, 7), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
+                                                                     (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, net.part_w_rows, net.part_w, net.d_gcnt,
+                                                                     max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, nullptr);
+    k_win_finish<<<(unsigned)(((size_t)stiles * GT_BS * 64 + 255) / 256), 256, 0, st>>>(net.part_w, net.part_w_rows, net.d_gcnt, net.d_tile_info,
+                                                                                         (const uint2*)net.d_slot_desc, net.part, bias_fc0, h0, 128);
 }
 
 static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1) {
     const int hw = net.hw;
-    const int ks0 = hw * 8;
     static const int use_sib = getenv("OMOK_TRUNK_SIB") ? atoi(getenv("OMOK_TRUNK_SIB")) : 2; // 0: every row through k_trunk, 1: copy path, 2: difference path
     const bool sib = net.n == 15 && !from_f32 && sib_side >= 0 && use_sib && net.siblings && net.d_groups;
     const bool delta = sib && use_sib >= 2;
