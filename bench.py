@@ -223,6 +223,10 @@ def precision_check(args, rows, device):
     x = np.concatenate(xs)[:rows]
     eng.close()
     out = oa.precision.measure(oa.weights.init_random(n, seed=0), n, x, device=device, batch_k=k)
+    # the search rounds' own path through trunk and fc0 (N = 15: sibling base + window differences), on the rows of real rounds
+    out["search_rounds"] = oa.precision.measure_search_rounds(oa.weights.init_random(n, seed=0), n, games=max(8, rows // (6 * k)), batch_k=k,
+                                                              rounds=6, plies=3, device=device, seed=args.seed + 2)
+    out["within_contract"] = bool(out["within_contract"] and out["search_rounds"]["within_contract"])
     out["reference"] = "OMOK_NET_F32 kernels on the same GPU (fp32 VALU, k-ascending sums)"
     out["contract"] = "1e-3 on the outputs of AgentModel::evaluate_pv (p after softmax, v after tanh)"
     return out

@@ -920,13 +920,22 @@ __global__ __launch_bounds__(256) void k_facc_reduce(float* __restrict__ part, s
 // DELTA (difference path): a_out holds the FULL rows (one per run, written by k_trunk<BASE | DELTA>); the child's window entries are
 // stored as DIFFERENCES to the base's entries (dequantised: f16 hi + fp6 residual * 2^scale, exactly what fc0 will multiply), in the
 // same entry format, into the child's slot row of d_rows: fc0(child) = fc0(base row) + W[window] * difference row.
-template <bool DELTA>
+template <bool DELTA, bool TPROF = false> // TPROF (OMOK_SIB_PROF=1, timing only): shader-clock cycles per phase, summed over wave 0's passes, into tprof[]
 __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict__ board, const uint4* __restrict__ wt, const float* __restrict__ side,
                                                       uint4* __restrict__ a_out, size_t row_u4, const uint4* __restrict__ sib_rows,
                                                       const int32_t* __restrict__ d_cnt, const float* __restrict__ hscr,
                                                       const uint32_t* __restrict__ sib_slot, const int32_t* __restrict__ bin_start,
-                                                      uint4* __restrict__ d_rows, uint2* __restrict__ slot_desc) {
+                                                      uint4* __restrict__ d_rows, uint2* __restrict__ slot_desc,
+                                                      unsigned long long* __restrict__ tprof) {
     constexpr int N = 15;
+    unsigned long long tp_acc[12] = {}, tp_last = 0;
+    auto TP = [&](int phase) { // (phase = what ended here)
+        if (TPROF) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            tp_acc[phase] += now - tp_last;
+            tp_last = now;
+        }
+    };
     using TG = TrunkGeo<N>;
     constexpr int HW = TG::HW, NW = Geo<N>::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -944,26 +953,42 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
     // are PAIR barriers (a flag per wave in LDS, the LDS executes a wave's accesses in order), not workgroup barriers.  The four pairs
     // then need not march in step -- they are started a quarter of a pass apart, so that the two waves of a SIMD (pairs p and p + 2) are
     // half a pass apart: one is in its matrix phases while the other reads windows or waits for memory.
-    volatile int* pbar = (volatile int*)(smem + TR_WBYTES + 4 * SIB_CGRID_BYTES + TR_SIDE_FLOATS * 4);
+    __shared__ volatile int pbar[8]; // (a static LDS object: through a pointer into `smem` the accesses became FLAT instructions, whose
+                                     //  waits also drain every outstanding global store and load)
     if (tid < 8) pbar[tid] = 0;
     __syncthreads();
+    typedef volatile __attribute__((address_space(3))) int* lds_flag_t; // (an LDS-typed pointer: captured in the lambda as a generic one it is flat again)
+    const lds_flag_t flag_mine = (lds_flag_t)(volatile int*)&pbar[wv], flag_mate = (lds_flag_t)(volatile int*)&pbar[wv ^ 1];
     int pbar_k = 0;
-    auto lds_barrier = [&]() {
+    auto bar_post = [&]() { // "my LDS accesses so far are done"
         ++pbar_k;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) pbar[wv] = pbar_k;
-        while (__builtin_amdgcn_readfirstlane(pbar[wv ^ 1]) < pbar_k) __builtin_amdgcn_s_sleep(1);
+        if (lane == 0) *flag_mine = pbar_k;
+    };
+    auto bar_wait = [&]() { // until the mate has posted as often as this wave
+        while (__builtin_amdgcn_readfirstlane(*flag_mate) < pbar_k) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
     };
+    auto lds_barrier = [&]() { bar_post(); bar_wait(); };
     for (int i = 0; i < 2 * (wv >> 1); ++i) __builtin_amdgcn_s_sleep(94); // (64 clocks per unit: ~6 us per pair index)
     const int nsib = d_cnt[2];
     const half8* convW = (const half8*)(wt + TR_WBYTES / 16);
+    // conv_in fragments: 32 registers that are only needed at the top of a pass.  They are fetched again at the END of every pass (from
+    // L2, under the stores) instead of living through the blocks, where they pushed lane-constant addresses into scratch whose
+    // reloads (a dozen dependent round trips in the store phase) cost more than the whole arithmetic of the pass
     half8 cwh[4], cwl[4];
+    auto load_conv_w = [&]() {
+        typedef const __attribute__((address_space(1))) half8* gptr_t; // (global, not generic: a flat load would also count as an LDS access)
+        unsigned long long cpv = (unsigned long long)convW;
+        asm volatile("" : "+s"(cpv)); // (opaque: keeps the loads inside the loop)
+        gptr_t cp = (gptr_t)cpv;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        cwh[m] = convW[m * 64 + lane];
-        cwl[m] = convW[(4 + m) * 64 + lane];
-    }
+        for (int m = 0; m < 4; ++m) {
+            cwh[m] = cp[m * 64 + lane];
+            cwl[m] = cp[(4 + m) * 64 + lane];
+        }
+    };
+    load_conv_w();
     // wave pair = child, wave parity = window tile
     const int pair = wv >> 1, wt2 = wv & 1, ptid = tid & 127;
     const int c_w = 32 * wt2 + l31;            // window pixel of this lane, row-major in the 7x7 window
@@ -1217,6 +1242,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
         const float* dwt = lside + blk * TR_SIDE_PER_BLOCK;
         f32x16 acc;
         L0_tile(x, blk, acc);
+        TP(1);
         if (c_valid) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -1229,6 +1255,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
 #pragma unroll
         for (int u = 0; u < 2; ++u) *(uint4*)(cgrid + ring_off[u]) = ring[u]; // halo ring <- the base's h of this block (zero outside the board)
         lds_barrier(); // B2
+        TP(2);
         if (fetch_next_ring) ring_fetch(hb, blk + 1, wy0, wx0, ring);
         // depthwise over the 7x7 window: (row, strip of 4 | 3 pixels, 4-channel group) = 112 items for the pair's 128 threads
         f32x4 dout[TG::SW];
@@ -1245,6 +1272,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
             f32x4 w9[9];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) w9[tap] = *(const f32x4*)(dwt + tap * NM + 4 * cg);
+            bar_post(); // B3, first half: this wave's window reads have returned; the arithmetic runs under the mate's
 #pragma unroll
             for (int p = 0; p < TG::SW; ++p) {
                 f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1257,7 +1285,8 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
                 dout[p] = o;
             }
         }
-        lds_barrier(); // B3
+        TP(3);
+        bar_wait(); // B3, second half: the grid can be overwritten in place
         if (ptid < 7 * 2 * 8) {
 #pragma unroll
             for (int p = 0; p < TG::SW; ++p)
@@ -1270,6 +1299,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
 #pragma unroll
             for (int i = 0; i < 4; ++i) d[4 * g + i] = dv[i];
         }
+        TP(4);
     };
     // A workgroup takes a CONTIGUOUS range of the rows (a run's children are adjacent: the 16 children of a run are four consecutive
     // passes of one workgroup, so the base's h grids and operand row come from HBM once and from this XCD's L2 afterwards; dealt
@@ -1280,6 +1310,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
     window_of(ent_c, wy0, wx0);
     ring_fetch(hscr + (size_t)ent_c.y * 3 * SIB_HB_FLOATS, 0, wy0, wx0, ring);
     for (int e0 = e_begin; e0 < e_end; e0 += pass_stride) { // four children per pass; uniform over the workgroup
+        if (TPROF) tp_last = __builtin_readcyclecounter();
         const bool act = e0 + pair < e_end;
         const uint4 ent = ent_c;
         const int crow = (int)ent.x;
@@ -1301,21 +1332,26 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
         input_bits(cw, turn, q, bits);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         conv_in_tile(x, bits[0], bits[1], bits[2]);
+        TP(0);
         float d[16];
 #pragma unroll 1
         for (int blk = 0; blk < 2; ++blk) {
             block_front(blk, d, true);
             L1L2_tile(x, blk, d);
+            TP(5);
         }
         block_front(2, d, false);
         if (DELTA) base_fetch(a_out + (size_t)ent.y * row_u4, q);
         L1L2_tile(x, 2, d);
+        TP(5);
         { // the window's 49 pixel entries: over the copied base row, or (DELTA) as differences into the slot's row
             int rd_gi[4], rd_px[4];
             bool rd_ok[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int w = 32 * wt2 + 8 * i + (lane >> 3);
+                int w = 32 * wt2 + 8 * i + (lane >> 3);
+                asm volatile("" : "+v"(w)); // (opaque: the store addresses are a few adds per pass; hoisted out of the loop as lane-constant
+                                            //  64-bit offsets they were spilled, and every reload's wait drained the stores in flight)
                 const int wc = w < SIB_WPX ? w : SIB_WPX - 1;
                 rd_gi[i] = (wc / SIB_WIN + 1) * SIB_GW + (wc % SIB_WIN + 1);
                 rd_px[i] = DELTA ? wc : (wy0 + wc / SIB_WIN) * N + (wx0 + wc % SIB_WIN);
@@ -1325,18 +1361,24 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
                 base_subtract(x);
                 if (act && wt2 == 0 && lane == 0) slot_desc[slot] = make_uint2((uint32_t)crow, ent.y);
             }
+            TP(6);
             // the next pass's first halo ring before this pass's stores queue up behind it
             window_of(ent_n, wy0, wx0);
             ring_fetch(hscr + (size_t)ent_n.y * 3 * SIB_HB_FLOATS, 0, wy0, wx0, ring);
             store_rows(x, crow_p, c_valid, cgrid + c_gi * GRID_STRIDE, rd_gi, rd_px, rd_ok, cgrid);
         }
+        load_conv_w();
         ent_c = ent_n;
         ent_n = ent_nn;
         slot_c = slot_n;
         slot_n = slot_nn;
         word_c = word_n;
-        lds_barrier(); // the staging rows are free again (the next pass writes the pad row / grid)
+        TP(7);
+        // (no barrier here: the staging rows a wave read back are its own pixels' rows, the board words its own copy; the mate's next
+        //  accesses to this wave's rows are window reads behind B2 of the next pass)
     }
+    if (TPROF && lane == 0 && (wv == 0 || wv == 5))
+        for (int i = 0; i < 9; ++i) atomicAdd(&tprof[(wv ? 16 : 0) + i], tp_acc[i]);
 }
 
 // ===============================================================================================
@@ -2325,8 +2367,8 @@ static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_
 // delta = false: copy path (the base row is stored into every child row, the children overwrite their windows; fc0 unchanged).
 // delta = true: difference path (full rows for the runs' bases and the single rows, difference rows for the children; fc0 = launch_fc0_delta).
 static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_count, hipStream_t st, bool delta) {
-    constexpr int LDS = TR_WBYTES + 4 * SIB_CGRID_BYTES + TR_SIDE_FLOATS * 4 + 32; // (+ the pair-barrier flags)
-    static_assert(LDS <= 160 * 1024, "k_sib_children LDS");
+    constexpr int LDS = TR_WBYTES + 4 * SIB_CGRID_BYTES + TR_SIDE_FLOATS * 4;
+    static_assert(LDS + 32 <= 160 * 1024, "k_sib_children LDS (+ the static pair-barrier flags)");
     static bool attr_done[64] = {};
     if (!attr_done[net.device & 63]) {
         hipFuncSetAttribute((const void*)k_sib_children<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -2340,16 +2382,40 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
     if (!delta) {
         launch_trunk<15, false, 16>(net, S, max_groups, st, nullptr, net.d_gcnt);                 // base positions of the runs
         k_sib_children<false><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
-                                                      (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, nullptr, nullptr, nullptr, nullptr);
+                                                      (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, nullptr, nullptr, nullptr, nullptr, nullptr);
         launch_trunk<15, false>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1);            // the rows outside the runs
         return;
     }
     k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu);
     launch_trunk<15, false, 48>(net, S, max_groups, st, nullptr, net.d_gcnt);                              // base positions -> full rows [0, runs)
     launch_trunk<15, false, 32>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1, net.d_gcnt);         // single rows -> full rows [runs, runs + singles)
+    static const bool tprof = getenv("OMOK_SIB_PROF") && atoi(getenv("OMOK_SIB_PROF")); // timing experiments only
+    if (tprof) {
+        static unsigned long long* d_tp = nullptr;
+        static unsigned long long acc[32] = {};
+        static int launches = 0;
+        if (!d_tp) { hipMalloc(&d_tp, 256); hipMemset(d_tp, 0, 256); hipFuncSetAttribute((const void*)k_sib_children<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }
+        k_sib_children<true, true><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
+                                                           (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, net.d_sib_slot, net.d_bin_start,
+                                                           (uint4*)net.d_rows, (uint2*)net.d_slot_desc, d_tp);
+        if (++launches % 100 == 0) {
+            hipStreamSynchronize(st);
+            hipMemcpy(acc, d_tp, 256, hipMemcpyDeviceToHost);
+            static const char* names[9] = {"inputs+conv_in", "L0", "grid write + B2", "ring fetch + depthwise", "B3 + write + B4 + read d", "L1L2 (+ base fetch)",
+                                           "base subtract", "stores (+ next ring fetch)", "end barrier"};
+            for (int w = 0; w < 2; ++w) {
+                double tot = 0;
+                for (int i = 0; i < 9; ++i) tot += (double)acc[16 * w + i];
+                fprintf(stderr, "[sib prof] wave %d, %d launches x 256 workgroups: ", w ? 5 : 0, launches);
+                for (int i = 0; i < 9; ++i) fprintf(stderr, "%s %.1f%%  ", names[i], 100.0 * (double)acc[16 * w + i] / tot);
+                fprintf(stderr, " | %.0f cycles per workgroup and launch\n", tot / 256.0 / launches);
+            }
+        }
+        return;
+    }
     k_sib_children<true><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
                                                  (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, net.d_sib_slot, net.d_bin_start,
-                                                 (uint4*)net.d_rows, (uint2*)net.d_slot_desc);
+                                                 (uint4*)net.d_rows, (uint2*)net.d_slot_desc, nullptr);
 }
 
 // fc0 of a sibling round on the difference path: fp32 fc0 rows of the full rows (split-K over blockIdx.y: there are ~16x fewer full rows

@@ -4,7 +4,11 @@ the outputs of AgentModel::evaluate_pv (alpha-zero/src/agent_model.rs:116-134): 
 correction terms carry 4 significant bits (block-scaled fp6), i.e. products are good to ~2^-16: with random-init weights the
 outputs agree to 1e-4 .. 7e-4, with trained weights the value head has been seen at 1.05e-3 (N = 9, 200 Adadelta steps).  A
 caller that needs the bound unconditionally runs this check after every weight update (`Trainer` does and logs it) and can fall
-back to `net_mode = OMOK_NET_F32`."""
+back to `net_mode = OMOK_NET_F32`.
+
+At board_size 15 the SEARCH ROUNDS take a different path through the first two stages of the net (sibling requests = one base row
++ 7x7-window difference rows) than `omok_evaluate_pv`; `measure_search_rounds` checks that path on the request rows of
+real rounds."""
 import numpy as np
 
 from . import api
@@ -31,5 +35,38 @@ def measure(tensors, n, inputs, device=0, batch_k=16):
     out["max_dvpre"] = float(np.abs(vp - vp32).max())
     out["logit_abs_max"] = float(np.abs(lg32).max())
     out["logit_std"] = float(lg32.std())
+    out["within_contract"] = bool(out["max_dp"] < 1e-3 and out["max_dv"] < 1e-3)
+    return out
+
+
+def measure_search_rounds(tensors, n, games=64, batch_k=16, rounds=6, plies=3, device=0, seed=1):
+    """The same comparison for the outputs of search rounds: plays `plies` plies of `rounds` rounds on `games` trees with the
+    product engine and compares every round's p / v with the fp32 kernels' evaluation of the same request rows."""
+    eng = api.Engine(board_size=n, games=games, max_nodes=max(1024, 2 * rounds * batch_k), max_tables=256, max_batch_k=batch_k, device=device,
+                     seed=seed, net_mode=B.NET_F16X3)
+    eng.load_weights(tensors)
+    ref = api.Engine(board_size=n, games=games, max_nodes=8, max_tables=4, max_batch_k=batch_k, device=device, net_mode=B.NET_F32)
+    ref.load_weights(tensors)
+    sp = api.SelfPlay(eng)
+    sp.reset()
+    out = {"rows": 0, "max_dp": 0.0, "max_dv": 0.0}
+    for _ in range(plies):
+        if sp.alive_count == 0:
+            break
+        for rnd in range(rounds):
+            nreq = sp.round_generate(rnd, batch_k, 0.25, 0.03)
+            x = sp.round_inputs().copy()
+            p, v = sp.round_eval()
+            p, v = np.array(p).reshape(nreq, -1), np.array(v).reshape(-1)
+            sp.round_scatter()
+            if nreq:
+                p32, v32 = ref.evaluate_pv(x)
+                out["max_dp"] = max(out["max_dp"], float(np.abs(p - p32.reshape(nreq, -1)).max()))
+                out["max_dv"] = max(out["max_dv"], float(np.abs(v - v32.reshape(-1)).max()))
+                out["rows"] += int(nreq)
+        sp.sample_actions(1.0, 30)
+        sp.advance()
+    eng.close()
+    ref.close()
     out["within_contract"] = bool(out["max_dp"] < 1e-3 and out["max_dv"] < 1e-3)
     return out

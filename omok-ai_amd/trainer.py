@@ -93,6 +93,11 @@ class Trainer:
                 x, _, _ = T.decode_records(records[: self.precision_rows], self.n)
                 chk = precision.measure(self.phase.net.tensors(), self.n, x.reshape(x.shape[0], -1).cpu().numpy(), device=self.local_rank,
                                         batch_k=p.evaluate_batch_size)
+                rounds = precision.measure_search_rounds(self.phase.net.tensors(), self.n, games=16, batch_k=p.evaluate_batch_size, rounds=4, plies=2,
+                                                         device=self.local_rank, seed=self.iteration)
+                chk["search_rounds"] = rounds
+                chk["max_dp"], chk["max_dv"] = max(chk["max_dp"], rounds["max_dp"]), max(chk["max_dv"], rounds["max_dv"])
+                chk["within_contract"] = bool(chk["within_contract"] and rounds["within_contract"])
                 self.last_precision = chk
                 if not chk["within_contract"]:
                     log(f"[iter={self.iteration}] WARNING: net outputs differ from the fp32 kernels by |dp| {chk['max_dp']:.2e} |dv| {chk['max_dv']:.2e} "
