@@ -352,10 +352,13 @@ def main():
         ach = rows * flop_row / sec / 1e12 if sec > 0 else 0.0
         per_row = pmc.get(kernel + "_hbm_bytes_per_row_calibrated") or pmc.get(kernel + "_hbm_bytes_per_row") or PMC_HBM_BYTES_PER_ROW.get(n, {}).get(kernel)
         per_row_x2 = pmc.get(kernel + "_hbm_bytes_per_row")
-        # trunk: the 384-B-per-pixel operand row it writes; at N = 15 (sibling path) also the child's 49 window pixels written a second time
-        # and a sixteenth of the base pass's three h grids
-        alg_row = {"k_trunk": 2 * 8 * ((hw + 63) // 64) + 16 + 384.0 * hw + (49 * 384.0 + 3 * hw * 128.0 / 16 if n == 15 else 0.0),
-                   "k_fc0_mx": 384.0 * hw + 2048}[kernel]
+        # Bytes a launch has to move per request row.  N = 9: trunk = the 384-B-per-pixel operand row it writes, fc0 = that row read once.
+        # N = 15 (difference path): trunk = the child's 49-pixel difference row written (18816 B) + the base's 49 entries read
+        # + 1/15 of a full row and of the base's three h grids (one base per run of ~15 siblings); fc0 = the difference row + 1/15 full row.
+        if n == 15:
+            alg_row = {"k_trunk": 2 * 18816.0 + (384.0 * hw + 3 * hw * 128.0) / 15.0, "k_fc0_mx": 18816.0 + 384.0 * hw / 15.0 + 2048}[kernel]
+        else:
+            alg_row = {"k_trunk": 2 * 8 * ((hw + 63) // 64) + 16 + 384.0 * hw, "k_fc0_mx": 384.0 * hw + 2048}[kernel]
         return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / F16_DENSE_PEAK_TFLOPS, "traffic": per_row * rows / launches if per_row else None,
                 "traffic_uncalibrated_x2": per_row_x2 * rows / launches if per_row_x2 else None,
@@ -365,12 +368,15 @@ def main():
                 "avg_launch_ms": k_ms[kernel] / launches, "rows_per_launch": rows / launches, "share_of_kernel_time": k_ms[kernel] / max(sum(k_ms.values()), 1e-9),
                 "note": note}
 
-    note_trunk = ("conv_in + 3 bottleneck blocks (k_group + k_trunk<BASE> + k_sib_children + k_trunk on the rows outside sibling runs), ALGORITHMIC flops "
-                  "2*MAC of a full evaluation (13.0 MFLOP/eval at N = 15) / HIP-event time on the engine's stream.  Every product runs as 3 f16 MFMAs "
-                  "(split operands), and at N = 15 sibling requests share a base pass and recompute only a 7x7 window each, so the EXECUTED matrix "
-                  "work is ~0.3x the algorithmic figure: `achieved` counts useful work, the kernels' own MFMA utilisation is in profiles/")
-    note_fc0 = ("algorithmic flops 2*128*HW*512 per eval; per K = 64 the kernel issues 4 f16 + 2 block-scaled fp6 MFMAs (split operands) = 1.5x the "
-                "pipe time of a plain-f16 product, so frac <= 0.67 by construction")
+    note_trunk = ("conv_in + 3 bottleneck blocks (k_group + k_bin_prefix + k_trunk<BASE> + k_sib_children + k_trunk on the rows outside sibling runs), "
+                  "ALGORITHMIC flops 2*MAC of a full evaluation (13.0 MFLOP/eval at N = 15) / HIP-event time on the engine's stream.  Every product "
+                  "runs as 3 f16 MFMAs (split operands), and at N = 15 sibling requests share a base pass and recompute only a 7x7 window each, so "
+                  "the EXECUTED matrix work is ~0.3x the algorithmic figure: `achieved` counts useful work; the kernels' own utilisation (MFMA busy "
+                  "26 %, VALU 52 %) is in profiles/")
+    note_fc0 = ("ALGORITHMIC flops 2*128*HW*512 per eval / HIP-event time of all fc0 launches.  Per K = 64 the kernels issue 4 f16 + 2 block-scaled "
+                "fp6 MFMAs (split operands) = 1.5x the pipe time of a plain-f16 product (frac <= 0.67 for a dense fc0).  At N = 15 a search round "
+                "runs the dense fc0 only on one full row per run of siblings and 98 of the 450 K-steps (the 7x7 window) on each child's difference "
+                "row, i.e. ~0.28x of the algorithmic work is EXECUTED: `achieved` counts useful work and can exceed what a dense kernel could reach")
     net_s = (st["ms_trunk"] + st["ms_fc0"] + st["ms_tail"]) * 1e-3
     tree_s = st["ms_tree"] * 1e-3
     tree_traffic = pmc.get("tree_hbm_bytes_per_sim")

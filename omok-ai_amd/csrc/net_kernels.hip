@@ -826,7 +826,8 @@ __device__ inline int sib_bin_at(int pos) { // layout position -> bin
     return (1 + pos / E) * SIB_ORG + 1 + pos % E;                                                      // interior
 }
 __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, int32_t* __restrict__ bin_start, int32_t* __restrict__ tile_info,
-                                                    uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu) {
+                                                    uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu, int max_fways,
+                                                    int max_wways, int part_w_rows) {
     __shared__ int tile0[SIB_BINS + 2];
     const int tid = threadIdx.x;
     const int c = tid < SIB_BINS ? cnt[8 + tid] : (tid == SIB_BINS ? cnt[1] : 0);
@@ -848,12 +849,13 @@ __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, i
         }
         if (t_split < ntiles) t_split = first;
         int ways = ntiles > t_split ? n_cu / (ntiles - t_split) : 1;
-        if (ways > 7) ways = 7;
+        if (ways > max_wways) ways = max_wways;
+        if (ntiles > t_split && ways > part_w_rows / ((ntiles - t_split) * GT_BS)) ways = part_w_rows / ((ntiles - t_split) * GT_BS); // (partials slab)
         if (ways < 2) { ways = 1; t_split = ntiles; }
         cnt[3] = cnt[0] + cnt[1];
         const int ftiles = (cnt[3] + GT_BS - 1) / GT_BS;          // fc0 of the full rows: K split so that one round of workgroups covers it
         int fways = ftiles > 0 ? n_cu / ftiles : 1;
-        cnt[7] = fways < 1 ? 1 : (fways > 8 ? 8 : fways);
+        cnt[7] = fways < 1 ? 1 : (fways > max_fways ? max_fways : fways);
         cnt[4] = ntiles;
         cnt[5] = t_split;
         cnt[6] = ways;
@@ -874,6 +876,7 @@ __global__ __launch_bounds__(256) void k_win_finish(const float* __restrict__ pa
                                                     size_t out_row_u4) {
     const int nt = cnt[4], t0 = cnt[5], ways = cnt[6];
     if (ways < 2) return;
+    cap_rows = (size_t)(nt - t0) * GT_BS; // the split set's slots, densely
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // (local slot, mt 16, s 2, h 2)
     const size_t local = i >> 6;
     const int tile = t0 + (int)(local / GT_BS);
@@ -1499,6 +1502,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
             ways = d_count[6];
             if ((int)blockIdx.y >= ways) return;
             part_row0 = t_split * GT_BS;
+            out_row_u4 = (size_t)(nt - t_split) * GT_BS; // partials: [split][slot inside the split set]
         }
         b0 = tile * GT_BS;
         const int ti = tile_info[tile], bin = ti & 0xFF;
@@ -2364,6 +2368,14 @@ static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_
                                   out_row_u4, out_logits, S.d_count, max_count);
 }
 
+// K splits of the difference path's fc0 launches (chosen on the device, k_bin_prefix): the full rows up to 30 ways as far as the
+// partial slab holds ways x (the launch's row capacity); window tiles of the split set up to 14 ways (7 super-steps each)
+constexpr int SIB_MAX_WWAYS = 14;
+static int sib_max_fways(const Net& net, int max_count) {
+    const size_t cap_rows = (size_t)((max_count + GT_BS - 1) / GT_BS) * GT_BS;
+    const size_t w = net.part_rows / cap_rows;
+    return w > 30 ? 30 : (w < 1 ? 1 : (int)w);
+}
 // delta = false: copy path (the base row is stored into every child row, the children overwrite their windows; fc0 unchanged).
 // delta = true: difference path (full rows for the runs' bases and the single rows, difference rows for the children; fc0 = launch_fc0_delta).
 static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_count, hipStream_t st, bool delta) {
@@ -2386,7 +2398,21 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         launch_trunk<15, false>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1);            // the rows outside the runs
         return;
     }
-    k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu);
+    k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu,
+                                    sib_max_fways(net, max_count), SIB_MAX_WWAYS, (int)std::min<size_t>(net.part_w_rows * 7, (size_t)1 << 30));
+    static const bool stats = getenv("OMOK_SIB_STATS") && atoi(getenv("OMOK_SIB_STATS")); // diagnostics only: synchronises every round
+    if (stats) {
+        static long long acc[8] = {}, launches = 0;
+        int32_t c[8];
+        hipStreamSynchronize(st);
+        hipMemcpy(c, net.d_gcnt, sizeof(c), hipMemcpyDeviceToHost);
+        for (int i = 0; i < 8; ++i) acc[i] += c[i];
+        if (++launches % 50 == 0) {
+            fprintf(stderr, "[sib stats] rounds %lld: per round runs %.0f singles %.0f rows-in-runs %.0f (run length %.2f) window tiles %.1f (split set from %.1f, %.1f ways) full-row K split %.1f\n",
+                    launches, acc[0] / 50.0, acc[1] / 50.0, acc[2] / 50.0, acc[0] ? (double)acc[2] / acc[0] : 0.0, acc[4] / 50.0, acc[5] / 50.0, acc[6] / 50.0, acc[7] / 50.0);
+            for (int i = 0; i < 8; ++i) acc[i] = 0;
+        }
+    }
     launch_trunk<15, false, 48>(net, S, max_groups, st, nullptr, net.d_gcnt);                              // base positions -> full rows [0, runs)
     launch_trunk<15, false, 32>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1, net.d_gcnt);         // single rows -> full rows [runs, runs + singles)
     static const bool tprof = getenv("OMOK_SIB_PROF") && atoi(getenv("OMOK_SIB_PROF")); // timing experiments only
@@ -2425,8 +2451,8 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
     const int tiles_max = (max_count + GT_BS - 1) / GT_BS;
     const size_t cap_rows = (size_t)tiles_max * GT_BS;
     const int n_cu = net.n_cu;
-    // the live count of full rows is only known on the device: k_bin_prefix chose the K split (d_gcnt[7], at most 8 ways)
-    k_fc0_mx<EPI_PARTIAL><<<dim3(tiles_max, 8), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32,
+    // the live count of full rows is only known on the device: k_bin_prefix chose the K split (d_gcnt[7], at most sib_max_fways)
+    k_fc0_mx<EPI_PARTIAL><<<dim3(tiles_max, sib_max_fways(net, max_count)), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32,
                                                                (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, cap_rows, net.part, net.d_gcnt + 3,
                                                                max_count, net.d_gcnt + 7, nullptr, nullptr);
     k_facc_reduce<<<512, 256, 0, st>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 7);
@@ -2436,7 +2462,7 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
                                                                        (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr, net.d_gcnt, max_count,
                                                                        net.d_tile_info, (const uint2*)net.d_slot_desc, net.part);
     const int stiles = wtiles_max < n_cu + 8 ? wtiles_max : n_cu + 8;
-    k_fc0_mx<EPI_PARTIAL, 0, true><<<dim3(stiles, 7), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
+    k_fc0_mx<EPI_PARTIAL, 0, true><<<dim3(stiles, SIB_MAX_WWAYS), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
                                                                      (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, net.part_w_rows, net.part_w, net.d_gcnt,
                                                                      max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, nullptr);
     k_win_finish<<<(unsigned)(((size_t)stiles * GT_BS * 64 + 255) / 256), 256, 0, st>>>(net.part_w, net.part_w_rows, net.d_gcnt, net.d_tile_info,
@@ -2447,7 +2473,11 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     const int hw = net.hw;
     static const int use_sib = getenv("OMOK_TRUNK_SIB") ? atoi(getenv("OMOK_TRUNK_SIB")) : 2; // 0: every row through k_trunk, 1: copy path, 2: difference path
     const bool sib = net.n == 15 && !from_f32 && sib_side >= 0 && use_sib && net.siblings && net.d_groups;
-    const bool delta = sib && use_sib >= 2;
+    // Small rounds (the thin tail of an episode) take the copy path: the difference path needs one fc0 tile per non-empty window bin
+    // (81 + 1) however few rows there are, the copy path rows / 128 tiles of the full K -- measured break-even between 4096 and 8192 rows.  The choice is a
+    // function of the host's bound on the request count (alive games x K) only, so a run is reproducible.
+    static const int delta_min_rows = getenv("OMOK_SIB_DELTA_MIN") ? atoi(getenv("OMOK_SIB_DELTA_MIN")) : 6144;
+    const bool delta = sib && use_sib >= 2 && max_count >= delta_min_rows;
     if (prof) prof->begin(PC_TRUNK, st);
     if (sib) launch_trunk_siblings(net, S, sib_side, max_count, st, delta);
     else if (net.n == 9) { if (from_f32) launch_trunk<9, true>(net, S, max_count, st); else launch_trunk<9, false>(net, S, max_count, st); }

@@ -27,7 +27,8 @@ if a.json:
         return sum(v for (k, c), v in agg.items() if c == counter and any(k.startswith(p) for p in prefixes))
     out = {"board": a.board, "rows": a.rows, "sims": a.sims, "unit": "bytes", "source": a.root,
            "method": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE [KiB] x 1024; raw (x1) fetch kept beside it"}
-    for name, pre in (("k_trunk", ["k_trunk", "k_sib_children", "k_group"]), ("k_fc0_mx", ["k_fc0_mx", "k_splitk_finish"]),
+    for name, pre in (("k_trunk", ["k_trunk", "k_sib_children", "k_group", "k_bin_prefix"]),
+                      ("k_fc0_mx", ["k_fc0_mx", "k_splitk_finish", "k_facc_reduce", "k_win_finish"]),
                       ("tree", ["k_round", "k_scan", "k_fill", "k_scatter", "k_add_evals"])):
         f, w = tot(pre, "FETCH_SIZE") * 1024.0, tot(pre, "WRITE_SIZE") * 1024.0
         denom = a.sims if name == "tree" else a.rows
@@ -39,7 +40,8 @@ if a.json:
             out[key.replace("hbm_bytes", "write_bytes")] = w / denom
             if name == "k_fc0_mx":  # a third of its sample stream (the fp6 residual part: 128 B per pixel) is fetched in exact 64-B requests,
                 # which the counter tallies in full: x2 only applies to the rest (calibration of profiles/README.md, round 1)
-                resid = 128.0 * a.board * a.board
+                # (N = 15, difference path: the residual parts of a request are those of its 49-pixel difference row + 1/15 of a full row)
+                resid = 128.0 * 49 + 128.0 * a.board * a.board / 15.0 if a.board == 15 else 128.0 * a.board * a.board
                 out[key + "_calibrated"] = (2.0 * f + w) / denom - resid
     json.dump({str(a.board): out}, open(a.json, "w"), indent=1)
     print(json.dumps(out, indent=1))
