@@ -58,6 +58,8 @@ def parse(argv=None):
     ap.add_argument("--gather", action="store_true", help="RCCL all-gather-v of replay tuples at episode end")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=20, help="training steps timed after the episode (0 = skip; batch 128)")
+    ap.add_argument("--profile-every", type=int, default=8, help="HIP-event timing of the kernel categories on 1 search round in N (sums scaled); "
+                    "an event record idles the queue ~5 us, 6 category boundaries per round")
     ap.add_argument("--precision-rows", type=int, default=4096, help="rows of the in-run precision check (0 = skip)")
     ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("OMOK_BENCH_BUDGET_S", "540")),
                     help="wall-clock budget of the whole process: the extra legs only run while there is room")
@@ -224,8 +226,8 @@ def precision_check(args, rows, device):
     eng.close()
     out = oa.precision.measure(oa.weights.init_random(n, seed=0), n, x, device=device, batch_k=k)
     # the search rounds' own path through trunk and fc0 (N = 15: sibling base + window differences), on the rows of real rounds
-    out["search_rounds"] = oa.precision.measure_search_rounds(oa.weights.init_random(n, seed=0), n, games=max(8, rows // (6 * k)), batch_k=k,
-                                                              rounds=6, plies=3, device=device, seed=args.seed + 2)
+    out["search_rounds"] = oa.precision.measure_search_rounds(oa.weights.init_random(n, seed=0), n, games=512, batch_k=k,
+                                                              rounds=4, plies=2, device=device, seed=args.seed + 2)  # (8192-row rounds)
     out["within_contract"] = bool(out["within_contract"] and out["search_rounds"]["within_contract"])
     out["reference"] = "OMOK_NET_F32 kernels on the same GPU (fp32 VALU, k-ascending sums)"
     out["contract"] = "1e-3 on the outputs of AgentModel::evaluate_pv (p after softmax, v after tanh)"
@@ -274,7 +276,7 @@ def main():
                     seed=args.seed, game_offset=oa.dist.game_offset(rank, games))
     eng.load_random_weights(0)
     sp = oa.SelfPlay(eng)
-    eng.set_profiling(True)
+    eng.set_profiling(max(1, args.profile_every))
 
     def barrier():
         if use_cuda:
@@ -405,6 +407,8 @@ def main():
                           "traffic": tree_traffic * st["sims"] / max(st["round_launches"], 1.0) if tree_traffic else None,
                           "traffic_unit": "HBM bytes per round (k_round + k_scan + k_fill + k_scatter*): PMC bytes per simulation (profiles/) x simulations per round"},
         "rank0_kernel_ms": {kk: st[kk] for kk in ("ms_round", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply")},
+        "rank0_kernel_ms_method": f"HIP events on the engine's stream around every kernel category of 1 search round in {max(1, args.profile_every)} "
+                                  "(ply-level work: always), sampled sums scaled by rounds seen / rounds timed",
         "rank0_timed_region_ms": 1e3 * dt,
         "game_length_percentiles": {str(q): float(np.percentile(plies, q)) for q in (0, 10, 25, 50, 75, 90, 99, 100)},
         "arena": {"max_nodes": max_nodes, "max_tables": max_tables, "peak_nodes": st["peak_nodes"], "peak_tables": st["peak_tables"]},

@@ -126,7 +126,8 @@ class Engine:
 
     # ---- stats ------------------------------------------------------------------------------
     def set_profiling(self, on=True):
-        self._chk(B.lib().omok_set_profiling(self.h, 1 if on else 0))
+        """True / 1: time every launch; N > 1: time one search round in N (stats are scaled); False: off."""
+        self._chk(B.lib().omok_set_profiling(self.h, int(on)))
 
     def stats(self):
         s = (C.c_double * 16)()

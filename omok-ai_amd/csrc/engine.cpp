@@ -26,7 +26,7 @@ hipEvent_t Prof::get() {
     return e;
 }
 void Prof::begin(int cat, hipStream_t st) {
-    if (!enabled) return;
+    if (!enabled || !active) return;
     if (n_items == cap_items) {
         if (cap_items >= 8192) resolve();
         else {
@@ -34,12 +34,12 @@ void Prof::begin(int cat, hipStream_t st) {
             items = (Item*)realloc(items, sizeof(Item) * cap_items);
         }
     }
-    Item it{cat, get(), get()};
+    Item it{cat, in_round, get(), get()};
     hipEventRecord(it.a, st);
     items[n_items++] = it;
 }
 void Prof::end(hipStream_t st) {
-    if (!enabled || n_items == 0) return;
+    if (!enabled || !active || n_items == 0) return;
     hipEventRecord(items[n_items - 1].b, st);
 }
 void Prof::resolve() {
@@ -52,8 +52,8 @@ void Prof::resolve() {
     for (int i = 0; i < n_items; ++i) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, items[i].a, items[i].b) == hipSuccess) {
-            ms[items[i].cat] += t;
-            launches[items[i].cat] += 1;
+            if (items[i].sampled) { ms_s[items[i].cat] += t; launches_s[items[i].cat] += 1; }
+            else { ms[items[i].cat] += t; launches[items[i].cat] += 1; }
         }
         pool[n_pool++] = items[i].a;
         pool[n_pool++] = items[i].b;
@@ -582,6 +582,7 @@ static int need_reset(omok_engine* e) {
 static void enqueue_round(omok_engine* e, int round, int K, float eps, float alpha, bool eval_and_scatter, int alive) {
     const int side = e->ply & 1;
     RoundArgs a{side, round, K, e->ply, eps, alpha, e->key, e->cfg.game_offset};
+    e->prof.round_begin();
     e->prof.begin(PC_ROUND, e->st);
     launch_round(e->n, e->S, a, e->st);
     e->prof.end(e->st);
@@ -595,6 +596,7 @@ static void enqueue_round(omok_engine* e, int round, int K, float eps, float alp
         launch_scatter(e->n, e->S, side, e->net.p, e->net.v, alive * K, e->st);
         e->prof.end(e->st);
     }
+    e->prof.round_end();
 }
 
 static int enqueue_execute(omok_engine* e, int count, int K, float eps, float alpha, int alive) {
@@ -1176,16 +1178,16 @@ extern "C" int omok_get_stats(omok_engine* e, double* stats) {
     stats[OMOK_STAT_EVALS] = e->evals + (double)ev;
     stats[OMOK_STAT_PLY_GAMES] = e->ply_games;
     stats[OMOK_STAT_FINISHED] = e->finished;
-    stats[OMOK_STAT_MS_TREE] = e->prof.ms[PC_ROUND] + e->prof.ms[PC_TREE_OTHER];
-    stats[OMOK_STAT_MS_TRUNK] = e->prof.ms[PC_TRUNK];
-    stats[OMOK_STAT_MS_FC0] = e->prof.ms[PC_FC0];
-    stats[OMOK_STAT_MS_TAIL] = e->prof.ms[PC_TAIL];
-    stats[OMOK_STAT_MS_PLY] = e->prof.ms[PC_PLY];
-    stats[OMOK_STAT_FC0_LAUNCHES] = (double)e->prof.launches[PC_FC0];
+    stats[OMOK_STAT_MS_TREE] = e->prof.total_ms(PC_ROUND) + e->prof.total_ms(PC_TREE_OTHER);
+    stats[OMOK_STAT_MS_TRUNK] = e->prof.total_ms(PC_TRUNK);
+    stats[OMOK_STAT_MS_FC0] = e->prof.total_ms(PC_FC0);
+    stats[OMOK_STAT_MS_TAIL] = e->prof.total_ms(PC_TAIL);
+    stats[OMOK_STAT_MS_PLY] = e->prof.total_ms(PC_PLY);
+    stats[OMOK_STAT_FC0_LAUNCHES] = e->prof.total_launches(PC_FC0);
     stats[OMOK_STAT_FC0_ROWS] = e->evals + (double)ev;
     stats[OMOK_STAT_TREE_BYTES] = (double)by;
-    stats[OMOK_STAT_ROUND_LAUNCHES] = (double)e->prof.launches[PC_ROUND];
-    stats[OMOK_STAT_MS_ROUND] = e->prof.ms[PC_ROUND];
+    stats[OMOK_STAT_ROUND_LAUNCHES] = e->prof.total_launches(PC_ROUND);
+    stats[OMOK_STAT_MS_ROUND] = e->prof.total_ms(PC_ROUND);
     stats[OMOK_STAT_PEAK_NODES] = (double)e->peak_nodes;
     stats[OMOK_STAT_PEAK_TABLES] = (double)e->peak_tables;
     return OMOK_OK;
@@ -1195,7 +1197,8 @@ extern "C" int omok_reset_stats(omok_engine* e) {
     ENTER(e);
     if (sync_and_check(e, "reset_stats")) return OMOK_ERR_HIP;
     e->prof.resolve();
-    for (int i = 0; i < PC_COUNT; ++i) { e->prof.ms[i] = 0; e->prof.launches[i] = 0; }
+    for (int i = 0; i < PC_COUNT; ++i) { e->prof.ms[i] = 0; e->prof.launches[i] = 0; e->prof.ms_s[i] = 0; e->prof.launches_s[i] = 0; }
+    e->prof.rounds_seen = e->prof.rounds_timed = 0;
     e->sims = e->evals = e->ply_games = e->finished = 0;
     e->peak_nodes = e->peak_tables = 0;
     hipMemset(e->d_evals, 0, 16);
@@ -1205,7 +1208,9 @@ extern "C" int omok_reset_stats(omok_engine* e) {
 
 extern "C" int omok_set_profiling(omok_engine* e, int32_t enabled) {
     if (!e) return OMOK_ERR_INVALID;
-    if (!enabled) e->prof.resolve();
+    if (enabled < 0) return OMOK_ERR_INVALID;
+    e->prof.resolve();
     e->prof.enabled = enabled != 0;
+    e->prof.every = enabled > 1 ? enabled : 1;
     return OMOK_OK;
 }

@@ -93,7 +93,7 @@ class Trainer:
                 x, _, _ = T.decode_records(records[: self.precision_rows], self.n)
                 chk = precision.measure(self.phase.net.tensors(), self.n, x.reshape(x.shape[0], -1).cpu().numpy(), device=self.local_rank,
                                         batch_k=p.evaluate_batch_size)
-                rounds = precision.measure_search_rounds(self.phase.net.tensors(), self.n, games=16, batch_k=p.evaluate_batch_size, rounds=4, plies=2,
+                rounds = precision.measure_search_rounds(self.phase.net.tensors(), self.n, games=max(16, 6144 // p.evaluate_batch_size + 1), batch_k=p.evaluate_batch_size, rounds=3, plies=1,
                                                          device=self.local_rank, seed=self.iteration)
                 chk["search_rounds"] = rounds
                 chk["max_dp"], chk["max_dv"] = max(chk["max_dp"], rounds["max_dp"]), max(chk["max_dv"], rounds["max_dv"])

@@ -269,40 +269,49 @@ def test_net_precision_after_training_steps(n):
 
 
 # ---- self-play: tree arithmetic bit-exact ---------------------------------------------------------
-def test_search_round_outputs_on_the_sibling_path():
-    """The p / v a SEARCH ROUND produces at N = 15 (sibling path: base row + window difference rows) against the fp32
-    kernels and against the plain path (evaluate_pv) of the same engine, on the very request rows of the rounds."""
-    n, games, k, count = 15, 40, 16, 96
+@pytest.mark.parametrize("games,path", [(40, "copy"), (448, "difference")])
+def test_search_round_outputs_on_the_sibling_path(games, path):
+    """The p / v a SEARCH ROUND produces at N = 15 against the fp32 kernels and against the row-by-row path (evaluate_pv) of the same
+    engine, on the very request rows of the rounds.  Rounds of >= 6144 rows take the difference path (base row + window difference
+    rows, DESIGN 3.3: different rounding, inside the contract), smaller rounds the copy path (bit-identical to row-by-row)."""
+    n, k, count = 15, 16, 96
     tensors = oa.weights.init_random(n, seed=3)
-    eng = oa.Engine(board_size=n, games=games, max_nodes=1024, max_tables=256, max_batch_k=k, seed=11, net_mode=B.NET_F16X3)
+    eng = oa.Engine(board_size=n, games=games, max_nodes=512, max_tables=128, max_batch_k=k, seed=11, net_mode=B.NET_F16X3)
     eng.load_weights(tensors)
     ref = oa.Engine(board_size=n, games=games, max_nodes=8, max_tables=4, max_batch_k=k, net_mode=B.NET_F32)
     ref.load_weights(tensors)
     sp = oa.SelfPlay(eng)
     sp.reset()
-    xs, ps, vs = [], [], []
-    for ply in range(4):
+    rows, dp, dv, dpp, dvp, differing = 0, 0.0, 0.0, 0.0, 0.0, 0
+    for ply in range(3 if path == "difference" else 4):
         for rnd in range(count // k):
             nreq = sp.round_generate(rnd, k, 0.25, 0.03)
             x = sp.round_inputs().copy()
             p, v = sp.round_eval()
             assert len(x) == nreq and len(p) == nreq
-            xs.append(x); ps.append(np.array(p).reshape(nreq, -1)); vs.append(np.array(v).reshape(-1))
+            p, v = np.array(p).reshape(nreq, -1).copy(), np.array(v).reshape(-1).copy()
             sp.round_scatter()
+            if rnd == 0:
+                continue  # (the first round of a ply has one request per tree: no siblings)
+            assert nreq == games * k
+            p32, v32 = ref.evaluate_pv(x)
+            pp, vp = eng.evaluate_pv(x)
+            p32, pp = p32.reshape(nreq, -1), pp.reshape(nreq, -1)
+            dp, dv = max(dp, np.abs(p - p32).max()), max(dv, np.abs(v - v32.reshape(-1)).max())
+            dpp, dvp = max(dpp, np.abs(p - pp).max()), max(dvp, np.abs(v - vp.reshape(-1)).max())
+            differing += int((p.view(np.uint32) != pp.view(np.uint32)).any(axis=1).sum())
+            rows += nreq
         sp.sample_actions(1.0, 30)
         sp.mirror_generate()
         sp.mirror_eval()
         sp.mirror_apply()
-    x, p, v = np.concatenate(xs), np.concatenate(ps), np.concatenate(vs)
-    assert len(x) > 4 * games * (count - k)  # (rounds after the first are full: K requests per tree)
-    p32, v32 = ref.evaluate_pv(x)
-    pp, vp = eng.evaluate_pv(x)
-    p32, pp = p32.reshape(len(x), -1), pp.reshape(len(x), -1)
-    dp, dv = np.abs(p - p32).max(), np.abs(v - v32.reshape(-1)).max()
-    dpp, dvp = np.abs(p - pp).max(), np.abs(v - vp.reshape(-1)).max()
-    print(f"sibling rounds, {len(x)} rows: vs fp32 max|dp| {dp:.2e} max|dv| {dv:.2e}; vs plain path max|dp| {dpp:.2e} max|dv| {dvp:.2e}")
+    print(f"{path} path, {rows} rows: vs fp32 max|dp| {dp:.2e} max|dv| {dv:.2e}; vs row-by-row max|dp| {dpp:.2e} max|dv| {dvp:.2e}, {differing} rows differ")
     assert dp < 1e-3 and dv < 1e-3
-    assert dpp < 5e-4 and dvp < 5e-4
+    if path == "copy":
+        assert differing == 0 and dvp == 0.0
+    else:
+        assert differing > rows // 2     # (the path under test really ran)
+        assert dpp < 5e-4 and dvp < 5e-4
     eng.close()
     ref.close()
 
