@@ -58,6 +58,8 @@ def parse(argv=None):
     ap.add_argument("--gather", action="store_true", help="RCCL all-gather-v of replay tuples at episode end")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=20, help="training steps timed after the episode (0 = skip; batch 128)")
+    ap.add_argument("--slots-multiple", type=int, default=3, help="extra leg (outside the timed region): slots mode, this many x games played on the "
+                    "engine's game slots with finished slots restarted (omok_selfplay_run_slots); 0 = skip")
     ap.add_argument("--profile-every", type=int, default=8, help="HIP-event timing of the kernel categories on 1 search round in N (sums scaled); "
                     "an event record idles the queue ~5 us, 6 category boundaries per round")
     ap.add_argument("--precision-rows", type=int, default=4096, help="rows of the in-run precision check (0 = skip)")
@@ -466,6 +468,30 @@ def main():
                 del buf
             except Exception as ex:  # an extra line of the report must never cost the bench line itself
                 out["replay_postprocess_error"] = repr(ex)
+            extras = True
+        if args.slots_multiple > 0 and args.max_plies == 0 and hasattr(sp, "run_slots") and room(20 + 1.2 * args.slots_multiple * dt / max(args.steps, 1)):
+            # Slots mode: the same games (by index) as an episode of slots_multiple x games, but a slot whose game is over takes the next
+            # index instead of idling until the episode's longest game ends (the last 40 % of an episode's rounds hold < 10 % of its rows).  (After the post-processing leg: it resets the engine.)
+            try:
+                total = args.slots_multiple * games
+                cap = int(total * min(hw, 1.25 * mean_plies + 8))
+                buf = torch.empty(cap * rec, dtype=torch.uint8, device=device)
+                sp.set_episode(args.warmup + args.steps + 1)
+                sp.reset()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sst, nrec, _, ln, _ = sp.run_slots(total, args.sims, k, buf.data_ptr(), cap, 0.25, 0.03, 1.0, 30)
+                torch.cuda.synchronize()
+                dt_s = time.perf_counter() - t1
+                out["slots_mode"] = {"games": total, "slots": games, "seconds": dt_s, "games_per_s": total / dt_s, "records_packed": nrec,
+                                     "mean_plies_per_game": float(ln.mean()),
+                                     "note": "omok_selfplay_run_slots: finished slots restart with the next game index (RNG keyed by game index and the "
+                                             "game's own ply: per-game results are those of one episode of all the games, tests/test_gpu_slots.py); "
+                                             "includes packing every finished game's transitions; one call, wall time, rank 0; NOT `value` "
+                                             "(the reference's schedule is the episode: its batch shrinks as games end)"}
+                del buf
+            except Exception as ex:
+                out["slots_mode"] = {"error": repr(ex)}
             extras = True
     if args.cpu_seconds > 0 and world == 1:
         share = min(args.cpu_seconds, args.budget_seconds - elapsed() - 10.0)

@@ -157,6 +157,19 @@ int omok_set_actions(omok_engine* e, const int32_t* actions);
 int omok_selfplay_run(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha,
                       float temperature, int32_t threshold, int32_t max_plies, double* stats);
 
+/* Slots mode ("continuous refill"): plays `total_games` >= games games on the engine's `games` slots; a slot whose game is over takes the
+   next game index instead of idling until the episode's longest game ends.  Per-game results are those of an episode of total_games
+   games (omok_selfplay_run on an engine with games = total_games): a game's RNG streams are keyed by game_offset + index and its own
+   ply, trees are independent (bit for bit with board_size 9 or OMOK_NET_F16X3_ROWS / OMOK_NET_F32; in the default net mode at
+   board_size 15 a row's p / v carry ~5e-5 of rounding that depends on the path a round takes, see OMOK_NET_F16X3_ROWS).  Call after
+   omok_selfplay_reset.  Finished games' transitions are appended to records_dev (device memory, cap_records records of
+   omok_replay_record_bytes, the omok_replay_pack_dev format) in completion order; per game index: game_offsets[i] = first record,
+   game_lengths[i] = records, game_status[i] = OMOK_STATUS_* (arrays of total_games, may be NULL); *n_records = records written.
+   Extends src/trainer.rs:95-205 (the reference removes finished games from its agent list and lets the batch shrink). */
+int omok_selfplay_run_slots(omok_engine* e, int32_t total_games, int32_t count, int32_t batch_size, float epsilon, float alpha,
+                            float temperature, int32_t threshold, void* records_dev, int64_t cap_records, int64_t* game_offsets,
+                            int32_t* game_lengths, int32_t* game_status, int64_t* n_records, double* stats);
+
 /* step-wise form of execute() for parity tests: generate -> (eval | inject) -> scatter */
 int omok_round_generate(omok_engine* e, int32_t round, int32_t batch_size, float epsilon, float alpha,
                         int32_t* n_requests);

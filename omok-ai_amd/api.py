@@ -242,6 +242,21 @@ class SelfPlay:
         self._chk(B.lib().omok_selfplay_run(self.h, count, batch_size, epsilon, alpha, temperature, threshold, max_plies, s))
         return dict(zip(B.STAT_NAMES, list(s)))
 
+    def run_slots(self, total_games, count, batch_size, records_ptr, cap_records, epsilon=0.25, alpha=0.03, temperature=1.0, threshold=30):
+        """Slots mode (omok_selfplay_run_slots): `total_games` games on the engine's slots, finished slots restarted with the next game
+        index.  `records_ptr` = device buffer of cap_records x replay_record_bytes (e.g. a torch uint8 tensor's data_ptr()).
+        Returns (stats, n_records, offsets[int64], lengths[int32], status[int32]) indexed by game index."""
+        s = (C.c_double * 16)()
+        off = np.zeros(total_games, dtype=np.int64)
+        ln = np.zeros(total_games, dtype=np.int32)
+        stt = np.zeros(total_games, dtype=np.int32)
+        n = C.c_int64()
+        self._chk(B.lib().omok_selfplay_run_slots(self.h, total_games, count, batch_size, epsilon, alpha, temperature, threshold,
+                                                  C.c_void_p(records_ptr), cap_records, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                  ln.ctypes.data_as(C.POINTER(C.c_int32)), stt.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                  C.byref(n), s))
+        return dict(zip(B.STAT_NAMES, list(s))), int(n.value), off, ln, stt
+
     # ---- step-wise (parity tests) -----------------------------------------------------------
     def round_generate(self, rnd, batch_size, epsilon=0.25, alpha=0.03):
         n = C.c_int32()

@@ -21,7 +21,7 @@ SYMBOLS = [
     "omok_create", "omok_destroy", "omok_last_error", "omok_net_num_tensors", "omok_net_tensor_size", "omok_net_load",
     "omok_net_commit", "omok_net_load_file", "omok_net_save_file", "omok_evaluate_pv", "omok_evaluate_logits", "omok_env_play", "omok_env_place_stone", "omok_encode_nn_input", "omok_selfplay_reset", "omok_set_episode", "omok_execute", "omok_execute_shared",
     "omok_compute_policy", "omok_play_actions", "omok_set_actions", "omok_root_children",
-    "omok_sample_actions", "omok_advance", "omok_selfplay_run", "omok_round_generate", "omok_round_inputs",
+    "omok_sample_actions", "omok_advance", "omok_selfplay_run", "omok_selfplay_run_slots", "omok_round_generate", "omok_round_inputs",
     "omok_round_eval", "omok_round_outputs", "omok_round_inject", "omok_round_scatter", "omok_mirror_generate",
     "omok_mirror_inputs", "omok_mirror_eval", "omok_mirror_outputs", "omok_mirror_inject", "omok_mirror_apply",
     "omok_alive_count", "omok_current_ply", "omok_game_info", "omok_tree_dump", "omok_tree_root", "omok_replay_game",
@@ -87,6 +87,8 @@ def lib():
     L.omok_advance.argtypes = [H]
     L.omok_selfplay_run.argtypes = [H, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                     C.POINTER(C.c_double)]
+    L.omok_selfplay_run_slots.argtypes = [H, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_int64,
+                                          C.POINTER(C.c_int64), ip, ip, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.omok_round_generate.argtypes = [H, C.c_int32, C.c_int32, C.c_float, C.c_float, ip]
     L.omok_round_inputs.argtypes = [H, fp]
     L.omok_round_eval.argtypes = [H]

@@ -59,12 +59,13 @@ struct GameState {
     uint8_t alive;
     uint8_t status;
     uint8_t external; // the pending move (last_action) was supplied by the caller (omok_play_actions), not sampled
-    uint8_t pad1;
+    uint8_t harvested; // slots mode: the finished game's records have been packed out, the slot may take a new game
     int32_t plies;       // moves played
     int32_t last_action;
     int32_t mirror_idx;
     int32_t rp_len;      // transitions recorded = moves SAMPLED so far (turn_counts[index], src/trainer.rs:85,139,148)
-    int32_t pad2[3];
+    int32_t gid;         // game index of the slot's game (+ cfg.game_offset = the global id that keys its RNG streams); = the slot after a reset
+    int32_t pad2[2];
 };
 static_assert(sizeof(GameState) == 32, "GameState must be 32 bytes");
 
@@ -102,6 +103,12 @@ struct RoundArgs {
 
 // ---- tree_kernels.hip launchers (all asynchronous on `st`) ---------------------------------
 void launch_reset(int n, const Store& S, const float* root_policy_dev /*ROWP*/, hipStream_t st);
+// slots mode (omok_selfplay_run_slots): finished games are packed out (records appended at *out_count, per-game meta by game index) and their
+// slots restarted with the next game indices while any are left
+struct SlotMeta { long long offset; int32_t len; int32_t status; }; // per game index: first record, records, final GameStatus
+void launch_harvest(int n, const Store& S, uint8_t* mask_dev /*[G]*/, long long* slot_off_dev /*[G]*/, long long* out_count_dev, SlotMeta* meta_dev,
+                    uint8_t* dst_dev, long long cap_records, hipStream_t st);
+void launch_refill(int n, const Store& S, const float* root_policy_dev, int32_t* next_gid_dev, int total_games, int32_t* new_gid_dev /*[G]*/, hipStream_t st);
 void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st);
 void launch_scan(int n, const Store& S, int side, int K, hipStream_t st);
 // one tree searched by `waves` waves (MCTSExecutor::run): sh_req [waves][KMAX] u16, sh_cnt [2 * KMAX] u32 (counts | bases)

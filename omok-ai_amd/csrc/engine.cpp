@@ -742,6 +742,85 @@ extern "C" int omok_selfplay_run(omok_engine* e, int32_t count, int32_t batch_si
 }
 
 
+// Slots mode: the engine's `games` slots are kept full.  Same games, same results as an episode of `total_games` games (every game
+// is keyed by its index: RNG streams by cfg.game_offset + index and the game's own ply; trees are independent), but a slot whose game
+// is over takes the next index instead of idling until the longest game of the episode ends (the last 40 % of an episode's rounds
+// hold < 10 % of its rows).  Games start on even engine plies only (one `side` per ply: a slot may wait one ply), finished games'
+// transitions are packed out (k_replay_pack records) before their slot is reused.
+extern "C" int omok_selfplay_run_slots(omok_engine* e, int32_t total_games, int32_t count, int32_t batch_size, float epsilon, float alpha,
+                                       float temperature, int32_t threshold, void* records_dev, int64_t cap_records, int64_t* game_offsets,
+                                       int32_t* game_lengths, int32_t* game_status, int64_t* n_records, double* stats) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (need_net(e) || need_reset(e)) return OMOK_ERR_STATE;
+    if (check_exec_args(e, count, batch_size, epsilon, alpha)) return OMOK_ERR_INVALID;
+    if (!(temperature > 0.0f)) return fail(e, OMOK_ERR_INVALID, "temperature must be > 0");
+    const int G = e->cfg.games;
+    if (total_games < G) return fail(e, OMOK_ERR_INVALID, "total_games (%d) must be >= the engine's game slots (%d)", total_games, G);
+    if (!records_dev || cap_records < 1) return fail(e, OMOK_ERR_INVALID, "records buffer required (omok_replay_record_bytes per record)");
+    if (e->ply != 0) return fail(e, OMOK_ERR_STATE, "omok_selfplay_run_slots starts from a fresh omok_selfplay_reset (ply %d)", e->ply);
+    ENTER(e);
+    uint8_t* d_mask = nullptr;
+    long long *d_slot_off = nullptr, *d_out = nullptr;
+    int32_t *d_next = nullptr, *d_new = nullptr;
+    SlotMeta* d_meta = nullptr;
+    auto cleanup = [&]() { for (void* p : {(void*)d_mask, (void*)d_slot_off, (void*)d_out, (void*)d_next, (void*)d_new, (void*)d_meta}) if (p) hipFree(p); };
+    if (hipMalloc(&d_mask, G) != hipSuccess || hipMalloc(&d_slot_off, sizeof(long long) * G) != hipSuccess || hipMalloc(&d_out, 8) != hipSuccess ||
+        hipMalloc(&d_next, 4) != hipSuccess || hipMalloc(&d_new, sizeof(int32_t) * G) != hipSuccess ||
+        hipMalloc(&d_meta, sizeof(SlotMeta) * (size_t)total_games) != hipSuccess) {
+        cleanup();
+        return fail(e, OMOK_ERR_HIP, "slots mode: device allocation failed");
+    }
+    hipMemsetAsync(d_out, 0, 8, e->st);
+    hipMemsetAsync(d_meta, 0xFF, sizeof(SlotMeta) * (size_t)total_games, e->st);
+    hipMemcpyAsync(d_next, &G, 4, hipMemcpyHostToDevice, e->st); // the reset started games 0 .. G-1
+    uint32_t bits = 0, alive = 0;
+    if (read_status(e, &bits, &alive)) { cleanup(); return OMOK_ERR_HIP; }
+    int rc = OMOK_OK;
+    while (alive > 0) {
+        const int rounds = enqueue_execute(e, count, batch_size, epsilon, alpha, (int)alive);
+        enqueue_sample(e, temperature, threshold);
+        enqueue_mirror_and_advance(e, (int)alive);
+        e->sims += (double)rounds * batch_size * alive;
+        e->ply_games += alive;
+        e->ply += 1;
+        e->prof.begin(PC_PLY, e->st);
+        launch_harvest(e->n, e->S, d_mask, d_slot_off, d_out, d_meta, (uint8_t*)records_dev, cap_records, e->st);
+        if ((e->ply & 1) == 0) launch_refill(e->n, e->S, e->d_root_policy, d_next, total_games, d_new, e->st);
+        e->prof.end(e->st);
+        uint32_t after = 0;
+        if (read_status(e, &bits, &after)) { cleanup(); return OMOK_ERR_HIP; }
+        alive = after;
+        if (tree_error(e, bits)) { rc = bits & 1u ? OMOK_ERR_OVERFLOW : OMOK_ERR_ILLEGAL; break; }
+        if (alive == 0 && (e->ply & 1)) { // every slot is waiting for an even ply with games left to start: let the ply pass
+            int32_t next = 0;
+            hipMemcpy(&next, d_next, 4, hipMemcpyDeviceToHost);
+            if (next >= total_games) break;
+            e->ply += 1;
+            launch_refill(e->n, e->S, e->d_root_policy, d_next, total_games, d_new, e->st);
+            if (read_status(e, &bits, &alive)) { cleanup(); return OMOK_ERR_HIP; }
+        }
+    }
+    e->sampled = false;
+    long long out = 0;
+    hipMemcpy(&out, d_out, 8, hipMemcpyDeviceToHost);
+    if (n_records) *n_records = out;
+    if (rc == OMOK_OK && out > cap_records) rc = fail(e, OMOK_ERR_OVERFLOW, "slots mode: %lld records do not fit the buffer (%lld)", out, (long long)cap_records);
+    if (game_offsets || game_lengths || game_status) {
+        std::vector<SlotMeta> meta((size_t)total_games);
+        hipMemcpy(meta.data(), d_meta, sizeof(SlotMeta) * meta.size(), hipMemcpyDeviceToHost);
+        for (int i = 0; i < total_games; ++i) {
+            if (game_offsets) game_offsets[i] = meta[i].offset;
+            if (game_lengths) game_lengths[i] = meta[i].len;
+            if (game_status) game_status[i] = meta[i].status;
+        }
+    }
+    e->finished += (double)total_games;
+    cleanup();
+    if (rc != OMOK_OK) return rc;
+    if (stats) return omok_get_stats(e, stats);
+    return OMOK_OK;
+}
+
 extern "C" int omok_set_episode(omok_engine* e, uint64_t episode) {
     if (!e) return OMOK_ERR_INVALID;
     e->episode = episode;

@@ -490,12 +490,16 @@ __global__ __launch_bounds__(64) void k_round(Store S, RoundArgs A) {
     using G = Geo<N>;
     __shared__ float s_row[G::ROWP];
     const int g = blockIdx.x;
-    if (!S.gs[g].alive) return;
+    const GameState gs0 = S.gs[g];
+    if (!gs0.alive) return;
     const int t = A.side * S.games + g;
     const Tree<N> T(S, t);
     const TreeState ts = *T.ts;
     Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
-    const uint32_t tree_global = (uint32_t)((A.game_offset + g) * 2 + A.side);
+    // RNG streams are keyed by the GAME (its global id and its own ply), not by the slot or the engine's ply counter: in an episode the
+    // two coincide; in slots mode a slot's later games have their own ids and start their plies at 0
+    A.ply = gs0.plies;
+    const uint32_t tree_global = (uint32_t)((A.game_offset + gs0.gid) * 2 + A.side);
     if (A.round == 0) apply_noise<N>(T, A, tree_global, s_row);
     for (int i = 0; i < A.K; ++i) run_sim<N>(S, T, R, A, (uint32_t)(A.round * A.K + i), tree_global);
     if (LANE == 0) {
@@ -863,7 +867,111 @@ __global__ __launch_bounds__(64) void k_reset(Store S, const float* __restrict__
         *T.ts = s;
         if (t < S.games) {
             GameState gs{};
-            gs.alive = 1; gs.status = ST_IN_PROGRESS; gs.last_action = -1; gs.mirror_idx = -1;
+            gs.alive = 1; gs.status = ST_IN_PROGRESS; gs.last_action = -1; gs.mirror_idx = -1; gs.gid = t;
+            S.gs[t] = gs;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// slots mode: harvest finished games, restart their slots (omok_selfplay_run_slots)
+// ---------------------------------------------------------------------------------------------
+// one workgroup: slots whose game is over and not yet harvested, in slot order -> record offsets (appended at *out_count), per-game meta
+template <int N>
+__global__ __launch_bounds__(1024) void k_harvest_scan(Store S, uint8_t* __restrict__ mask, long long* __restrict__ slot_off, long long* __restrict__ out_count,
+                                                       SlotMeta* __restrict__ meta) {
+    __shared__ int s_part[1024];
+    __shared__ long long s_base;
+    const int tid = threadIdx.x, per = (S.games + 1023) / 1024;
+    int mine = 0;
+    for (int i = 0; i < per; ++i) {
+        const int g = tid * per + i;
+        if (g < S.games) {
+            const GameState gs = S.gs[g];
+            if (!gs.alive && !gs.harvested) mine += gs.rp_len < Geo<N>::HW ? gs.rp_len : Geo<N>::HW;
+        }
+    }
+    s_part[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int i = 0; i < 1024; ++i) { const int v = s_part[i]; s_part[i] = acc; acc += v; }
+        s_base = *out_count;
+        *out_count = s_base + acc;
+    }
+    __syncthreads();
+    long long off = s_base + s_part[tid];
+    for (int i = 0; i < per; ++i) {
+        const int g = tid * per + i;
+        if (g >= S.games) break;
+        const GameState gs = S.gs[g];
+        const bool take = !gs.alive && !gs.harvested;
+        mask[g] = take ? 1 : 0;
+        if (take) {
+            const int len = gs.rp_len < Geo<N>::HW ? gs.rp_len : Geo<N>::HW;
+            slot_off[g] = off;
+            meta[gs.gid] = SlotMeta{off, len, (int32_t)gs.status};
+            off += len;
+            S.gs[g].harvested = 1;
+        }
+    }
+}
+
+// one workgroup: harvested slots in slot order take the next game indices while any are left (deterministic: a prefix sum, no atomics)
+__global__ __launch_bounds__(1024) void k_refill_assign(Store S, int32_t* __restrict__ next_gid, int total_games, int32_t* __restrict__ new_gid) {
+    __shared__ int s_part[1024];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, per = (S.games + 1023) / 1024;
+    int mine = 0;
+    for (int i = 0; i < per; ++i) {
+        const int g = tid * per + i;
+        if (g < S.games && !S.gs[g].alive && S.gs[g].harvested) mine += 1;
+    }
+    s_part[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int i = 0; i < 1024; ++i) { const int v = s_part[i]; s_part[i] = acc; acc += v; }
+        s_base = *next_gid;
+        const int left = total_games - s_base;
+        *next_gid = s_base + (acc < left ? acc : (left > 0 ? left : 0));
+    }
+    __syncthreads();
+    int id = s_base + s_part[tid];
+    for (int i = 0; i < per; ++i) {
+        const int g = tid * per + i;
+        if (g >= S.games) break;
+        int v = -1;
+        if (!S.gs[g].alive && S.gs[g].harvested) { v = id < total_games ? id : -1; id += 1; }
+        new_gid[g] = v;
+    }
+}
+
+// Agent::new for both trees of the slots that take a new game
+template <int N>
+__global__ __launch_bounds__(64) void k_refill_reset(Store S, const float* __restrict__ root_policy, const int32_t* __restrict__ new_gid) {
+    using G = Geo<N>;
+    const int t = blockIdx.x, g = t % S.games;
+    const int gid = new_gid[g];
+    if (gid < 0) return;
+    const int lane = LANE;
+    const Tree<N> T(S, t);
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) {
+        const int a = j * 64 + lane;
+        T.pol[a] = a < G::HW ? root_policy[a] : 0.0f;
+    }
+    if (lane < 2 * G::NW) T.board[lane] = 0ULL;
+    if (lane == 0) {
+        NodeHdr h;
+        h.parent = NONE16; h.table = NONE16; h.legal = (uint16_t)G::HW; h.nch = 0;
+        h.action = NONE8; h.status = ST_IN_PROGRESS; h.turn = 0; h.has_policy = 1; h.pad = 0;
+        T.hdr[0] = h;
+        TreeState s{1u, 0u, 0u, 0.0f, 0u, 0u, 0u, 0u};
+        *T.ts = s;
+        if (t < S.games) {
+            GameState gs{};
+            gs.alive = 1; gs.status = ST_IN_PROGRESS; gs.last_action = -1; gs.mirror_idx = -1; gs.gid = gid;
             S.gs[t] = gs;
         }
     }
@@ -929,7 +1037,7 @@ __global__ __launch_bounds__(64) void k_sample(Store S, int side, int ply, float
         __syncthreads();
         if (lane == 0) {
             const float total = seq_sum(s_row, G::HW);
-            const U4 o = philox(seed, 0u, (uint32_t)ply, (uint32_t)((game_offset + g) * 2 + side), RNG_SAMPLE);
+            const U4 o = philox(seed, 0u, (uint32_t)S.gs[g].plies, (uint32_t)((game_offset + S.gs[g].gid) * 2 + side), RNG_SAMPLE); // (the game's own ply and id)
             const float u = (float)(o.x >> 8) * 5.9604644775390625e-8f;
             const float target = u * total;
             float cum = 0.0f;
@@ -1438,12 +1546,14 @@ __global__ __launch_bounds__(256) void k_encode_boards(const uint8_t* __restrict
 // replay tuples packed for an RCCL gather: board u8[HW], turn u8, pad (zero) to 4, pi f32[HW], z f32; games in id order
 // (offsets = exclusive scan of the transition counts), transitions in play order: the packed buffer is deterministic
 template <int N>
-__global__ __launch_bounds__(64) void k_replay_pack(Store S, const long long* __restrict__ offsets, uint8_t* __restrict__ dst, long long cap) {
+__global__ __launch_bounds__(64) void k_replay_pack(Store S, const long long* __restrict__ offsets, uint8_t* __restrict__ dst, long long cap,
+                                                    const uint8_t* __restrict__ mask) {
     using G = Geo<N>;
     constexpr int NW = G::NW, ROWP = G::ROWP;
     constexpr int BRD = (G::HW + 1 + 3) / 4 * 4, REC = BRD + 4 * G::HW + 4;
     const int g = blockIdx.x;
     const int lane = LANE;
+    if (mask && !mask[g]) return; // (harvest: only the slots k_harvest_scan picked)
     const int plies = S.gs[g].rp_len < G::HW ? S.gs[g].rp_len : G::HW;
     const long long base = offsets[g];
     for (int p = 0; p < plies; ++p) {
@@ -1627,8 +1737,17 @@ void launch_replay_augment(int n, const Store& S, const long long* offsets, int 
                (k_replay_augment<15><<<dim3(225, game_count), 64, 0, st>>>(S, offsets, game_first, base_sub, dst, cap)));
 }
 void launch_replay_pack(int n, const Store& S, const long long* offsets, uint8_t* dst, long long cap, hipStream_t st) {
-    DISPATCH_N(n, (k_replay_pack<9><<<S.games, 64, 0, st>>>(S, offsets, dst, cap)),
-               (k_replay_pack<15><<<S.games, 64, 0, st>>>(S, offsets, dst, cap)));
+    DISPATCH_N(n, (k_replay_pack<9><<<S.games, 64, 0, st>>>(S, offsets, dst, cap, nullptr)),
+               (k_replay_pack<15><<<S.games, 64, 0, st>>>(S, offsets, dst, cap, nullptr)));
+}
+void launch_harvest(int n, const Store& S, uint8_t* mask, long long* slot_off, long long* out_count, SlotMeta* meta, uint8_t* dst, long long cap,
+                    hipStream_t st) {
+    DISPATCH_N(n, (k_harvest_scan<9><<<1, 1024, 0, st>>>(S, mask, slot_off, out_count, meta)), (k_harvest_scan<15><<<1, 1024, 0, st>>>(S, mask, slot_off, out_count, meta)));
+    DISPATCH_N(n, (k_replay_pack<9><<<S.games, 64, 0, st>>>(S, slot_off, dst, cap, mask)), (k_replay_pack<15><<<S.games, 64, 0, st>>>(S, slot_off, dst, cap, mask)));
+}
+void launch_refill(int n, const Store& S, const float* rp, int32_t* next_gid, int total_games, int32_t* new_gid, hipStream_t st) {
+    k_refill_assign<<<1, 1024, 0, st>>>(S, next_gid, total_games, new_gid);
+    DISPATCH_N(n, (k_refill_reset<9><<<2 * S.games, 64, 0, st>>>(S, rp, new_gid)), (k_refill_reset<15><<<2 * S.games, 64, 0, st>>>(S, rp, new_gid)));
 }
 
 } // namespace omok
