@@ -702,25 +702,32 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
 }
 
 // ===============================================================================================
-// OMOK_NET_F16X3: trunk for SIBLING requests (N = 15): k_group, k_trunk<.., BASE>, k_sib_children
+// OMOK_NET_F16X3: SIBLING requests of a search round (N = 15): k_group, k_bin_prefix, k_trunk<.., BASE>, k_sib_children, fc0 window tiles
 // ===============================================================================================
 // The K requests a tree contributes to a round are, almost always, children of ONE leaf (tree_kernels.hip: between two backups
-// the PUCT descent reaches the same leaf, and a round has no backups except terminal ones; measured: 99.6 % of the request rows
-// of configs[1] sit in runs of >= 4 siblings, 90 % of the runs are full K = 16).  Siblings are positions that differ in one
-// stone, and the trunk is local: 1x1 convolutions plus three 3x3 depthwise stages.  A child's trunk activations therefore equal
-// those of a shared BASE position (the parent's board with the child's side to move) everywhere outside the 7x7 window around
-// the pixel its stone changes (the flat encoder.rs layout puts the stone's float into pixel (2a + 1) / 3).  Per round:
+// the PUCT descent reaches the same leaf, and a round has no backups except terminal ones; measured over a configs[1] episode:
+// runs of 14.4-15.8 siblings at every ply, < 0.2 % of the rows outside runs).  Siblings are positions that differ in one stone,
+// and the trunk is local: 1x1 convolutions plus three 3x3 depthwise stages.  A child's trunk activations therefore equal those
+// of a shared BASE position (the parent's board with the child's side to move) everywhere outside the 7x7 window around the
+// pixel its stone changes (the flat encoder.rs layout puts the stone's float into pixel (2a + 1) / 3).  Per round:
 //   k_group          runs of siblings in the request list (first row, length >= SIB_MIN), the rows inside runs, the other rows
-//   k_trunk<BASE>    the whole trunk once per run for the base position; its fc0 operand row is stored into EVERY child row of
-//                    the run (the rows fc0 reads must exist: 86 KB per request, the HBM-write floor of this path), the depthwise
-//                    inputs (h grids) of its three blocks go to a scratch
+//   k_trunk<BASE>    the whole trunk once per run for the base position; the depthwise inputs (h grids) of its three blocks go
+//                    to a scratch; its fc0 operand row goes
+//                      COPY path        into EVERY child row of the run (the rows a dense fc0 reads must exist);
+//                      DIFFERENCE path  once, to full row `run`
 //   k_sib_children   per child ONE 7x7 window (49 pixels = two 32-pixel MFMA tiles = a wave pair; four children per workgroup
 //                    pass): conv_in and the three blocks on the window only, the depthwise halo ring taken from the base's h
-//                    grid of the same block; the window's 49 pixel entries overwrite the base's in the child's row
-//   k_trunk<rows>    the rows outside runs, as before
-// Every pixel goes through the same operations in the same order as in k_trunk (MFMA columns are independent, the depthwise taps
-// accumulate in (dy, dx) order, operand-row entries are per pixel), so the rows are BIT-IDENTICAL to a full evaluation; the MFMA
-// work per child falls from 8 tiles to 2 + 8 / (run length).
+//                    grid of the same block; the window's 49 pixel entries
+//                      COPY path        overwrite the base's in the child's row -> dense fc0 as for any other rows;
+//                      DIFFERENCE path  minus the base's entries (as fc0 sees them) -> the slot's difference row; fc0 is linear:
+//                                       fc0(child) = fc0(full row of the run) + W[window pixels] * difference row, 98 of the 450
+//                                       super-steps per child (launch_fc0_delta: k_fc0_mx<EPI_PARTIAL> on the full rows, then
+//                                       k_fc0_mx<.., WIN> on tiles of slots that share a window)
+//   k_trunk<rows>    the rows outside runs, as before (DIFFERENCE path: into full rows behind the runs')
+// COPY path: every pixel goes through the same operations in the same order as in k_trunk (MFMA columns are independent, the
+// depthwise taps accumulate in (dy, dx) order, operand-row entries are per pixel), so the rows are BIT-IDENTICAL to a full
+// evaluation.  DIFFERENCE path: one more rounding (the quantisation of the difference), |dp| < 1e-4 measured; rounds of fewer than
+// 6144 rows stay on the copy path (forward_f16x3).  DESIGN.md 3.3.
 constexpr int SIB_MIN = 3;                       // runs shorter than this go to k_trunk (a base pass would not pay)
 constexpr int SIB_WIN = 7, SIB_GW = SIB_WIN + 2; // window side, child grid side (window + halo ring)
 constexpr int SIB_CGRID_ROWS = SIB_GW * SIB_GW + 1;
