@@ -225,7 +225,24 @@ struct Regs { // wave-uniform running state of a tree
     int memo_node = -1;
     uint32_t memo_n = 0;
     unsigned long long memo_bytes = 0;
+    bool dirty = false; // this wave has stores in flight that a later load of its own may depend on (see LeafCache)
 };
+
+// The memoised leaf in registers.  Consecutive simulations of a round expand the SAME leaf (see memo_node): after the first one the wave
+// knows the leaf's header, board and which of its cells are still untried -- it wrote the changes itself -- so the following
+// simulations need no load at all, and without a load of its own stores the wave needs no store -> load fence per simulation either
+// (each was a round trip to L2).  Any path that does read the tree (descent, backup, a new leaf) first waits for the stores in flight
+// (Regs::dirty).  The arithmetic and its order are unchanged.
+template <int N>
+struct LeafCache {
+    int node = -1;
+    NodeHdr h;
+    uint64_t bb[2 * Geo<N>::NW];
+    unsigned long long cand[Geo<N>::IT];
+};
+__device__ inline void fence_own_stores(Regs& R) {
+    if (R.dirty) { __syncthreads(); R.dirty = false; }
+}
 
 // environment/src/lib.rs:104-166 on bitboards, wave-cooperative (all 64 lanes must call).
 // `own` already contains the new stone.  Returns 1 if any of the 4 lines is EXACTLY five.
@@ -294,8 +311,8 @@ __device__ inline void backup(const Tree<N>& T, Regs& R, int x, float v) {
 // Adds a child under `parent` (hp = its header as currently stored).  Returns the node index,
 // or -1 on arena overflow.  Board words `bb` (black NW, white NW) are the child's board.
 template <int N>
-__device__ inline int add_child(const Store& S, const Tree<N>& T, Regs& R, int parent, const NodeHdr& hp, int action,
-                                const uint64_t* bb, int status, int turn, int has_policy) {
+__device__ inline int add_child(const Store& S, const Tree<N>& T, Regs& R, int parent, NodeHdr& hp, int action,
+                                const uint64_t* bb, int status, int turn, int has_policy) { // (hp is updated like the stored header: table, nch)
     using G = Geo<N>;
     const int lane = LANE;
     if (R.n_nodes >= (uint32_t)S.cap_nodes) { R.error |= 1u; return -1; }
@@ -335,6 +352,8 @@ __device__ inline int add_child(const Store& S, const Tree<N>& T, Regs& R, int p
         T.board[(size_t)idx * (2 * G::NW) + lane] = w;
     }
     R.bytes += 24 + 8 * 2 * G::NW;
+    hp.table = (uint16_t)tab;
+    hp.nch = (uint16_t)(hp.nch + 1);
     return idx;
 }
 
@@ -385,7 +404,7 @@ __device__ void apply_noise(const Tree<N>& T, const RoundArgs& A, uint32_t tree_
 }
 
 template <int N>
-__device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, const RoundArgs& A, uint32_t sim_index,
+__device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>& C, const RoundArgs& A, uint32_t sim_index,
                         uint32_t tree_global) {
     using G = Geo<N>;
     constexpr int ROWP = G::ROWP, NW = G::NW;
@@ -393,12 +412,16 @@ __device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, const RoundAr
     int node = 0;
     uint32_t node_n = R.root_n;
     unsigned long long path_bytes = 0;
-    if (R.memo_node >= 0) { // resume at the remembered leaf (its header is re-read: the last expansion changed nch / table)
+    if (R.memo_node >= 0) { // resume at the remembered leaf
         node = R.memo_node;
         node_n = R.memo_n;
         path_bytes = R.memo_bytes;
-    }
-    NodeHdr h = T.hdr[node];
+    } else C.node = -1;
+    const bool cached = C.node == node;
+    NodeHdr h;
+    if (cached) h = C.h;
+    else { fence_own_stores(R); h = T.hdr[node]; }
+    if (h.nch == h.legal && h.nch != 0) { fence_own_stores(R); C.node = -1; } // the descent reads the tables this wave has been writing
     // ---- select_leaf (node.rs:43-58) with the PUCT selector (pme.rs:81-90) ----
     while (h.nch == h.legal && h.nch != 0) {
         const uint32_t pn = node_n > 1u ? node_n : 1u;
@@ -435,24 +458,37 @@ __device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, const RoundAr
     R.memo_bytes = path_bytes;
     // ---- terminal leaf (pme.rs:92-97) ----
     if (h.status != ST_IN_PROGRESS) {
+        fence_own_stores(R);
         backup<N>(T, R, node, h.status >= ST_BLACK_WIN ? 1.0f : 0.0f);
         R.memo_node = -1; // n / w changed along the path
+        C.node = -1;
         __syncthreads();
         return;
     }
     // ---- random untried legal action (pme.rs:101-125) ----
     uint64_t bb[2 * NW];
-#pragma unroll
-    for (int i = 0; i < 2 * NW; ++i) bb[i] = T.board[(size_t)node * (2 * NW) + i];
     unsigned long long cand[G::IT];
     int total = 0;
+    if (C.node == node) { // (still valid: the descent above did not move)
 #pragma unroll
-    for (int j = 0; j < G::IT; ++j) {
-        const int a = j * 64 + lane;
-        bool c = a < G::HW && !(((bb[j] | bb[NW + j]) >> lane) & 1ULL);
-        if (c && h.table != NONE16) c = T.corder[(size_t)h.table * ROWP + a] == NONE8;
-        cand[j] = __ballot(c);
-        total += __popcll(cand[j]);
+        for (int i = 0; i < 2 * NW; ++i) bb[i] = C.bb[i];
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) { cand[j] = C.cand[j]; total += __popcll(cand[j]); }
+    } else {
+        fence_own_stores(R);
+#pragma unroll
+        for (int i = 0; i < 2 * NW; ++i) bb[i] = T.board[(size_t)node * (2 * NW) + i];
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const int a = j * 64 + lane;
+            bool c = a < G::HW && !(((bb[j] | bb[NW + j]) >> lane) & 1ULL);
+            if (c && h.table != NONE16) c = T.corder[(size_t)h.table * ROWP + a] == NONE8;
+            cand[j] = __ballot(c);
+            total += __popcll(cand[j]);
+        }
+        C.node = node;
+#pragma unroll
+        for (int i = 0; i < 2 * NW; ++i) C.bb[i] = bb[i];
     }
     R.bytes += 2 * (G::HW / 8);
     if (total == 0) return; // "There's no action for now": the simulation is consumed
@@ -472,17 +508,23 @@ __device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, const RoundAr
     const int status = place_and_status<N>(bb, h.turn, h.legal, action);
     // ---- expand (node.rs:61-81); the placeholder policy of pme.rs:140-156 is implicit ----
     const int child = add_child<N>(S, T, R, node, h, action, bb, status, 1 - h.turn, 0);
-    if (child < 0) return;
-    __syncthreads();
+    if (child < 0) { C.node = -1; return; }
+    R.dirty = true;
+    // the leaf as it is now: one more child, the cell no longer untried
+    C.h = h;
+#pragma unroll
+    for (int j = 0; j < G::IT; ++j) C.cand[j] = cand[j] & ~((action >> 6) == j ? (1ULL << (action & 63)) : 0ULL);
     if (status != ST_IN_PROGRESS) { // pme.rs:177-181
+        fence_own_stores(R);
         backup<N>(T, R, child, status == ST_DRAW ? 0.0f : 1.0f);
         R.memo_node = -1;
+        C.node = -1;
+        __syncthreads();
     } else {
         if (lane == 0) T.req[R.n_req] = (uint16_t)child;
         R.n_req += 1u;
         R.bytes += 4 + (G::HW + 2);
     }
-    __syncthreads();
 }
 
 template <int N>
@@ -501,7 +543,8 @@ __global__ __launch_bounds__(64) void k_round(Store S, RoundArgs A) {
     A.ply = gs0.plies;
     const uint32_t tree_global = (uint32_t)((A.game_offset + gs0.gid) * 2 + A.side);
     if (A.round == 0) apply_noise<N>(T, A, tree_global, s_row);
-    for (int i = 0; i < A.K; ++i) run_sim<N>(S, T, R, A, (uint32_t)(A.round * A.K + i), tree_global);
+    LeafCache<N> C;
+    for (int i = 0; i < A.K; ++i) run_sim<N>(S, T, R, C, A, (uint32_t)(A.round * A.K + i), tree_global);
     if (LANE == 0) {
         TreeState o = ts;
         o.n_nodes = R.n_nodes; o.n_tables = R.n_tables; o.root_n = R.root_n; o.root_w = R.root_w;
@@ -1335,7 +1378,8 @@ __device__ void ensure_action_exists(const Store& S, const Tree<N>& T, int actio
         const TreeState ts = *T.ts;
         Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
         if (!get_bit<NW>(bb, action) && !get_bit<NW>(bb + NW, action)) (void)place_and_status<N>(bb, h0.turn, h0.legal, action);
-        const int idx = add_child<N>(S, T, R, 0, h0, action, bb, ST_IN_PROGRESS, 1 - h0.turn, 1);
+        NodeHdr h0m = h0;
+        const int idx = add_child<N>(S, T, R, 0, h0m, action, bb, ST_IN_PROGRESS, 1 - h0.turn, 1);
         if (idx >= 0) {
 #pragma unroll
             for (int j = 0; j < G::IT; ++j) {
