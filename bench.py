@@ -370,6 +370,10 @@ def main():
                                 "FETCH_SIZE x 2 + WRITE_SIZE; fc0 calibrated for its 64-B residual requests, the flat x2 figure beside it) x rows per launch",
                 "algorithmic_bytes_per_launch": alg_row * rows / launches + ({"k_trunk": 110e3, "k_fc0_mx": 128.0 * hw * 512 * 3}[kernel]),
                 "avg_launch_ms": k_ms[kernel] / launches, "rows_per_launch": rows / launches, "share_of_kernel_time": k_ms[kernel] / max(sum(k_ms.values()), 1e-9),
+                "mfma_busy_pmc": pmc.get(kernel + "_mfma_busy"), "valu_busy_pmc": pmc.get(kernel + "_valu_busy"), "lds_busy_pmc": pmc.get(kernel + "_lds_busy"),
+                "busy_pmc_unit": "fraction of the kernel group's cycles its SIMDs' matrix pipes / vector ALUs / the CUs' LDS were busy, from the committed "
+                                 "rocprofv3 --pmc passes of this workload (profiles/pmc_bytes.json): SQ_VALU_MFMA_BUSY_CYCLES, 4 x SQ_INSTS_VALU, SQ_LDS_IDX_ACTIVE "
+                                 "over GRBM_GUI_ACTIVE",
                 "note": note}
 
     note_trunk = ("conv_in + 3 bottleneck blocks (k_group + k_bin_prefix + k_trunk<BASE> + k_sib_children + k_trunk on the rows outside sibling runs), "
@@ -407,6 +411,7 @@ def main():
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (st["tree_bytes"] / tree_s / 1e9 / HBM_PEAK_GBS) if tree_s > 0 else 0.0,
                           "algorithmic_bytes_per_sim": st["tree_bytes"] / max(st["sims"], 1.0),
                           "traffic": tree_traffic * st["sims"] / max(st["round_launches"], 1.0) if tree_traffic else None,
+                          "hbm_gbs_pmc": tree_traffic * st["sims"] / tree_s / 1e9 if tree_traffic and tree_s > 0 else None,
                           "traffic_unit": "HBM bytes per round (k_round + k_scan + k_fill + k_scatter*): PMC bytes per simulation (profiles/) x simulations per round"},
         "rank0_kernel_ms": {kk: st[kk] for kk in ("ms_round", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply")},
         "rank0_kernel_ms_method": f"HIP events on the engine's stream around every kernel category of 1 search round in {max(1, args.profile_every)} "

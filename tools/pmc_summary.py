@@ -31,6 +31,13 @@ if a.json:
                       ("k_fc0_mx", ["k_fc0_mx", "k_splitk_finish", "k_facc_reduce", "k_win_finish"]),
                       ("tree", ["k_round", "k_scan", "k_fill", "k_scatter", "k_add_evals"])):
         f, w = tot(pre, "FETCH_SIZE") * 1024.0, tot(pre, "WRITE_SIZE") * 1024.0
+        # unit utilisation of the group over the profiled launches: MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x shader-engine-clock cycles);
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs, a launch keeps 1024 SIMDs: busy / (1024 x GRBM / 8)
+        grbm, mf = tot(pre, "GRBM_GUI_ACTIVE"), tot(pre, "SQ_VALU_MFMA_BUSY_CYCLES")
+        if grbm > 0 and name != "tree":
+            out[f"{name}_mfma_busy"] = mf / (1024.0 * grbm / 8.0)
+            out[f"{name}_valu_busy"] = 4.0 * tot(pre, "SQ_INSTS_VALU") / (1024.0 * grbm / 8.0)
+            out[f"{name}_lds_busy"] = tot(pre, "SQ_LDS_IDX_ACTIVE") / (256.0 * grbm / 8.0)
         denom = a.sims if name == "tree" else a.rows
         key = "tree_hbm_bytes_per_sim" if name == "tree" else f"{name}_hbm_bytes_per_row"
         if denom > 0 and (f > 0 or w > 0):
