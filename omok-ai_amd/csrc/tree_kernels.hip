@@ -862,21 +862,84 @@ __global__ __launch_bounds__(64) void k_scatter_policy(Store S, const float* __r
     }
 }
 
-// part 2, one wave per TREE: backups in simulation order (the f32 sums of w depend on the order), pme.rs:229,264
+// part 2, one wave per TREE: backups in simulation order (the f32 sums of w depend on the order), pme.rs:229,264.
+// The requests of a tree and round are (almost always) children of ONE leaf, so their backups climb the SAME path: it is walked once
+// (lane i keeps the (n, w) slot of the path's level i), every request's value is then added level-parallel in registers -- each
+// level's w still receives its addends one request after the other, in simulation order, with the sign of its distance, exactly as
+// Node::propagate applies them -- and stored once.  Per request only its own (fresh) slot in the leaf's table is touched, by its own
+// lane.  That is 3 dependent loads per level of the path instead of per level AND request.  Requests with different parents (a
+// backup of a terminal node between them moved the descent) take the plain per-request walk.
 template <int N>
 __global__ __launch_bounds__(64) void k_scatter(Store S, int side, const float* __restrict__ V) {
     using G = Geo<N>;
+    constexpr int ROWP = G::ROWP;
     const int g = blockIdx.x;
     if (!S.gs[g].alive) return;
     const int t = side * S.games + g;
     const Tree<N> T(S, t);
     const TreeState ts = *T.ts;
     if (ts.n_req == 0) return;
+    const int lane = LANE, nreq = (int)ts.n_req;
     Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
-    for (uint32_t r = 0; r < ts.n_req; ++r) {
-        backup<N>(T, R, T.req[r], -V[(size_t)ts.req_base + r]);
-        __syncthreads();
-        R.bytes += 8ull * G::HW + 4;
+    // every request's node, its parent and action (one lane per request; n_req <= KMAX = 64)
+    int x = 0, par = -1, act = 0;
+    float val = 0.0f;
+    if (lane < nreq) {
+        x = (int)T.req[lane];
+        const NodeHdr hx = T.hdr[x];
+        par = (int)hx.parent;
+        act = (int)hx.action;
+        val = V[(size_t)ts.req_base + lane];
+    }
+    const int leaf = __shfl(par, 0, 64);
+    const bool same = __ballot(lane < nreq && par != leaf) == 0ULL;
+    // the path above the leaf: level 0 = the leaf's slot in its parent's table, ... up to the child of the root
+    int depth = 0;
+    size_t my_slot = 0;
+    uint32_t my_n = 0;
+    float my_w = 0.0f;
+    bool fits = same;
+    if (same) {
+        int y = leaf;
+        while (y != 0) {
+            const NodeHdr h = T.hdr[y];
+            const size_t slot = (size_t)T.hdr[h.parent].table * ROWP + h.action;
+            const uint32_t n = T.cn[slot];
+            const float w = T.cw[slot];
+            if (lane == depth) { my_slot = slot; my_n = n; my_w = w; }
+            y = h.parent;
+            depth += 1;
+            if (depth >= 64) { fits = y == 0; break; }
+        }
+    }
+    if (fits) {
+        const size_t tab_leaf = (size_t)T.hdr[leaf].table * ROWP;
+        // own slots: n += 1, w += -v (the first step of propagate), one lane per request
+        if (lane < nreq) {
+            const size_t slot = tab_leaf + act;
+            const uint32_t n = T.cn[slot] + 1u;
+            const float w = T.cw[slot] + (-val);
+            T.cn[slot] = n;
+            T.cw[slot] = w;
+        }
+        // levels and root: the value alternates its sign with the distance; level i (distance i + 1 from the request) gets +v for even i
+        float root_w = R.root_w;
+        const float sgn_root = (depth & 1) ? -1.0f : 1.0f;
+        for (int r = 0; r < nreq; ++r) {
+            const float v = __shfl(val, r, 64);
+            if (lane < depth) { my_n += 1u; my_w += (lane & 1) ? -v : v; }
+            root_w += sgn_root * v; // (+-v exactly: a multiplication by +-1)
+        }
+        if (lane < depth) { T.cn[my_slot] = my_n; T.cw[my_slot] = my_w; }
+        R.root_n += (uint32_t)nreq;
+        R.root_w = root_w;
+        R.bytes += (unsigned long long)nreq * (16ull * (unsigned long long)(depth + 1) + 16ull + 8ull * G::HW + 4ull);
+    } else {
+        for (uint32_t r = 0; r < ts.n_req; ++r) {
+            backup<N>(T, R, T.req[r], -V[(size_t)ts.req_base + r]);
+            __syncthreads();
+            R.bytes += 8ull * G::HW + 4;
+        }
     }
     if (LANE == 0) {
         TreeState o = ts;
