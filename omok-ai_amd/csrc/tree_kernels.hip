@@ -183,6 +183,20 @@ __device__ inline float seq_sum(const float* s, int n) {
     return acc;
 }
 
+// The same sequential sum over a row held in REGISTERS (x[j] of lane l = element 64 j + l): element by element through v_readlane,
+// ascending -- the same additions in the same order as seq_sum, without 225 dependent LDS round trips (~16 k cycles per row, the
+// whole run time of k_scatter_policy).  Wave-uniform result.
+template <int N>
+__device__ inline float seq_sum_regs(const float (&x)[Geo<N>::IT]) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < Geo<N>::IT; ++j)
+#pragma unroll
+        for (int l = 0; l < 64; ++l)
+            if (j * 64 + l < Geo<N>::HW) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[j]), l));
+    return acc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // per-tree view
 // ---------------------------------------------------------------------------------------------
@@ -831,34 +845,29 @@ template <int N>
 __global__ __launch_bounds__(64) void k_scatter_policy(Store S, const float* __restrict__ P, int max_count) {
     using G = Geo<N>;
     constexpr int ROWP = G::ROWP, NW = G::NW;
-    __shared__ float s_row[ROWP];
     int count = S.d_count[0];
     if (count > max_count) count = max_count;
     const int lane = LANE;
+    // (four requests per iteration, their loads in flight together, measured SLOWER: 100 vs 67 us per 65536 requests)
     for (int d = blockIdx.x; d < count; d += gridDim.x) {
         const uint32_t ref = S.req_ref[d];
         const size_t tn = (size_t)(ref >> 16) * (size_t)S.cap_nodes + (size_t)(ref & 0xFFFFu);
         uint64_t occ[NW];
 #pragma unroll
         for (int i = 0; i < NW; ++i) occ[i] = S.board[tn * (2 * NW) + i] | S.board[tn * (2 * NW) + NW + i];
+        float row[G::IT];
 #pragma unroll
         for (int j = 0; j < G::IT; ++j) {
             const int a = j * 64 + lane;
             const bool empty = a < G::HW && !((occ[j] >> lane) & 1ULL);
-            s_row[a] = empty ? P[(size_t)d * ROWP + a] : 0.0f; // pme.rs:235-239
+            row[j] = empty ? P[(size_t)d * ROWP + a] : 0.0f; // pme.rs:235-239
         }
-        __syncthreads();
-        const float sum = seq_sum(s_row, G::HW);
+        const float sum = seq_sum_regs<N>(row);
         const bool renorm = F32_EPS <= sum;
         const float inv = renorm ? __fdiv_rn(1.0f, sum) : 1.0f;
 #pragma unroll
-        for (int j = 0; j < G::IT; ++j) {
-            const int a = j * 64 + lane;
-            const float x = s_row[a];
-            S.policy[tn * ROWP + a] = renorm ? x * inv : x;
-        }
+        for (int j = 0; j < G::IT; ++j) S.policy[tn * ROWP + j * 64 + lane] = renorm ? row[j] * inv : row[j];
         if (lane == 0) S.hdr[tn].has_policy = 1;
-        __syncthreads();
     }
 }
 
