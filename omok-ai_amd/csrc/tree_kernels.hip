@@ -152,9 +152,12 @@ __device__ inline uint32_t total_key_biased(float f) { // f32::total_cmp order a
     b ^= (int)(((unsigned)(b >> 31)) >> 1);
     return (uint32_t)b ^ 0x80000000u;
 }
-__device__ inline int nth_set_bit(unsigned long long m, int r) {
-    for (int i = 0; i < r; ++i) m &= m - 1;
-    return __ffsll((long long)m) - 1;
+__device__ inline int nth_set_bit(unsigned long long m, int r) { // index of the r-th (0-based) set bit of m; m, r wave-uniform, all 64 lanes call
+    // lane l: is bit l set and preceded by exactly r set bits?  (a loop clearing the lowest bit r times was ~100 scalar instructions per
+    //  simulation in k_round, whose cached simulations are bound by instruction issue)
+    const int l = (int)LANE;
+    const bool hit = ((m >> l) & 1ULL) && __popcll(m & ((1ULL << l) - 1ULL)) == r;
+    return __ffsll((long long)__ballot(hit)) - 1;
 }
 // (Both helpers touch EVERY word with a computed mask: a chain of selects on the word index is turned back into an indexed
 //  access by the compiler, which then keeps the bitboards in scratch memory -- 120 B per lane, ~6 KB of HBM writes per
