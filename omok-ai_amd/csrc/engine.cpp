@@ -290,6 +290,7 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     e->net.mode = cfg->net_mode == OMOK_NET_F16X3_ROWS ? OMOK_NET_F16X3 : cfg->net_mode;
     e->net.siblings = cfg->net_mode == OMOK_NET_F16X3;
     e->net.max_b = (int)max_b;
+    e->net.games = cfg->games;
     for (int i = 0; i < NET_TENSORS; ++i) e->net.wsize[i] = net_tensor_size(e->n, i);
     if (net_alloc(e->net) == 0) {
         g_create_error = "net buffer allocation failed (hipMalloc)";
@@ -327,6 +328,7 @@ extern "C" int omok_net_commit(omok_engine* e) {
         if (!e->net.loaded[i]) return fail(e, OMOK_ERR_STATE, "tensor %d was never loaded", i);
     HIPCHK(e, hipSetDevice(e->cfg.device));
     if (net_commit(e->net, e->st) != 0) return fail(e, OMOK_ERR_HIP, "weight packing failed");
+    net_invalidate_sibling_cache(e->net); // (new weights: cached base evaluations are void)
     HIPCHK(e, hipStreamSynchronize(e->st));
     e->net.committed = true;
     return OMOK_OK;
@@ -563,6 +565,7 @@ extern "C" int omok_selfplay_reset(omok_engine* e) {
     net_forward_inputs(e->net, e->S, 1, e->st, &e->prof);
     k_copy_root_policy<<<1, 256, 0, e->st>>>(e->net.p, e->d_root_policy, e->hw, e->rowp);
     launch_reset(e->n, e->S, e->d_root_policy, e->st);
+    net_invalidate_sibling_cache(e->net);
     if (sync_and_check(e, "selfplay_reset")) return OMOK_ERR_HIP;
     e->evals += 1;
     e->key = e->cfg.seed + e->episode * 0x9E3779B97F4A7C15ULL; // a fresh RNG stream per episode (the reference draws thread_rng anew, trainer.rs:71-93)
@@ -693,6 +696,7 @@ static void enqueue_mirror_and_advance(omok_engine* e, int alive) {
     net_forward_requests(e->net, e->S, alive, e->st, &e->prof);
     e->prof.begin(PC_PLY, e->st);
     launch_advance(e->n, e->S, side, e->net.p, e->st);
+    net_invalidate_sibling_cache(e->net);
     e->prof.end(e->st);
 }
 
@@ -786,6 +790,7 @@ extern "C" int omok_selfplay_run_slots(omok_engine* e, int32_t total_games, int3
         e->prof.begin(PC_PLY, e->st);
         launch_harvest(e->n, e->S, d_mask, d_slot_off, d_out, d_meta, (uint8_t*)records_dev, cap_records, e->st);
         if ((e->ply & 1) == 0) launch_refill(e->n, e->S, e->d_root_policy, d_next, total_games, d_new, e->st);
+        net_invalidate_sibling_cache(e->net);
         e->prof.end(e->st);
         uint32_t after = 0;
         if (read_status(e, &bits, &after)) { cleanup(); return OMOK_ERR_HIP; }
@@ -797,6 +802,7 @@ extern "C" int omok_selfplay_run_slots(omok_engine* e, int32_t total_games, int3
             if (next >= total_games) break;
             e->ply += 1;
             launch_refill(e->n, e->S, e->d_root_policy, d_next, total_games, d_new, e->st);
+            net_invalidate_sibling_cache(e->net);
             if (read_status(e, &bits, &alive)) { cleanup(); return OMOK_ERR_HIP; }
         }
     }
@@ -1061,6 +1067,7 @@ extern "C" int omok_mirror_apply(omok_engine* e) {
     uint32_t bits = 0, before = 0, after = 0;
     if (read_status(e, &bits, &before)) return OMOK_ERR_HIP;
     launch_advance(e->n, e->S, e->ply & 1, e->net.p, e->st);
+    net_invalidate_sibling_cache(e->net);
     if (read_status(e, &bits, &after)) return OMOK_ERR_HIP;
     e->ply_games += before;
     e->finished += (double)before - (double)after;

@@ -53,6 +53,15 @@ struct Net {
     void* d_slot_desc = nullptr;     // per slot: (request row, full-row index of its base / of itself)
     void* d_rows = nullptr;          // [slot][2 q][49 window pixels] f16 parts, then residual parts: the difference rows
     size_t d_slots = 0;              // slots allocated
+    // base cache: a leaf stays the expansion target of its tree for ~14 rounds, so its base evaluation (operand row, h grids, fp32 fc0 row)
+    // is kept per game slot and reused while the tree's runs keep the same parent (~78 % of the runs of a configs[1] episode)
+    int games = 0;                   // game slots of the engine (base slots [0, games): one per game; [games, base_slots): other runs of a round)
+    size_t base_slots = 0;
+    void* a_base = nullptr;          // [base_slots] operand rows of base positions (row_u4 each)
+    float* facc = nullptr;           // [base_slots + max_b][512] fp32 fc0 rows: base slots, then the round's single rows
+    int32_t* d_tags = nullptr;       // [games] node index of the leaf whose base sits in the game's slot, -1 = none
+    void* d_comp = nullptr;          // the round's positions to evaluate in full: (request row of the first child, base slot)
+    bool sib_cache_valid = false;    // false: the trees changed outside the search rounds (reset, advance, refill): tags are cleared first
     float* part_w = nullptr;         // fp32 partials of the K-split window tiles: [7][part_w_rows][512]
     size_t part_w_rows = 0;
     int n_cu = 256;                  // compute units of the device
@@ -91,6 +100,8 @@ void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t s
 // Forward of explicit f32 inputs already in net.in_f32 ([count][3HW]); count is a host value
 // and must also be stored in S.d_count[0] by the caller.
 void net_forward_inputs(Net& net, const Store& S, int count, hipStream_t st, struct Prof* prof);
+// The trees were changed outside the search rounds (reset, advance, refill, externally placed moves): cached base evaluations are void.
+inline void net_invalidate_sibling_cache(Net& net) { net.sib_cache_valid = false; }
 // Packs the raw tensors into the MFMA operand layouts (host-side repack + upload).
 int net_commit(Net& net, hipStream_t st);
 // pre-softmax policy logits of the LAST forward (rows of the last chunk in OMOK_NET_F32 mode): pointer and row stride in floats

@@ -253,12 +253,13 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                                                                     uint4* __restrict__ a_out, size_t row_u4, int max_count,
                                                                     const int32_t* __restrict__ row_list, const int32_t* __restrict__ d_nrows,
                                                                     const uint2* __restrict__ groups, float* __restrict__ hscr,
-                                                                    const int32_t* __restrict__ d_out_base) {
+                                                                    const int32_t* __restrict__ d_out_base, uint4* __restrict__ a_base) {
     // row_list != NULL: the kernel evaluates the request rows row_list[0 .. d_nrows[0]) (the rows outside the sibling runs).
     // BASE: sample i is the BASE position of sibling run groups[i] -- the parent's board with the children's side to move; the
     // depthwise inputs of its three blocks go to hscr[i][blk][pixel][32] and its operand row into every child row of the run
-    // (copy path) or, DELTA (difference path), once to full row i; with DELTA the rows of a row list go to full rows
-    // d_out_base[0] + i (behind the runs' rows).
+    // (copy path) or, DELTA (difference path), to the compact row i (fc0 of this round's evaluated positions) AND to base slot groups[i].y of
+    // a_base (what the children read, this round and while the slot's tag stays: the h grids go to hscr[slot] likewise); with DELTA the rows
+    // of a row list go to compact rows d_out_base[0] + i (behind the runs').
     constexpr bool BASE = (ABL & 16) != 0, DELTA = (ABL & 32) != 0;
     using TG = TrunkGeo<N>;
     constexpr int HW = TG::HW, NW = Geo<N>::NW;
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
             if (BASE && active) { // the base's depthwise input of this block -> scratch: the children's halo rings read it (225 pixels x 8 pieces of 16 B)
                 for (int i = stid; i < HW * 8; i += TG::THREADS) {
                     const int p = i >> 3, piece = i & 7;
-                    *(uint4*)(hscr + ((size_t)b * 3 + blk) * (HW * NM) + p * NM + piece * 4) =
+                    *(uint4*)(hscr + ((size_t)(DELTA ? (int)groups[bi].y : b) * 3 + blk) * (HW * NM) + p * NM + piece * 4) =
                         *(const uint4*)(grid + ((p / N + 1) * (N + 2) + (p % N + 1)) * GRID_STRIDE + piece * 4);
                 }
             }
@@ -606,6 +607,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
             if (BASE) orow = DELTA ? (uint32_t)(active ? bi : 0) : (active ? groups[bi].x : 0u);
             else if (DELTA && row_list) orow = (uint32_t)(d_out_base[0] + (active ? bi : 0));
             uint4* row = a_out + (size_t)orow * row_u4;
+            uint4* row2 = (BASE && DELTA) ? a_base + (size_t)(active ? groups[bi].y : 0u) * row_u4 : nullptr; // the base slot
             const int copies = (BASE && !DELTA) ? (active ? (int)groups[bi].y : 0) : 1;
             const float sc_lo_inv = __uint_as_float((uint32_t)(127 - MX_SA - 11) << 23); // fp8 = (x - hi) / 2^-(SA+11)
             uint4* stage_w = (uint4*)(grid + gi * GRID_STRIDE);          // this lane's pixel row (8 slots of 16 B)
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                         if (st_ok[i] && active) {
                             uint4* dst = &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + (8 * i + (lane >> 3)) * 8 + (lane & 7)];
                             if (BASE && !DELTA) for (int c = 0; c < copies; ++c) nt_store(v, dst + (size_t)c * row_u4);
-                            else if (DELTA) *dst = v; // (read again right away: by the children of the run and by fc0)
+                            else if (DELTA) { *dst = v; if (BASE) row2[dst - row] = v; } // (read again right away: by fc0; by the children of the run)
                             else nt_store(v, dst);
                         }
                     }
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                     if (st_ok[i] && active) {
                         uint4* dst = &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (8 * i + (lane >> 3)) * 4 + (lane & 3)];
                         if (BASE && !DELTA) for (int c = 0; c < copies; ++c) nt_store(v, dst + (size_t)c * row_u4);
-                        else if (DELTA) *dst = v;
+                        else if (DELTA) { *dst = v; if (BASE) row2[dst - row] = v; }
                         else nt_store(v, dst);
                     }
                 }
@@ -735,7 +737,8 @@ constexpr int SIB_CGRID_BYTES = SIB_CGRID_ROWS * GRID_STRIDE * 4; // 11808
 constexpr int SIB_HB_FLOATS = 225 * NM;          // one base h grid in the scratch: [pixel][32]
 // difference path: window bins (window origin (wy0, wx0) in 0..8 each), the single rows as bin SIB_BINS, counters, difference rows
 constexpr int SIB_ORG = 15 - SIB_WIN + 1, SIB_BINS = SIB_ORG * SIB_ORG; // 9, 81
-constexpr int SIB_CNT_INTS = 8 + SIB_BINS + 7;                            // d_gcnt: 5 counters, pad, bin counts (96 ints)
+constexpr int SIB_CNT_INTS = 8 + SIB_BINS + 7 + 16;                       // d_gcnt: 8 counters, bin counts (96 ints), [96] full evaluations of runs (base-cache
+                                                                          // misses + uncacheable runs), [97] uncacheable runs
 constexpr int SIB_WPX = SIB_WIN * SIB_WIN;                                // 49 window pixels = 98 fc0 super-steps
 constexpr int SIB_DROW_U4 = SIB_WPX * 2 * 12;                             // 1176 uint4 = 18816 B: [q][w] 128-B f16 parts, [q][w] 64-B residual parts
 constexpr int SIB_DLO_U4 = SIB_WPX * 2 * 8;                               // 784: first residual part
@@ -756,11 +759,15 @@ __device__ inline void sib_window(int action, int& wy0, int& wx0) { // the 7x7 w
 // atomic per counter (per-row atomics on 3 + 81 addresses serialised in L2: 0.24 ms per round).
 constexpr int GROUP_TREES = 16;
 __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, uint2* __restrict__ groups, int32_t* __restrict__ singles,
-                                                             uint4* __restrict__ sib_rows, int32_t* __restrict__ cnt, uint32_t* __restrict__ sib_slot) {
-    __shared__ int l_cnt[3 + SIB_BINS], l_base[3 + SIB_BINS];
+                                                             uint4* __restrict__ sib_rows, int32_t* __restrict__ cnt, uint32_t* __restrict__ sib_slot,
+                                                             int32_t* __restrict__ tags, uint2* __restrict__ comp) {
+    // Difference path (sib_slot != NULL): base slots.  The FIRST run of a tree uses the game's own slot g, whose content is reused while
+    // tags[g] names the run's parent (a leaf is its tree's expansion target for ~14 rounds); further runs of the tree in the same round
+    // (rare) take a slot behind the games' and are always evaluated.  comp[] lists the (first request row, slot) pairs to evaluate.
+    __shared__ int l_cnt[3 + SIB_BINS + 2], l_base[3 + SIB_BINS + 2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = blockIdx.x * GROUP_TREES + (tid >> 6);
-    if (tid < 3 + SIB_BINS) l_cnt[tid] = 0;
+    if (tid < 3 + SIB_BINS + 2) l_cnt[tid] = 0;
     __syncthreads();
     int n = 0;
     TreeState ts{};
@@ -788,9 +795,20 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
     const int len = re - rs;
     const bool in_run = lane < n && len >= SIB_MIN;
     int gslot = 0, rbase = 0, bin = 0, rank = 0, sidx = 0;
+    int bslot = -1, mi = -1, ex = -1; // base slot (>= 0: decided), index in the evaluation list (-1: cache hit), index among the uncacheable runs
+    const unsigned long long qual = __ballot(start && len >= SIB_MIN);
     if (start && len >= SIB_MIN) {
         gslot = atomicAdd(&l_cnt[0], 1);
         rbase = atomicAdd(&l_cnt[2], len);
+        if (sib_slot) {
+            if (lane == __ffsll((long long)qual) - 1) {
+                bslot = g;
+                if (tags[g] != parent) { tags[g] = parent; mi = atomicAdd(&l_cnt[3 + SIB_BINS], 1); }
+            } else {
+                ex = atomicAdd(&l_cnt[3 + SIB_BINS + 1], 1);
+                mi = atomicAdd(&l_cnt[3 + SIB_BINS], 1);
+            }
+        }
     }
     gslot = __shfl(gslot, rs, 64);
     rbase = __shfl(rbase, rs, 64);
@@ -803,12 +821,20 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
         }
     } else if (lane < n) sidx = atomicAdd(&l_cnt[1], 1);
     __syncthreads();
-    if (tid < 3 + SIB_BINS && l_cnt[tid] > 0 && (tid < 3 || sib_slot)) l_base[tid] = atomicAdd(&cnt[tid < 3 ? tid : 8 + (tid - 3)], l_cnt[tid]);
+    if (tid < 3 + SIB_BINS + 2 && l_cnt[tid] > 0 && (tid < 3 || sib_slot))
+        l_base[tid] = atomicAdd(&cnt[tid < 3 ? tid : (tid < 3 + SIB_BINS ? 8 + (tid - 3) : 96 + (tid - 3 - SIB_BINS))], l_cnt[tid]);
     __syncthreads();
-    if (start && len >= SIB_MIN) groups[l_base[0] + gslot] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)len);
+    if (start && len >= SIB_MIN) {
+        groups[l_base[0] + gslot] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)len);
+        if (sib_slot) {
+            if (ex >= 0) bslot = S.games + l_base[3 + SIB_BINS + 1] + ex;
+            if (mi >= 0) comp[l_base[3 + SIB_BINS] + mi] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)bslot);
+        }
+    }
+    bslot = __shfl(bslot, rs, 64);
     if (in_run) {
         const int ri = l_base[2] + rbase + (lane - rs);
-        sib_rows[ri] = make_uint4(ts.req_base + (uint32_t)lane, (uint32_t)(l_base[0] + gslot), tn, ta);
+        sib_rows[ri] = make_uint4(ts.req_base + (uint32_t)lane, sib_slot ? (uint32_t)bslot : (uint32_t)(l_base[0] + gslot), tn, ta);
         if (sib_slot) sib_slot[ri] = ((uint32_t)bin << 24) | (uint32_t)(l_base[3 + bin] + rank);
     } else if (lane < n) singles[l_base[1] + sidx] = (int32_t)(ts.req_base + (uint32_t)lane);
 }
@@ -834,7 +860,7 @@ __device__ inline int sib_bin_at(int pos) { // layout position -> bin
 }
 __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, int32_t* __restrict__ bin_start, int32_t* __restrict__ tile_info,
                                                     uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu, int max_fways,
-                                                    int max_wways, int part_w_rows) {
+                                                    int max_wways, int part_w_rows, int facc_single_base) {
     __shared__ int tile0[SIB_BINS + 2];
     const int tid = threadIdx.x;
     const int c = tid < SIB_BINS ? cnt[8 + tid] : (tid == SIB_BINS ? cnt[1] : 0);
@@ -859,7 +885,7 @@ __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, i
         if (ways > max_wways) ways = max_wways;
         if (ntiles > t_split && ways > part_w_rows / ((ntiles - t_split) * GT_BS)) ways = part_w_rows / ((ntiles - t_split) * GT_BS); // (partials slab)
         if (ways < 2) { ways = 1; t_split = ntiles; }
-        cnt[3] = cnt[0] + cnt[1];
+        cnt[3] = cnt[96] + cnt[1]; // positions evaluated in full this round: runs without a cached base, then the single rows
         const int ftiles = (cnt[3] + GT_BS - 1) / GT_BS;          // fc0 of the full rows: K split so that one round of workgroups covers it
         int fways = ftiles > 0 ? n_cu / ftiles : 1;
         cnt[7] = fways < 1 ? 1 : (fways > max_fways ? max_fways : fways);
@@ -872,8 +898,8 @@ __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, i
         bin_start[tid] = tile0[tid] * GT_BS;
         for (int t = 0; t * GT_BS < c; ++t) tile_info[tile0[tid] + t] = tid | ((c - t * GT_BS < GT_BS ? c - t * GT_BS : GT_BS) << 8);
     }
-    const int nsing = cnt[1], nruns = cnt[0], s0 = tile0[SIB_BINS] * GT_BS;
-    for (int i = tid; i < nsing; i += blockDim.x) slot_desc[s0 + i] = make_uint2((uint32_t)singles[i], (uint32_t)(nruns + i));
+    const int nsing = cnt[1], s0 = tile0[SIB_BINS] * GT_BS;
+    for (int i = tid; i < nsing; i += blockDim.x) slot_desc[s0 + i] = make_uint2((uint32_t)singles[i], (uint32_t)(facc_single_base + i)); // (fp32 fc0 row index)
 }
 
 // tiles of the K-split set (see k_bin_prefix): partials in split order + the slot's full row + bias, LeakyReLU, hi|lo operand row
@@ -913,9 +939,11 @@ __global__ __launch_bounds__(256) void k_win_finish(const float* __restrict__ pa
 }
 
 // full-row partial sums of fc0 -> one fp32 row per full row (in place, into split 0), in split order
-__global__ __launch_bounds__(256) void k_facc_reduce(float* __restrict__ part, size_t cap_rows, const int32_t* __restrict__ d_nrows, const int32_t* __restrict__ d_nsplit) {
+// (evaluated row i: i < nmiss -> the base slot comp[i].y, else the single row i - nmiss behind the base slots)
+__global__ __launch_bounds__(256) void k_facc_reduce(const float* __restrict__ part, size_t cap_rows, const int32_t* __restrict__ d_nrows, const int32_t* __restrict__ d_nsplit,
+                                                     float* __restrict__ facc, const uint2* __restrict__ comp, const int32_t* __restrict__ d_nmiss, int facc_single_base) {
     const size_t total = (size_t)d_nrows[0] * (NF / 4);
-    const int nsplit = d_nsplit[0];
+    const int nsplit = d_nsplit[0], nmiss = d_nmiss[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         f32x4 a = *(const f32x4*)(part + i * 4);
         for (int sp = 1; sp < nsplit; ++sp) {
@@ -923,7 +951,9 @@ __global__ __launch_bounds__(256) void k_facc_reduce(float* __restrict__ part, s
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] += b[j];
         }
-        *(f32x4*)(part + i * 4) = a;
+        const int row = (int)(i / (NF / 4));
+        const size_t dst = row < nmiss ? (size_t)comp[row].y : (size_t)(facc_single_base + (row - nmiss));
+        *(f32x4*)(facc + dst * NF + (i % (NF / 4)) * 4) = a;
     }
 }
 
@@ -2173,7 +2203,8 @@ size_t net_alloc(Net& net) {
             ok = ok && A((void**)&net.d_singles, sizeof(int32_t) * mb);
             ok = ok && A((void**)&net.d_gcnt, sizeof(int32_t) * SIB_CNT_INTS);
             ok = ok && A((void**)&net.d_sib_rows, sizeof(uint4) * mb);
-            ok = ok && A((void**)&net.sib_h, sizeof(float) * (mb / SIB_MIN + 1) * 3 * SIB_HB_FLOATS);
+            net.base_slots = (size_t)net.games + mb / SIB_MIN + 1; // a slot per game + the other runs a round can hold
+            ok = ok && A((void**)&net.sib_h, sizeof(float) * net.base_slots * 3 * SIB_HB_FLOATS);
             // difference path: slots (bins padded to whole tiles), their difference rows
             net.d_slots = mb + (size_t)(SIB_BINS + 1) * GT_BS;
             ok = ok && A((void**)&net.d_sib_slot, sizeof(uint32_t) * mb);
@@ -2181,6 +2212,10 @@ size_t net_alloc(Net& net) {
             ok = ok && A((void**)&net.d_tile_info, sizeof(int32_t) * (net.d_slots / GT_BS));
             ok = ok && A(&net.d_slot_desc, sizeof(uint2) * net.d_slots);
             ok = ok && A(&net.d_rows, net.d_slots * (size_t)SIB_DROW_U4 * 16);
+            ok = ok && A(&net.a_base, net.base_slots * row_u4 * 16);
+            ok = ok && A((void**)&net.facc, sizeof(float) * (net.base_slots + mb) * NF);
+            ok = ok && A((void**)&net.d_tags, sizeof(int32_t) * (size_t)(net.games > 0 ? net.games : 1));
+            ok = ok && A(&net.d_comp, sizeof(uint2) * (mb / SIB_MIN + 1));
             hipDeviceProp_t prop;
             net.n_cu = (hipGetDeviceProperties(&prop, net.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
             net.part_w_rows = std::min<size_t>((size_t)net.n_cu * GT_BS, net.d_slots); // K-split window tiles: at most one round of workgroups, 7 ways
@@ -2199,7 +2234,7 @@ void net_free(Net& net) {
                      (void**)&net.sg, (void**)&net.s0, (void**)&net.s1, &net.wt_trunk, (void**)&net.wt_first, &net.wt_fc0,
                      &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part, (void**)&net.d_chunk, (void**)&net.d_groups,
                      (void**)&net.d_singles, (void**)&net.d_gcnt, (void**)&net.sib_h, (void**)&net.d_sib_rows, (void**)&net.d_sib_slot,
-                     (void**)&net.d_bin_start, (void**)&net.d_tile_info, &net.d_slot_desc, &net.d_rows, (void**)&net.part_w};
+                     (void**)&net.d_bin_start, (void**)&net.d_tile_info, &net.d_slot_desc, &net.d_rows, (void**)&net.part_w, &net.a_base, (void**)&net.facc, (void**)&net.d_tags, &net.d_comp};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     for (int i = 0; i < NET_TENSORS; ++i) { if (net.w[i]) hipFree(net.w[i]); net.w[i] = nullptr; }
 }
@@ -2356,7 +2391,8 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
     const int wgs = (max_count + TG::SPW - 1) / TG::SPW;
     const int grid = wgs < 256 ? wgs : 256;
     kern<<<grid, TG::WG_THREADS, TG::LDS_BYTES, st>>>(S.req_ref, S.req_aux, S.board, S.hdr, S.d_count, S.cap_nodes, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first,
-                                                       (uint4*)net.a_fc0, net.row_u4, max_count, row_list, d_nrows, (const uint2*)net.d_groups, net.sib_h, d_out_base);
+                                                       (uint4*)net.a_fc0, net.row_u4, max_count, row_list, d_nrows,
+                                                       (ABL & 48) == 48 ? (const uint2*)net.d_comp : (const uint2*)net.d_groups, net.sib_h, d_out_base, (uint4*)net.a_base);
 }
 
 template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
@@ -2395,8 +2431,12 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         attr_done[net.device & 63] = true;
     }
     hipMemsetAsync(net.d_gcnt, 0, sizeof(int32_t) * SIB_CNT_INTS, st);
+    if (delta && !net.sib_cache_valid) { // the trees changed since the last search round: no cached base is valid
+        hipMemsetAsync(net.d_tags, 0xFF, sizeof(int32_t) * (size_t)net.games, st);
+        net.sib_cache_valid = true;
+    }
     k_group<<<(S.games + GROUP_TREES - 1) / GROUP_TREES, 64 * GROUP_TREES, 0, st>>>(S, side, (uint2*)net.d_groups, net.d_singles, (uint4*)net.d_sib_rows, net.d_gcnt,
-                                                                                     delta ? net.d_sib_slot : nullptr);
+                                                                                     delta ? net.d_sib_slot : nullptr, net.d_tags, (uint2*)net.d_comp);
     const int max_groups = max_count / SIB_MIN + 1;
     if (!delta) {
         launch_trunk<15, false, 16>(net, S, max_groups, st, nullptr, net.d_gcnt);                 // base positions of the runs
@@ -2406,7 +2446,7 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         return;
     }
     k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu,
-                                    sib_max_fways(net, max_count), SIB_MAX_WWAYS, (int)std::min<size_t>(net.part_w_rows * 7, (size_t)1 << 30));
+                                    sib_max_fways(net, max_count), SIB_MAX_WWAYS, (int)std::min<size_t>(net.part_w_rows * 7, (size_t)1 << 30), (int)net.base_slots);
     static const bool stats = getenv("OMOK_SIB_STATS") && atoi(getenv("OMOK_SIB_STATS")); // diagnostics only: synchronises every round
     if (stats) {
         static long long acc[8] = {}, launches = 0;
@@ -2420,15 +2460,15 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
             for (int i = 0; i < 8; ++i) acc[i] = 0;
         }
     }
-    launch_trunk<15, false, 48>(net, S, max_groups, st, nullptr, net.d_gcnt);                              // base positions -> full rows [0, runs)
-    launch_trunk<15, false, 32>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1, net.d_gcnt);         // single rows -> full rows [runs, runs + singles)
+    launch_trunk<15, false, 48>(net, S, max_groups, st, nullptr, net.d_gcnt + 96);                         // runs without a cached base -> compact rows [0, misses) + their base slots
+    launch_trunk<15, false, 32>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1, net.d_gcnt + 96);    // single rows -> compact rows [misses, misses + singles)
     static const bool tprof = getenv("OMOK_SIB_PROF") && atoi(getenv("OMOK_SIB_PROF")); // timing experiments only
     if (tprof) {
         static unsigned long long* d_tp = nullptr;
         static unsigned long long acc[32] = {};
         static int launches = 0;
         if (!d_tp) { hipMalloc(&d_tp, 256); hipMemset(d_tp, 0, 256); hipFuncSetAttribute((const void*)k_sib_children<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); }
-        k_sib_children<true, true><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
+        k_sib_children<true, true><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_base, net.row_u4,
                                                            (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, net.d_sib_slot, net.d_bin_start,
                                                            (uint4*)net.d_rows, (uint2*)net.d_slot_desc, d_tp);
         if (++launches % 100 == 0) {
@@ -2446,7 +2486,7 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         }
         return;
     }
-    k_sib_children<true><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
+    k_sib_children<true><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_base, net.row_u4,
                                                  (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, net.d_sib_slot, net.d_bin_start,
                                                  (uint4*)net.d_rows, (uint2*)net.d_slot_desc, nullptr);
 }
@@ -2462,18 +2502,18 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
     k_fc0_mx<EPI_PARTIAL><<<dim3(tiles_max, sib_max_fways(net, max_count)), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32,
                                                                (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, cap_rows, net.part, net.d_gcnt + 3,
                                                                max_count, net.d_gcnt + 7, nullptr, nullptr);
-    k_facc_reduce<<<512, 256, 0, st>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 7);
+    k_facc_reduce<<<512, 256, 0, st>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 7, net.facc, (const uint2*)net.d_comp, net.d_gcnt + 96, (int)net.base_slots);
     // window tiles: whole rounds of workgroups at full K, the tiles of the last partial round split over K (k_bin_prefix)
     const int wtiles_max = (tiles_max + SIB_BINS + 1 + 7) / 8 * 8 + 8; // (the XCD-aware tile mapping rounds an eighth of the tiles up)
     k_fc0_mx<EPI_SPLIT, 0, true><<<dim3(wtiles_max, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
                                                                        (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr, net.d_gcnt, max_count,
-                                                                       net.d_tile_info, (const uint2*)net.d_slot_desc, net.part);
+                                                                       net.d_tile_info, (const uint2*)net.d_slot_desc, net.facc);
     const int stiles = wtiles_max < n_cu + 8 ? wtiles_max : n_cu + 8;
     k_fc0_mx<EPI_PARTIAL, 0, true><<<dim3(stiles, SIB_MAX_WWAYS), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
                                                                      (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, net.part_w_rows, net.part_w, net.d_gcnt,
                                                                      max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, nullptr);
     k_win_finish<<<(unsigned)(((size_t)stiles * GT_BS * 64 + 255) / 256), 256, 0, st>>>(net.part_w, net.part_w_rows, net.d_gcnt, net.d_tile_info,
-                                                                                         (const uint2*)net.d_slot_desc, net.part, bias_fc0, h0, 128);
+                                                                                         (const uint2*)net.d_slot_desc, net.facc, bias_fc0, h0, 128);
 }
 
 static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1) {
