@@ -860,7 +860,7 @@ __device__ inline int sib_bin_at(int pos) { // layout position -> bin
 }
 __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, int32_t* __restrict__ bin_start, int32_t* __restrict__ tile_info,
                                                     uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu, int max_fways,
-                                                    int max_wways, int part_w_rows, int facc_single_base) {
+                                                    int max_wways, int part_w_rows, int facc_single_base, int part_f_rows) {
     __shared__ int tile0[SIB_BINS + 2];
     const int tid = threadIdx.x;
     const int c = tid < SIB_BINS ? cnt[8 + tid] : (tid == SIB_BINS ? cnt[1] : 0);
@@ -886,9 +886,12 @@ __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, i
         if (ntiles > t_split && ways > part_w_rows / ((ntiles - t_split) * GT_BS)) ways = part_w_rows / ((ntiles - t_split) * GT_BS); // (partials slab)
         if (ways < 2) { ways = 1; t_split = ntiles; }
         cnt[3] = cnt[96] + cnt[1]; // positions evaluated in full this round: runs without a cached base, then the single rows
-        const int ftiles = (cnt[3] + GT_BS - 1) / GT_BS;          // fc0 of the full rows: K split so that one round of workgroups covers it
-        int fways = ftiles > 0 ? n_cu / ftiles : 1;
-        cnt[7] = fways < 1 ? 1 : (fways > max_fways ? max_fways : fways);
+        const int ftiles = (cnt[3] + GT_BS - 1) / GT_BS;          // fc0 of the full rows: K split so that one round of workgroups covers it;
+        int fways = ftiles > 0 ? n_cu / ftiles : 1;              // partials [split][row < ftiles * 128]: as many ways as the slab holds
+        const int fcap = (ftiles > 0 ? ftiles : 1) * GT_BS;
+        if (fways > part_f_rows / fcap) fways = part_f_rows / fcap;
+        cnt[98] = fways < 1 ? 1 : (fways > max_fways ? max_fways : fways);
+        cnt[99] = fcap;
         cnt[4] = ntiles;
         cnt[5] = t_split;
         cnt[6] = ways;
@@ -944,6 +947,7 @@ __global__ __launch_bounds__(256) void k_facc_reduce(const float* __restrict__ p
                                                      float* __restrict__ facc, const uint2* __restrict__ comp, const int32_t* __restrict__ d_nmiss, int facc_single_base) {
     const size_t total = (size_t)d_nrows[0] * (NF / 4);
     const int nsplit = d_nsplit[0], nmiss = d_nmiss[0];
+    cap_rows = (size_t)d_nsplit[1];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         f32x4 a = *(const f32x4*)(part + i * 4);
         for (int sp = 1; sp < nsplit; ++sp) {
@@ -1525,27 +1529,33 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     __shared__ uint4 ldsW0[MXS_U4], ldsW1[MXS_U4], ldsW2[MXS_U4], ldsW3[MXS_U4]; // [4 i][6 frag][64] each
     auto ring = [&](int slot) -> uint4* { return slot == 0 ? ldsW0 : slot == 1 ? ldsW1 : slot == 2 ? ldsW2 : ldsW3; };
     int b0 = blockIdx.x * GT_BS;
-    int count, win_oy = 0, win_ox = 0, ubeg = 0, part_row0 = 0;
+    int count, win_oy = 0, win_ox = 0, ubeg = 0, part_row0 = 0, split_y = (int)blockIdx.y;
     if (WIN) { // EPI_SPLIT: the tiles below the K-split set, whole K; EPI_PARTIAL: tile d_count[5] + blockIdx.x, K split d_count[6] ways over blockIdx.y
         // Workgroups go to the 8 XCDs round-robin and every XCD has its own L2: XCD x takes a contiguous eighth of the tiles (tiles are
         // ordered by bin = by weight slice), so the workgroups that share an L2 stream the same 9 MB of weights in step instead of
         // every L2 streaming every slice (dealt round-robin, 46 % of the weight reads missed L2: 2.5 GB per launch, HBM-bound).
         const int nt = d_count[4], t_split = d_count[5];
         const int n_here = EPI == EPI_PARTIAL ? nt - t_split : t_split, eighth = (n_here + 7) >> 3;
-        int tile = ((int)blockIdx.x & 7) * eighth + ((int)blockIdx.x >> 3), ways = 1;
-        if (((int)blockIdx.x >> 3) >= eighth || tile >= n_here) return;
-        if (EPI == EPI_PARTIAL) {
-            tile += t_split;
+        int tile, ways = 1;
+        if (EPI == EPI_PARTIAL) { // 1-D grid over (tile of the split set, split): tiles x ways <= CUs (a 2-D grid of mostly idle, LDS-heavy workgroups
+                                  // costs more to dispatch than the work takes)
             ways = d_count[6];
-            if ((int)blockIdx.y >= ways) return;
+            const int total = n_here * ways, per_xcd = (total + 7) >> 3;                    // XCD x takes consecutive tiles, each with all its splits
+            const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+            if (n_here <= 0 || ((int)blockIdx.x >> 3) >= per_xcd || item >= total) return;
+            split_y = item % ways;
+            tile = t_split + item / ways;
             part_row0 = t_split * GT_BS;
-            out_row_u4 = (size_t)(nt - t_split) * GT_BS; // partials: [split][slot inside the split set]
+            out_row_u4 = (size_t)n_here * GT_BS; // partials: [split][slot inside the split set]
+        } else {
+            tile = ((int)blockIdx.x & 7) * eighth + ((int)blockIdx.x >> 3);
+            if (((int)blockIdx.x >> 3) >= eighth || tile >= n_here) return;
         }
         b0 = tile * GT_BS;
         const int ti = tile_info[tile], bin = ti & 0xFF;
         count = b0 + (ti >> 8);
         const int nsup = bin < SIB_BINS ? 2 * SIB_WPX : 0, per = (nsup + ways - 1) / ways;
-        ubeg = (int)blockIdx.y * per;
+        ubeg = split_y * per;
         ksup = nsup - ubeg < per ? nsup - ubeg : per;
         if (ksup < 0) ksup = 0;
         win_oy = bin / SIB_ORG;
@@ -1553,13 +1563,21 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     } else {
         count = d_count[0];
         if (count > max_count) count = max_count;
-        if (b0 >= count) return;
-        if (EPI == EPI_PARTIAL && tile_info) { // the number of K splits was chosen on the device (tile_info[0]); uneven split
+        if (EPI == EPI_PARTIAL && tile_info) { // the number of K splits and the partial slab's row capacity were chosen on the device (tile_info[0], [1]); uneven split.
+            // 1-D grid: workgroup w = (tile w % tiles, split w / tiles) -- a (tiles_max x ways_max) grid of which a few dozen workgroups have work
+            // costs more to dispatch (~65-100 workgroups per us) than the work takes
             const int ways = tile_info[0], nsup = full_tiles * 64 + 2 * last_cnt, per = (nsup + ways - 1) / ways;
-            if ((int)blockIdx.y >= ways) return;
-            ubeg = (int)blockIdx.y * per;
+            const int tiles = (count + GT_BS - 1) / GT_BS;
+            if (tiles == 0 || (int)blockIdx.x >= tiles * ways) return;
+            split_y = (int)blockIdx.x / tiles;
+            b0 = ((int)blockIdx.x % tiles) * GT_BS;
+            out_row_u4 = (size_t)tile_info[1];
+            ubeg = split_y * per;
             ksup = nsup - ubeg < per ? nsup - ubeg : per;
-        } else ubeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksup : 0;
+        } else {
+            if (b0 >= count) return;
+            ubeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksup : 0;
+        }
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // 0..3 = m-tile inside a group
@@ -1825,7 +1843,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
                     f32x4 o;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) o[q] = acc[g][c][4 * q4 + q];
-                    *(f32x4*)(out_part + ((size_t)blockIdx.y * out_row_u4 + sample) * NF + 32 * mt + 8 * q4 + 4 * h) = o;
+                    *(f32x4*)(out_part + ((size_t)split_y * out_row_u4 + sample) * NF + 32 * mt + 8 * q4 + 4 * h) = o;
                 }
             } else {
                 float y[16];
@@ -2414,11 +2432,7 @@ static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_
 // K splits of the difference path's fc0 launches (chosen on the device, k_bin_prefix): the full rows up to 30 ways as far as the
 // partial slab holds ways x (the launch's row capacity); window tiles of the split set up to 14 ways (7 super-steps each)
 constexpr int SIB_MAX_WWAYS = 14;
-static int sib_max_fways(const Net& net, int max_count) {
-    const size_t cap_rows = (size_t)((max_count + GT_BS - 1) / GT_BS) * GT_BS;
-    const size_t w = net.part_rows / cap_rows;
-    return w > 30 ? 30 : (w < 1 ? 1 : (int)w);
-}
+static int sib_max_fways(const Net&, int) { return 30; } // (capped on the device by the slab: part_rows / (tiles of full rows x 128))
 // delta = false: copy path (the base row is stored into every child row, the children overwrite their windows; fc0 unchanged).
 // delta = true: difference path (full rows for the runs' bases and the single rows, difference rows for the children; fc0 = launch_fc0_delta).
 static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_count, hipStream_t st, bool delta) {
@@ -2446,17 +2460,21 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         return;
     }
     k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu,
-                                    sib_max_fways(net, max_count), SIB_MAX_WWAYS, (int)std::min<size_t>(net.part_w_rows * 7, (size_t)1 << 30), (int)net.base_slots);
+                                    sib_max_fways(net, max_count), SIB_MAX_WWAYS, (int)std::min<size_t>(net.part_w_rows * 7, (size_t)1 << 30), (int)net.base_slots,
+                                    (int)std::min<size_t>(net.part_rows, (size_t)1 << 30));
     static const bool stats = getenv("OMOK_SIB_STATS") && atoi(getenv("OMOK_SIB_STATS")); // diagnostics only: synchronises every round
     if (stats) {
         static long long acc[8] = {}, launches = 0;
-        int32_t c[8];
+        int32_t c[8], c2[4];
         hipStreamSynchronize(st);
         hipMemcpy(c, net.d_gcnt, sizeof(c), hipMemcpyDeviceToHost);
+        hipMemcpy(c2, net.d_gcnt + 96, sizeof(c2), hipMemcpyDeviceToHost);
+        c[3] = c2[0]; // (runs evaluated in full: base-cache misses + uncacheable runs)
+        c[7] = c2[2]; // (K split of the full-row fc0)
         for (int i = 0; i < 8; ++i) acc[i] += c[i];
         if (++launches % 50 == 0) {
-            fprintf(stderr, "[sib stats] rounds %lld: per round runs %.0f singles %.0f rows-in-runs %.0f (run length %.2f) window tiles %.1f (split set from %.1f, %.1f ways) full-row K split %.1f\n",
-                    launches, acc[0] / 50.0, acc[1] / 50.0, acc[2] / 50.0, acc[0] ? (double)acc[2] / acc[0] : 0.0, acc[4] / 50.0, acc[5] / 50.0, acc[6] / 50.0, acc[7] / 50.0);
+            fprintf(stderr, "[sib stats] rounds %lld: per round runs %.0f (evaluated in full %.0f) singles %.0f rows-in-runs %.0f (run length %.2f) window tiles %.1f (split set from %.1f, %.1f ways) full-row K split %.1f\n",
+                    launches, acc[0] / 50.0, acc[3] / 50.0, acc[1] / 50.0, acc[2] / 50.0, acc[0] ? (double)acc[2] / acc[0] : 0.0, acc[4] / 50.0, acc[5] / 50.0, acc[6] / 50.0, acc[7] / 50.0);
             for (int i = 0; i < 8; ++i) acc[i] = 0;
         }
     }
@@ -2498,18 +2516,19 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
     const int tiles_max = (max_count + GT_BS - 1) / GT_BS;
     const size_t cap_rows = (size_t)tiles_max * GT_BS;
     const int n_cu = net.n_cu;
-    // the live count of full rows is only known on the device: k_bin_prefix chose the K split (d_gcnt[7], at most sib_max_fways)
-    k_fc0_mx<EPI_PARTIAL><<<dim3(tiles_max, sib_max_fways(net, max_count)), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32,
+    // the live count of full rows is only known on the device: k_bin_prefix chose the K split and the partial slab's row stride (d_gcnt[98], [99])
+    const int fgrid = tiles_max > n_cu ? tiles_max : n_cu; // (tiles x ways <= CUs by construction unless there are more tiles than CUs: then 1 way)
+    k_fc0_mx<EPI_PARTIAL><<<dim3(fgrid, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32,
                                                                (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, cap_rows, net.part, net.d_gcnt + 3,
-                                                               max_count, net.d_gcnt + 7, nullptr, nullptr);
-    k_facc_reduce<<<512, 256, 0, st>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 7, net.facc, (const uint2*)net.d_comp, net.d_gcnt + 96, (int)net.base_slots);
+                                                               max_count, net.d_gcnt + 98, nullptr, nullptr);
+    k_facc_reduce<<<512, 256, 0, st>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 98, net.facc, (const uint2*)net.d_comp, net.d_gcnt + 96, (int)net.base_slots);
     // window tiles: whole rounds of workgroups at full K, the tiles of the last partial round split over K (k_bin_prefix)
     const int wtiles_max = (tiles_max + SIB_BINS + 1 + 7) / 8 * 8 + 8; // (the XCD-aware tile mapping rounds an eighth of the tiles up)
     k_fc0_mx<EPI_SPLIT, 0, true><<<dim3(wtiles_max, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
                                                                        (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr, net.d_gcnt, max_count,
                                                                        net.d_tile_info, (const uint2*)net.d_slot_desc, net.facc);
     const int stiles = wtiles_max < n_cu + 8 ? wtiles_max : n_cu + 8;
-    k_fc0_mx<EPI_PARTIAL, 0, true><<<dim3(stiles, SIB_MAX_WWAYS), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
+    k_fc0_mx<EPI_PARTIAL, 0, true><<<dim3(n_cu + 8, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
                                                                      (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, net.part_w_rows, net.part_w, net.d_gcnt,
                                                                      max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, nullptr);
     k_win_finish<<<(unsigned)(((size_t)stiles * GT_BS * 64 + 255) / 256), 256, 0, st>>>(net.part_w, net.part_w_rows, net.d_gcnt, net.d_tile_info,
