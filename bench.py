@@ -358,9 +358,11 @@ def main():
         per_row_x2 = pmc.get(kernel + "_hbm_bytes_per_row")
         # Bytes a launch has to move per request row.  N = 9: trunk = the 384-B-per-pixel operand row it writes, fc0 = that row read once.
         # N = 15 (difference path): trunk = the child's 49-pixel difference row written (18816 B) + the base's 49 entries read
-        # + 1/15 of a full row and of the base's three h grids (one base per run of ~15 siblings); fc0 = the difference row + 1/15 full row.
+        # + per run of ~15 siblings whose base is not cached (22 % of the runs over a configs[1] episode, OMOK_SIB_STATS) a full row written twice
+        # (fc0's compact copy, the base slot) and the base's three h grids; fc0 = the difference row + that share of a full row.
         if n == 15:
-            alg_row = {"k_trunk": 2 * 18816.0 + (384.0 * hw + 3 * hw * 128.0) / 15.0, "k_fc0_mx": 18816.0 + 384.0 * hw / 15.0 + 2048}[kernel]
+            miss = 0.22
+            alg_row = {"k_trunk": 2 * 18816.0 + miss * (2 * 384.0 * hw + 3 * hw * 128.0) / 15.0, "k_fc0_mx": 18816.0 + miss * 384.0 * hw / 15.0 + 2048}[kernel]
         else:
             alg_row = {"k_trunk": 2 * 8 * ((hw + 63) // 64) + 16 + 384.0 * hw, "k_fc0_mx": 384.0 * hw + 2048}[kernel]
         return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
