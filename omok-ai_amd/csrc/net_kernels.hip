@@ -761,9 +761,9 @@ constexpr int GROUP_TREES = 16;
 __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, uint2* __restrict__ groups, int32_t* __restrict__ singles,
                                                              uint4* __restrict__ sib_rows, int32_t* __restrict__ cnt, uint32_t* __restrict__ sib_slot,
                                                              int32_t* __restrict__ tags, uint2* __restrict__ comp) {
-    // Difference path (sib_slot != NULL): base slots.  The FIRST run of a tree uses the game's own slot g, whose content is reused while
-    // tags[g] names the run's parent (a leaf is its tree's expansion target for ~14 rounds); further runs of the tree in the same round
-    // (rare) take a slot behind the games' and are always evaluated.  comp[] lists the (first request row, slot) pairs to evaluate.
+    // Difference path (sib_slot != NULL): base slots.  The FIRST run of a tree uses one of the game's two slots (2 g, 2 g + 1), whose content is
+    // reused while a tag names the run's parent (a leaf is its tree's expansion target for ~14 rounds); further runs of the tree in the same
+    // round (rare) take a slot behind the games' and are always evaluated.  comp[] lists the (first request row, slot) pairs to evaluate.
     __shared__ int l_cnt[3 + SIB_BINS + 2], l_base[3 + SIB_BINS + 2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = blockIdx.x * GROUP_TREES + (tid >> 6);
@@ -802,8 +802,19 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
         rbase = atomicAdd(&l_cnt[2], len);
         if (sib_slot) {
             if (lane == __ffsll((long long)qual) - 1) {
-                bslot = g;
-                if (tags[g] != parent) { tags[g] = parent; mi = atomicAdd(&l_cnt[3 + SIB_BINS], 1); }
+                // two slots per game, most recently used first; a tag = leaf node | slot << 16, -1 = empty (one slot hits 77 % of the
+                // runs of a configs[1] episode, two 86 %, four 88 %: the descent alternates between two leaves while their scores cross)
+                const int t0 = tags[2 * g], t1 = tags[2 * g + 1];
+                int way;
+                if (t0 >= 0 && (t0 & 0xFFFF) == parent) way = t0 >> 16;
+                else if (t1 >= 0 && (t1 & 0xFFFF) == parent) { way = t1 >> 16; tags[2 * g] = t1; tags[2 * g + 1] = t0; }
+                else {
+                    way = t1 >= 0 ? (t1 >> 16) : (t0 >= 0 ? 1 - (t0 >> 16) : 0);
+                    tags[2 * g + 1] = t0;
+                    tags[2 * g] = parent | (way << 16);
+                    mi = atomicAdd(&l_cnt[3 + SIB_BINS], 1);
+                }
+                bslot = 2 * g + way;
             } else {
                 ex = atomicAdd(&l_cnt[3 + SIB_BINS + 1], 1);
                 mi = atomicAdd(&l_cnt[3 + SIB_BINS], 1);
@@ -827,7 +838,7 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
     if (start && len >= SIB_MIN) {
         groups[l_base[0] + gslot] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)len);
         if (sib_slot) {
-            if (ex >= 0) bslot = S.games + l_base[3 + SIB_BINS + 1] + ex;
+            if (ex >= 0) bslot = 2 * S.games + l_base[3 + SIB_BINS + 1] + ex;
             if (mi >= 0) comp[l_base[3 + SIB_BINS] + mi] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)bslot);
         }
     }
@@ -2221,7 +2232,7 @@ size_t net_alloc(Net& net) {
             ok = ok && A((void**)&net.d_singles, sizeof(int32_t) * mb);
             ok = ok && A((void**)&net.d_gcnt, sizeof(int32_t) * SIB_CNT_INTS);
             ok = ok && A((void**)&net.d_sib_rows, sizeof(uint4) * mb);
-            net.base_slots = (size_t)net.games + mb / SIB_MIN + 1; // a slot per game + the other runs a round can hold
+            net.base_slots = (size_t)2 * net.games + mb / SIB_MIN + 1; // two slots per game + the other runs a round can hold
             ok = ok && A((void**)&net.sib_h, sizeof(float) * net.base_slots * 3 * SIB_HB_FLOATS);
             // difference path: slots (bins padded to whole tiles), their difference rows
             net.d_slots = mb + (size_t)(SIB_BINS + 1) * GT_BS;
@@ -2232,7 +2243,7 @@ size_t net_alloc(Net& net) {
             ok = ok && A(&net.d_rows, net.d_slots * (size_t)SIB_DROW_U4 * 16);
             ok = ok && A(&net.a_base, net.base_slots * row_u4 * 16);
             ok = ok && A((void**)&net.facc, sizeof(float) * (net.base_slots + mb) * NF);
-            ok = ok && A((void**)&net.d_tags, sizeof(int32_t) * (size_t)(net.games > 0 ? net.games : 1));
+            ok = ok && A((void**)&net.d_tags, sizeof(int32_t) * (size_t)(net.games > 0 ? 2 * net.games : 2));
             ok = ok && A(&net.d_comp, sizeof(uint2) * (mb / SIB_MIN + 1));
             hipDeviceProp_t prop;
             net.n_cu = (hipGetDeviceProperties(&prop, net.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -2446,7 +2457,7 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
     }
     hipMemsetAsync(net.d_gcnt, 0, sizeof(int32_t) * SIB_CNT_INTS, st);
     if (delta && !net.sib_cache_valid) { // the trees changed since the last search round: no cached base is valid
-        hipMemsetAsync(net.d_tags, 0xFF, sizeof(int32_t) * (size_t)net.games, st);
+        hipMemsetAsync(net.d_tags, 0xFF, sizeof(int32_t) * (size_t)net.games * 2, st);
         net.sib_cache_valid = true;
     }
     k_group<<<(S.games + GROUP_TREES - 1) / GROUP_TREES, 64 * GROUP_TREES, 0, st>>>(S, side, (uint2*)net.d_groups, net.d_singles, (uint4*)net.d_sib_rows, net.d_gcnt,
