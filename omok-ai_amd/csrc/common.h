@@ -118,6 +118,9 @@ void launch_scatter_shared(int n, const Store& S, int side, const float* p_dev, 
                            const uint32_t* sh_cnt, hipStream_t st);
 constexpr int MAX_TREE_WAVES = 16; // one workgroup of 1024 threads
 void launch_scatter(int n, const Store& S, int side, const float* p_dev, const float* v_dev, int max_count, hipStream_t st);
+// the same from the net's logits (softmax / tanh of the split-precision path fused into the policy scatter): writes v, vpre, the trees
+void launch_softmax_scatter(int n, const Store& S, int side, const float* logits_dev, int lrow, float* v_dev, float* vpre_dev, int max_count,
+                            hipStream_t st);
 void launch_sample(int n, const Store& S, int side, int ply, float temperature, int threshold, uint64_t seed,
                    int64_t game_offset, int32_t* actions_dev, hipStream_t st);
 void launch_mirror_scan(int n, const Store& S, int side, hipStream_t st);

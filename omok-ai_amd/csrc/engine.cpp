@@ -594,9 +594,15 @@ static void enqueue_round(omok_engine* e, int round, int K, float eps, float alp
     k_add_evals<<<1, 64, 0, e->st>>>(e->S.d_count, e->d_evals);
     e->prof.end(e->st);
     if (eval_and_scatter) {
-        net_forward_requests(e->net, e->S, alive * K, e->st, &e->prof, side);
+        // the split-precision net hands over its logits: softmax / tanh run inside the policy scatter (no [requests][ROWP] round trip of p)
+        const bool fused = net_logits_cover_batch(e->net, alive * K);
+        net_forward_requests(e->net, e->S, alive * K, e->st, &e->prof, side, fused);
         e->prof.begin(PC_TREE_OTHER, e->st);
-        launch_scatter(e->n, e->S, side, e->net.p, e->net.v, alive * K, e->st);
+        if (fused) {
+            int lrow = 0;
+            const float* lg = net_logits(e->net, &lrow);
+            launch_softmax_scatter(e->n, e->S, side, lg, lrow, e->net.v, e->net.vpre, alive * K, e->st);
+        } else launch_scatter(e->n, e->S, side, e->net.p, e->net.v, alive * K, e->st);
         e->prof.end(e->st);
     }
     e->prof.round_end();

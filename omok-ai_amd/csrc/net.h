@@ -96,7 +96,10 @@ inline int64_t net_tensor_size(int n, int idx) {
 // device; grids are sized for max_count).  Results in net.p / net.v.
 // sibling_side >= 0: the rows are the requests of a search round of that side's trees (S.ts / S.req_node describe them): runs of
 // sibling requests take the incremental trunk path.  -1: plain rows (mirror evaluations, shared-tree rounds).
-void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, struct Prof* prof, int sibling_side = -1);
+// true if a forward of max_count rows leaves ALL its logits in net_logits() (split-precision modes, not chunked): skip_softmax may be used
+bool net_logits_cover_batch(const Net& net, int max_count);
+// skip_softmax (split-precision modes only): stop behind the heads; the caller turns net_logits() into p / v itself (launch_softmax_scatter).
+void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, struct Prof* prof, int sibling_side = -1, bool skip_softmax = false);
 // Forward of explicit f32 inputs already in net.in_f32 ([count][3HW]); count is a host value
 // and must also be stored in S.d_count[0] by the caller.
 void net_forward_inputs(Net& net, const Store& S, int count, hipStream_t st, struct Prof* prof);

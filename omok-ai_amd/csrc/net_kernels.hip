@@ -2546,7 +2546,7 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
                                                                                          (const uint2*)net.d_slot_desc, net.facc, bias_fc0, h0, 128);
 }
 
-static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1) {
+static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1, bool skip_softmax = false) {
     const int hw = net.hw;
     static const int use_sib = getenv("OMOK_TRUNK_SIB") ? atoi(getenv("OMOK_TRUNK_SIB")) : 2; // 0: every row through k_trunk, 1: copy path, 2: difference path
     const bool sib = net.n == 15 && !from_f32 && sib_side >= 0 && use_sib && net.siblings && net.d_groups;
@@ -2628,7 +2628,7 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     if (MT == 8) launch_gemm<8, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
     else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
     const int sg = max_count < 32768 ? max_count : 32768; // one wave per row up to 32 waves per SIMD: the row loop is a chain of dependent loads
-    k_softmax<<<sg, 64, 0, st>>>(net.s0, MT * 32, hw, net.rowp, net.p, net.v, net.vpre, S.d_count, max_count);
+    if (!skip_softmax) k_softmax<<<sg, 64, 0, st>>>(net.s0, MT * 32, hw, net.rowp, net.p, net.v, net.vpre, S.d_count, max_count);
     if (prof) prof->end(st);
 }
 
@@ -2647,10 +2647,10 @@ __global__ void k_chunk_counts(const int32_t* __restrict__ d_count, int max_coun
     out[i * 4] = v < 0 ? 0 : (v > chunk ? chunk : v);
 }
 
-static void forward_chunked(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1) {
+static void forward_chunked(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1, bool skip_softmax = false) {
     static const int chunk_max = getenv("OMOK_NET_CHUNK") ? atoi(getenv("OMOK_NET_CHUNK")) : NET_CHUNK_DEFAULT;
     if (chunk_max <= 0 || max_count <= chunk_max) {
-        forward_f16x3(net, S, max_count, from_f32, st, prof, sib_side);
+        forward_f16x3(net, S, max_count, from_f32, st, prof, sib_side, skip_softmax);
         return;
     }
     int n_chunks = (max_count + chunk_max - 1) / chunk_max;
@@ -2674,14 +2674,19 @@ static void forward_chunked(Net& net, const Store& S, int max_count, bool from_f
     }
 }
 
-void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, Prof* prof, int sibling_side) {
+bool net_logits_cover_batch(const Net& net, int max_count) {
+    static const int chunk_max = getenv("OMOK_NET_CHUNK") ? atoi(getenv("OMOK_NET_CHUNK")) : NET_CHUNK_DEFAULT;
+    return net.mode != OMOK_NET_F32 && max_count <= net.max_b && (chunk_max <= 0 || max_count <= chunk_max);
+}
+
+void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, Prof* prof, int sibling_side, bool skip_softmax) {
     if (max_count <= 0) return;
     if (max_count > net.max_b) max_count = net.max_b;
     if (net.mode == OMOK_NET_F32) {
         launch_encode_requests(net.n, S, net.in_f32, max_count, st);
         forward_f32(net, S, max_count, st, prof);
     } else {
-        forward_chunked(net, S, max_count, false, st, prof, sibling_side);
+        forward_chunked(net, S, max_count, false, st, prof, sibling_side, skip_softmax);
     }
 }
 

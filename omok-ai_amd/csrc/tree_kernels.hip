@@ -874,6 +874,57 @@ __global__ __launch_bounds__(64) void k_scatter_policy(Store S, const float* __r
     }
 }
 
+// k_softmax (net_kernels.hip) + part 1 in one pass for the rounds of the run loop: the probabilities go from registers straight into the
+// node's policy row instead of through a [requests][ROWP] array in HBM and a second kernel.  The softmax is k_softmax's, operation for
+// operation (the step-wise API evaluates with the separate kernels and must produce the same bits), the rest is part 1's.
+template <int N>
+__global__ __launch_bounds__(64) void k_softmax_scatter_policy(Store S, const float* __restrict__ logits, int lrow, float* __restrict__ V,
+                                                               float* __restrict__ Vpre, int max_count) {
+    using G = Geo<N>;
+    constexpr int ROWP = G::ROWP, NW = G::NW, hw = G::HW;
+    int count = S.d_count[0];
+    if (count > max_count) count = max_count;
+    const int lane = LANE;
+    for (int d = blockIdx.x; d < count; d += gridDim.x) {
+        const float* l = logits + (size_t)d * lrow;
+        // (the node's occupancy first: a chain of two dependent loads that runs under the softmax)
+        const uint32_t ref = S.req_ref[d];
+        const size_t tn = (size_t)(ref >> 16) * (size_t)S.cap_nodes + (size_t)(ref & 0xFFFFu);
+        uint64_t occ[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) occ[i] = S.board[tn * (2 * NW) + i] | S.board[tn * (2 * NW) + NW + i];
+        float lv[G::IT];
+#pragma unroll
+        for (int i = 0; i < G::IT; ++i) lv[i] = lane + 64 * i < hw ? l[lane + 64 * i] : -INFINITY;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < G::IT; ++i) mx = fmaxf(mx, lv[i]); // (ascending cells, as k_softmax's loop)
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.0f, row[G::IT];
+#pragma unroll
+        for (int i = 0; i < G::IT; ++i) {
+            const int a = lane + 64 * i;
+            row[i] = 0.0f;
+            if (a < hw) { row[i] = expf(lv[i] - mx); sum += row[i]; }
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0) { V[d] = tanhf(l[hw]); Vpre[d] = l[hw]; }
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const int a = j * 64 + lane;
+            const float p = a < hw ? row[j] / sum : 0.0f;       // the softmax output of this cell
+            const bool empty = a < hw && !((occ[j] >> lane) & 1ULL);
+            row[j] = empty ? p : 0.0f;                           // pme.rs:235-239
+        }
+        const float msum = seq_sum_regs<N>(row);
+        const bool renorm = F32_EPS <= msum;
+        const float inv = renorm ? __fdiv_rn(1.0f, msum) : 1.0f;
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) S.policy[tn * ROWP + j * 64 + lane] = renorm ? row[j] * inv : row[j];
+        if (lane == 0) S.hdr[tn].has_policy = 1;
+    }
+}
+
 // part 2, one wave per TREE: backups in simulation order (the f32 sums of w depend on the order), pme.rs:229,264.
 // The requests of a tree and round are (almost always) children of ONE leaf, so their backups climb the SAME path: it is walked once
 // (lane i keeps the (n, w) slot of the path's level i), every request's value is then added level-parallel in registers -- each
@@ -1803,6 +1854,12 @@ void launch_scan(int n, const Store& S, int side, int K, hipStream_t st) {
 void launch_scatter(int n, const Store& S, int side, const float* p, const float* v, int max_count, hipStream_t st) {
     const int grid = max_count < 8192 ? (max_count > 0 ? max_count : 1) : 8192;
     DISPATCH_N(n, (k_scatter_policy<9><<<grid, 64, 0, st>>>(S, p, max_count)), (k_scatter_policy<15><<<grid, 64, 0, st>>>(S, p, max_count)));
+    DISPATCH_N(n, (k_scatter<9><<<S.games, 64, 0, st>>>(S, side, v)), (k_scatter<15><<<S.games, 64, 0, st>>>(S, side, v)));
+}
+void launch_softmax_scatter(int n, const Store& S, int side, const float* logits, int lrow, float* v, float* vpre, int max_count, hipStream_t st) {
+    const int grid = max_count < 8192 ? (max_count > 0 ? max_count : 1) : 8192;
+    DISPATCH_N(n, (k_softmax_scatter_policy<9><<<grid, 64, 0, st>>>(S, logits, lrow, v, vpre, max_count)),
+               (k_softmax_scatter_policy<15><<<grid, 64, 0, st>>>(S, logits, lrow, v, vpre, max_count)));
     DISPATCH_N(n, (k_scatter<9><<<S.games, 64, 0, st>>>(S, side, v)), (k_scatter<15><<<S.games, 64, 0, st>>>(S, side, v)));
 }
 void launch_sample(int n, const Store& S, int side, int ply, float temperature, int threshold, uint64_t seed,
