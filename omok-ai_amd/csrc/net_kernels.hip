@@ -2623,10 +2623,10 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
         }
     }
     if (prof) { prof->end(st); prof->begin(PC_TAIL, st); }
-    launch_gemm<16, EPI_SPLIT, 1, 4>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st, net.device);
+    launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st, net.device);
     const int MT = heads_mt(hw);
-    if (MT == 8) launch_gemm<8, EPI_LOGITS, 2, 6>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
-    else launch_gemm<4, EPI_LOGITS, 2, 6>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
+    if (MT == 8) launch_gemm<8, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
+    else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
     const int sg = max_count < 32768 ? max_count : 32768; // one wave per row up to 32 waves per SIMD: the row loop is a chain of dependent loads
     if (!skip_softmax) k_softmax<<<sg, 64, 0, st>>>(net.s0, MT * 32, hw, net.rowp, net.p, net.v, net.vpre, S.d_count, max_count);
     if (prof) prof->end(st);
