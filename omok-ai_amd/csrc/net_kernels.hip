@@ -729,7 +729,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
 // COPY path: every pixel goes through the same operations in the same order as in k_trunk (MFMA columns are independent, the
 // depthwise taps accumulate in (dy, dx) order, operand-row entries are per pixel), so the rows are BIT-IDENTICAL to a full
 // evaluation.  DIFFERENCE path: one more rounding (the quantisation of the difference), |dp| < 1e-4 measured; rounds of fewer than
-// 6144 rows stay on the copy path (forward_f16x3).  DESIGN.md 3.3.
+// 3072 rows stay on the copy path (forward_f16x3).  DESIGN.md 3.3.
 constexpr int SIB_MIN = 3;                       // runs shorter than this go to k_trunk (a base pass would not pay)
 constexpr int SIB_WIN = 7, SIB_GW = SIB_WIN + 2; // window side, child grid side (window + halo ring)
 constexpr int SIB_CGRID_ROWS = SIB_GW * SIB_GW + 1;
@@ -2551,9 +2551,9 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     static const int use_sib = getenv("OMOK_TRUNK_SIB") ? atoi(getenv("OMOK_TRUNK_SIB")) : 2; // 0: every row through k_trunk, 1: copy path, 2: difference path
     const bool sib = net.n == 15 && !from_f32 && sib_side >= 0 && use_sib && net.siblings && net.d_groups;
     // Small rounds (the thin tail of an episode) take the copy path: the difference path needs one fc0 tile per non-empty window bin
-    // (81 + 1) however few rows there are, the copy path rows / 128 tiles of the full K -- measured break-even between 4096 and 8192 rows.  The choice is a
+    // (81 + 1) however few rows there are, the copy path rows / 128 tiles of the full K -- measured break-even between 2048 and 4096 rows.  The choice is a
     // function of the host's bound on the request count (alive games x K) only, so a run is reproducible.
-    static const int delta_min_rows = getenv("OMOK_SIB_DELTA_MIN") ? atoi(getenv("OMOK_SIB_DELTA_MIN")) : 6144;
+    static const int delta_min_rows = getenv("OMOK_SIB_DELTA_MIN") ? atoi(getenv("OMOK_SIB_DELTA_MIN")) : 3072;
     const bool delta = sib && use_sib >= 2 && max_count >= delta_min_rows;
     if (prof) prof->begin(PC_TRUNK, st);
     if (sib) launch_trunk_siblings(net, S, sib_side, max_count, st, delta);

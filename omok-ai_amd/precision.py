@@ -42,7 +42,7 @@ def measure(tensors, n, inputs, device=0, batch_k=16):
 def measure_search_rounds(tensors, n, games=64, batch_k=16, rounds=6, plies=3, device=0, seed=1):
     """The same comparison for the outputs of search rounds: plays `plies` plies of `rounds` rounds on `games` trees with the
     product engine and compares every round's p / v with the fp32 kernels' evaluation of the same request rows.  (At board_size
-    15 only rounds of >= 6144 rows take the difference path: games * batch_k must reach that for the check to cover it.)"""
+    15 only rounds of >= 3072 rows take the difference path: games * batch_k must reach that for the check to cover it.)"""
     eng = api.Engine(board_size=n, games=games, max_nodes=max(1024, 2 * rounds * batch_k), max_tables=256, max_batch_k=batch_k, device=device,
                      seed=seed, net_mode=B.NET_F16X3)
     eng.load_weights(tensors)

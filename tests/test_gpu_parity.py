@@ -272,7 +272,7 @@ def test_net_precision_after_training_steps(n):
 @pytest.mark.parametrize("games,path", [(40, "copy"), (448, "difference")])
 def test_search_round_outputs_on_the_sibling_path(games, path):
     """The p / v a SEARCH ROUND produces at N = 15 against the fp32 kernels and against the row-by-row path (evaluate_pv) of the same
-    engine, on the very request rows of the rounds.  Rounds of >= 6144 rows take the difference path (base row + window difference
+    engine, on the very request rows of the rounds.  Rounds of >= 3072 rows take the difference path (base row + window difference
     rows, DESIGN 3.3: different rounding, inside the contract), smaller rounds the copy path (bit-identical to row-by-row)."""
     n, k, count = 15, 16, 96
     tensors = oa.weights.init_random(n, seed=3)
