@@ -872,16 +872,17 @@ __device__ inline int sib_bin_at(int pos) { // layout position -> bin
 __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, int32_t* __restrict__ bin_start, int32_t* __restrict__ tile_info,
                                                     uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu, int max_fways,
                                                     int max_wways, int part_w_rows, int facc_single_base, int part_f_rows) {
-    __shared__ int tile0[SIB_BINS + 2];
+    __shared__ int tile0[SIB_BINS + 2], binc[SIB_BINS + 1];
     const int tid = threadIdx.x;
     const int c = tid < SIB_BINS ? cnt[8 + tid] : (tid == SIB_BINS ? cnt[1] : 0);
+    if (tid <= SIB_BINS) binc[tid] = c;
+    __syncthreads();
     if (tid == 0) {
         int t = 0;
-        for (int pos = 0; pos <= SIB_BINS; ++pos) {
+        for (int pos = 0; pos <= SIB_BINS; ++pos) { // (counts from LDS: 82 serial global loads were most of this kernel's 16 us)
             const int b = sib_bin_at(pos);
             tile0[b] = t;
-            const int cb = b < SIB_BINS ? cnt[8 + b] : cnt[1];
-            t += (cb + GT_BS - 1) / GT_BS;
+            t += (binc[b] + GT_BS - 1) / GT_BS;
         }
         const int ntiles = t;
         int t_split = ntiles - (ntiles < n_cu ? ntiles : ntiles % n_cu); // first tile of the partial round ...
@@ -2444,6 +2445,9 @@ static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_
 // partial slab holds ways x (the launch's row capacity); window tiles of the split set up to 14 ways (7 super-steps each)
 constexpr int SIB_MAX_WWAYS = 14;
 static int sib_max_fways(const Net&, int) { return 30; } // (capped on the device by the slab: part_rows / (tiles of full rows x 128))
+__global__ void k_zero_ints(int32_t* __restrict__ p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
 // delta = false: copy path (the base row is stored into every child row, the children overwrite their windows; fc0 unchanged).
 // delta = true: difference path (full rows for the runs' bases and the single rows, difference rows for the children; fc0 = launch_fc0_delta).
 static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_count, hipStream_t st, bool delta) {
@@ -2455,7 +2459,7 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         hipFuncSetAttribute((const void*)k_sib_children<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done[net.device & 63] = true;
     }
-    hipMemsetAsync(net.d_gcnt, 0, sizeof(int32_t) * SIB_CNT_INTS, st);
+    k_zero_ints<<<1, 128, 0, st>>>(net.d_gcnt, SIB_CNT_INTS); // (a hipMemsetAsync of these 448 bytes is a 13-us fill kernel)
     if (delta && !net.sib_cache_valid) { // the trees changed since the last search round: no cached base is valid
         hipMemsetAsync(net.d_tags, 0xFF, sizeof(int32_t) * (size_t)net.games * 2, st);
         net.sib_cache_valid = true;
