@@ -99,6 +99,7 @@ struct RoundArgs {
     float epsilon, alpha;
     uint64_t seed; // Philox key of the current episode: cfg.seed + episode * 0x9E3779B97F4A7C15 (DESIGN.md "RNG contract")
     int64_t game_offset;
+    const float* scatter_v; // non-NULL: the PREVIOUS round's backups (k_scatter with these values) run at the head of this round's kernel
 };
 
 // ---- tree_kernels.hip launchers (all asynchronous on `st`) ---------------------------------
@@ -117,10 +118,12 @@ void launch_round_shared(int n, const Store& S, const RoundArgs& a, int rounds_t
 void launch_scatter_shared(int n, const Store& S, int side, const float* p_dev, const float* v_dev, int max_count, int waves, const uint16_t* sh_req,
                            const uint32_t* sh_cnt, hipStream_t st);
 constexpr int MAX_TREE_WAVES = 16; // one workgroup of 1024 threads
-void launch_scatter(int n, const Store& S, int side, const float* p_dev, const float* v_dev, int max_count, hipStream_t st);
+// backups = false: the policies only; the backups (k_scatter) are deferred to launch_backups or into the next round's kernel (RoundArgs::scatter_v)
+void launch_scatter(int n, const Store& S, int side, const float* p_dev, const float* v_dev, int max_count, hipStream_t st, bool backups = true);
+void launch_backups(int n, const Store& S, int side, const float* v_dev, hipStream_t st);
 // the same from the net's logits (softmax / tanh of the split-precision path fused into the policy scatter): writes v, vpre, the trees
 void launch_softmax_scatter(int n, const Store& S, int side, const float* logits_dev, int lrow, float* v_dev, float* vpre_dev, int max_count,
-                            hipStream_t st);
+                            hipStream_t st, bool backups = true);
 void launch_sample(int n, const Store& S, int side, int ply, float temperature, int threshold, uint64_t seed,
                    int64_t game_offset, int32_t* actions_dev, hipStream_t st);
 void launch_mirror_scan(int n, const Store& S, int side, hipStream_t st);

@@ -582,9 +582,12 @@ static int need_reset(omok_engine* e) {
     return 0;
 }
 
-static void enqueue_round(omok_engine* e, int round, int K, float eps, float alpha, bool eval_and_scatter, int alive) {
+// defer_backups (run loops): this round's backups are not launched here; pending_backups: the previous round's run at the head of this round's
+// kernel.  The caller launches the last round's backups itself (launch_backups).
+static void enqueue_round(omok_engine* e, int round, int K, float eps, float alpha, bool eval_and_scatter, int alive, bool defer_backups = false,
+                          bool pending_backups = false) {
     const int side = e->ply & 1;
-    RoundArgs a{side, round, K, e->ply, eps, alpha, e->key, e->cfg.game_offset};
+    RoundArgs a{side, round, K, e->ply, eps, alpha, e->key, e->cfg.game_offset, pending_backups ? e->net.v : nullptr};
     e->prof.round_begin();
     e->prof.begin(PC_ROUND, e->st);
     launch_round(e->n, e->S, a, e->st);
@@ -601,8 +604,8 @@ static void enqueue_round(omok_engine* e, int round, int K, float eps, float alp
         if (fused) {
             int lrow = 0;
             const float* lg = net_logits(e->net, &lrow);
-            launch_softmax_scatter(e->n, e->S, side, lg, lrow, e->net.v, e->net.vpre, alive * K, e->st);
-        } else launch_scatter(e->n, e->S, side, e->net.p, e->net.v, alive * K, e->st);
+            launch_softmax_scatter(e->n, e->S, side, lg, lrow, e->net.v, e->net.vpre, alive * K, e->st, !defer_backups);
+        } else launch_scatter(e->n, e->S, side, e->net.p, e->net.v, alive * K, e->st, !defer_backups);
         e->prof.end(e->st);
     }
     e->prof.round_end();
@@ -611,9 +614,14 @@ static void enqueue_round(omok_engine* e, int round, int K, float eps, float alp
 static int enqueue_execute(omok_engine* e, int count, int K, float eps, float alpha, int alive) {
     int processed = 0, round = 0;
     while (processed < count) { // pme.rs:39-42,207
-        enqueue_round(e, round, K, eps, alpha, true, alive);
+        enqueue_round(e, round, K, eps, alpha, true, alive, true, round > 0);
         processed += K;
         round += 1;
+    }
+    if (round > 0) { // the last round's backups
+        e->prof.begin(PC_TREE_OTHER, e->st);
+        launch_backups(e->n, e->S, e->ply & 1, e->net.v, e->st);
+        e->prof.end(e->st);
     }
     return round;
 }

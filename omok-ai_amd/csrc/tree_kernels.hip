@@ -555,6 +555,10 @@ __global__ __launch_bounds__(64) void k_round(Store S, RoundArgs A) {
     const Tree<N> T(S, t);
     const TreeState ts = *T.ts;
     Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
+    if (A.scatter_v && ts.n_req > 0) { // the previous round's backups, deferred into this kernel (run loop)
+        scatter_tree<N>(S, T, ts, R, A.scatter_v);
+        R.dirty = true;
+    }
     // RNG streams are keyed by the GAME (its global id and its own ply), not by the slot or the engine's ply counter: in an episode the
     // two coincide; in slots mode a slot's later games have their own ids and start their plies at 0
     A.ply = gs0.plies;
@@ -932,18 +936,13 @@ __global__ __launch_bounds__(64) void k_softmax_scatter_policy(Store S, const fl
 // Node::propagate applies them -- and stored once.  Per request only its own (fresh) slot in the leaf's table is touched, by its own
 // lane.  That is 3 dependent loads per level of the path instead of per level AND request.  Requests with different parents (a
 // backup of a terminal node between them moved the descent) take the plain per-request walk.
+// (device function: k_scatter proper, and the head of k_round when the run loop defers a round's backups into the next round's kernel --
+//  the backups then warm the very nodes the descent reads, and the round needs one launch less)
 template <int N>
-__global__ __launch_bounds__(64) void k_scatter(Store S, int side, const float* __restrict__ V) {
+__device__ inline void scatter_tree(const Store& S, const Tree<N>& T, const TreeState& ts, Regs& R, const float* __restrict__ V) {
     using G = Geo<N>;
     constexpr int ROWP = G::ROWP;
-    const int g = blockIdx.x;
-    if (!S.gs[g].alive) return;
-    const int t = side * S.games + g;
-    const Tree<N> T(S, t);
-    const TreeState ts = *T.ts;
-    if (ts.n_req == 0) return;
     const int lane = LANE, nreq = (int)ts.n_req;
-    Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
     // every request's node, its parent and action (one lane per request; n_req <= KMAX = 64)
     int x = 0, par = -1, act = 0;
     float val = 0.0f;
@@ -1004,6 +1003,18 @@ __global__ __launch_bounds__(64) void k_scatter(Store S, int side, const float* 
             R.bytes += 8ull * G::HW + 4;
         }
     }
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_scatter(Store S, int side, const float* __restrict__ V) {
+    const int g = blockIdx.x;
+    if (!S.gs[g].alive) return;
+    const int t = side * S.games + g;
+    const Tree<N> T(S, t);
+    const TreeState ts = *T.ts;
+    if (ts.n_req == 0) return;
+    Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
+    scatter_tree<N>(S, T, ts, R, V);
     if (LANE == 0) {
         TreeState o = ts;
         o.root_n = R.root_n; o.root_w = R.root_w; o.n_req = 0;
@@ -1851,16 +1862,20 @@ void launch_scan(int n, const Store& S, int side, int K, hipStream_t st) {
     k_scan<<<1, 1024, 0, st>>>(S, side);
     k_fill<<<(S.games * K + 255) / 256, 256, 0, st>>>(S, side, K);
 }
-void launch_scatter(int n, const Store& S, int side, const float* p, const float* v, int max_count, hipStream_t st) {
+void launch_scatter(int n, const Store& S, int side, const float* p, const float* v, int max_count, hipStream_t st, bool backups) {
     const int grid = max_count < 8192 ? (max_count > 0 ? max_count : 1) : 8192;
     DISPATCH_N(n, (k_scatter_policy<9><<<grid, 64, 0, st>>>(S, p, max_count)), (k_scatter_policy<15><<<grid, 64, 0, st>>>(S, p, max_count)));
+    if (backups) launch_backups(n, S, side, v, st);
+}
+void launch_backups(int n, const Store& S, int side, const float* v, hipStream_t st) {
     DISPATCH_N(n, (k_scatter<9><<<S.games, 64, 0, st>>>(S, side, v)), (k_scatter<15><<<S.games, 64, 0, st>>>(S, side, v)));
 }
-void launch_softmax_scatter(int n, const Store& S, int side, const float* logits, int lrow, float* v, float* vpre, int max_count, hipStream_t st) {
+void launch_softmax_scatter(int n, const Store& S, int side, const float* logits, int lrow, float* v, float* vpre, int max_count, hipStream_t st,
+                            bool backups) {
     const int grid = max_count < 8192 ? (max_count > 0 ? max_count : 1) : 8192;
     DISPATCH_N(n, (k_softmax_scatter_policy<9><<<grid, 64, 0, st>>>(S, logits, lrow, v, vpre, max_count)),
                (k_softmax_scatter_policy<15><<<grid, 64, 0, st>>>(S, logits, lrow, v, vpre, max_count)));
-    DISPATCH_N(n, (k_scatter<9><<<S.games, 64, 0, st>>>(S, side, v)), (k_scatter<15><<<S.games, 64, 0, st>>>(S, side, v)));
+    if (backups) launch_backups(n, S, side, v, st);
 }
 void launch_sample(int n, const Store& S, int side, int ply, float temperature, int threshold, uint64_t seed,
                    int64_t game_offset, int32_t* actions, hipStream_t st) {
