@@ -111,7 +111,7 @@ void launch_harvest(int n, const Store& S, uint8_t* mask_dev /*[G]*/, long long*
                     uint8_t* dst_dev, long long cap_records, hipStream_t st);
 void launch_refill(int n, const Store& S, const float* root_policy_dev, int32_t* next_gid_dev, int total_games, int32_t* new_gid_dev /*[G]*/, hipStream_t st);
 void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st);
-void launch_scan(int n, const Store& S, int side, int K, hipStream_t st);
+void launch_scan(int n, const Store& S, int side, int K, hipStream_t st, unsigned long long* evals_dev = nullptr); // evals_dev[0] += the round's requests
 // one tree searched by `waves` waves (MCTSExecutor::run): sh_req [waves][KMAX] u16, sh_cnt [2 * KMAX] u32 (counts | bases)
 void launch_round_shared(int n, const Store& S, const RoundArgs& a, int rounds_total, int group, int waves, uint16_t* sh_req, uint32_t* sh_cnt,
                          hipStream_t st);

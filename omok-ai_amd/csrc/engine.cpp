@@ -593,8 +593,7 @@ static void enqueue_round(omok_engine* e, int round, int K, float eps, float alp
     launch_round(e->n, e->S, a, e->st);
     e->prof.end(e->st);
     e->prof.begin(PC_TREE_OTHER, e->st);
-    launch_scan(e->n, e->S, side, K, e->st);
-    k_add_evals<<<1, 64, 0, e->st>>>(e->S.d_count, e->d_evals);
+    launch_scan(e->n, e->S, side, K, e->st, e->d_evals);
     e->prof.end(e->st);
     if (eval_and_scatter) {
         // the split-precision net hands over its logits: softmax / tanh run inside the policy scatter (no [requests][ROWP] round trip of p)

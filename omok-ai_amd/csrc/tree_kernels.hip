@@ -792,7 +792,7 @@ __global__ __launch_bounds__(1024) void k_scatter_shared(Store S, int side, cons
 // ---------------------------------------------------------------------------------------------
 // k_scan: dense, order-preserving request list over the live trees of one side
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan(Store S, int side) {
+__global__ __launch_bounds__(1024) void k_scan(Store S, int side, unsigned long long* __restrict__ evals) {
     // exclusive scan of the per-tree request counts in game order: each thread owns a contiguous chunk of
     // games, chunk sums are scanned with wave shuffles (64 lanes) and a 16-entry LDS table
     __shared__ uint32_t s_wave[16];
@@ -828,7 +828,10 @@ __global__ __launch_bounds__(1024) void k_scan(Store S, int side) {
             run += S.ts[t].n_req;
         }
     }
-    if (tid == 0) S.d_count[0] = (int32_t)total;
+    if (tid == 0) {
+        S.d_count[0] = (int32_t)total;
+        if (evals) evals[0] += total; // (the evaluation counter of the stats: one launch less per round than a kernel of its own)
+    }
 }
 
 // dense request list (tree, node) in tree order then simulation order (pme.rs:194-205)
@@ -1858,8 +1861,8 @@ void launch_scatter_shared(int n, const Store& S, int side, const float* p, cons
     DISPATCH_N(n, (k_scatter_shared<9><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt)),
                (k_scatter_shared<15><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt)));
 }
-void launch_scan(int n, const Store& S, int side, int K, hipStream_t st) {
-    k_scan<<<1, 1024, 0, st>>>(S, side);
+void launch_scan(int n, const Store& S, int side, int K, hipStream_t st, unsigned long long* evals) {
+    k_scan<<<1, 1024, 0, st>>>(S, side, evals);
     k_fill<<<(S.games * K + 255) / 256, 256, 0, st>>>(S, side, K);
 }
 void launch_scatter(int n, const Store& S, int side, const float* p, const float* v, int max_count, hipStream_t st, bool backups) {
