@@ -735,6 +735,7 @@ constexpr int SIB_WIN = 7, SIB_GW = SIB_WIN + 2; // window side, child grid side
 constexpr int SIB_CGRID_ROWS = SIB_GW * SIB_GW + 1;
 constexpr int SIB_CGRID_BYTES = SIB_CGRID_ROWS * GRID_STRIDE * 4; // 11808
 constexpr int SIB_HB_FLOATS = 225 * NM;          // one base h grid in the scratch: [pixel][32]
+constexpr int SIB_PAIR_CUT1 = 289, SIB_PAIR_CUT2 = 578, SIB_PAIR_CUT3 = 801; // shares of a workgroup's children per wave pair, cumulative / 1024 (k_sib_children)
 // difference path: window bins (window origin (wy0, wx0) in 0..8 each), the single rows as bin SIB_BINS, counters, difference rows
 constexpr int SIB_ORG = 15 - SIB_WIN + 1, SIB_BINS = SIB_ORG * SIB_ORG; // 9, 81
 constexpr int SIB_CNT_INTS = 8 + SIB_BINS + 7 + 16;                       // d_gcnt: 8 counters, bin counts (96 ints), [96] full evaluations of runs (base-cache
@@ -1026,7 +1027,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
         asm volatile("" ::: "memory");
     };
     auto lds_barrier = [&]() { bar_post(); bar_wait(); };
-    for (int i = 0; i < 2 * (wv >> 1); ++i) __builtin_amdgcn_s_sleep(94); // (64 clocks per unit: ~6 us per pair index)
+    for (int i = 0; i < (wv >> 1); ++i) __builtin_amdgcn_s_sleep(118); // (64 clocks per unit: a quarter of a ~30 k-cycle pass per pair index)
     const int nsib = d_cnt[2];
     const half8* convW = (const half8*)(wt + TR_WBYTES / 16);
     // conv_in fragments: 32 registers that are only needed at the top of a pass.  They are fetched again at the END of every pass (from
@@ -1213,10 +1214,16 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
     // A child's descriptor and board words are fetched ONE PASS AHEAD (a dependent pair of loads: their latency runs under the
     // current pass), its halo ring ONE BLOCK ahead.
     f32x16 x[4];
-    constexpr int pass_stride = 4;
-    const int per_wg = ((nsib + (int)gridDim.x - 1) / (int)gridDim.x + 3) & ~3;
-    const int e_begin = (int)blockIdx.x * per_wg, e_end = e_begin + per_wg < nsib ? e_begin + per_wg : nsib;
-    auto entry_of = [&](int e0) { const int ei = e0 + pair; return ei < e_end ? ei : (e0 < e_end ? e0 : (e_begin < nsib ? e_begin : 0)); }; // this pair's child in the pass at e0
+    // ... and inside the workgroup every PAIR takes its own contiguous part of that range and walks it at its own pace: pairs share nothing but
+    // read-only LDS, and the waves launched first (pairs 0, 1) get the issue slots of their SIMDs first -- in lockstep the workgroup ran at
+    // the pace of pairs 2, 3 (2.42 M cycles per launch against 2.01 M for pair 0).  The parts are sized by those speeds (SIB_PAIR_CUT / 1024).
+    constexpr int pass_stride = 1;
+    const int per_wg = (nsib + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int wg_begin = (int)blockIdx.x * per_wg < nsib ? (int)blockIdx.x * per_wg : nsib, wg_end = wg_begin + per_wg < nsib ? wg_begin + per_wg : nsib;
+    const int cut_lo = pair == 0 ? 0 : pair == 1 ? SIB_PAIR_CUT1 : pair == 2 ? SIB_PAIR_CUT2 : SIB_PAIR_CUT3;
+    const int cut_hi = pair == 0 ? SIB_PAIR_CUT1 : pair == 1 ? SIB_PAIR_CUT2 : pair == 2 ? SIB_PAIR_CUT3 : 1024;
+    const int e_begin = wg_begin + (int)(((long long)(wg_end - wg_begin) * cut_lo) >> 10), e_end = wg_begin + (int)(((long long)(wg_end - wg_begin) * cut_hi) >> 10);
+    auto entry_of = [&](int e0) { return e0 < e_end ? e0 : (e_begin < nsib ? e_begin : 0); }; // this pair's child in the pass at e0
     auto fetch_desc = [&](int e0) { return sib_rows[entry_of(e0)]; };
     auto fetch_slot = [&](int e0) { return DELTA ? sib_slot[entry_of(e0)] : 0u; };
     auto fetch_word = [&](const uint4& ent) { // lanes 0..7: the child's board words
@@ -1365,9 +1372,9 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
     uint64_t word_c = fetch_word(ent_c);
     window_of(ent_c, wy0, wx0);
     ring_fetch(hscr + (size_t)ent_c.y * 3 * SIB_HB_FLOATS, 0, wy0, wx0, ring);
-    for (int e0 = e_begin; e0 < e_end; e0 += pass_stride) { // four children per pass; uniform over the workgroup
+    for (int e0 = e_begin; e0 < e_end; e0 += pass_stride) { // one child per pass and pair; uniform over the pair
         if (TPROF) tp_last = __builtin_readcyclecounter();
-        const bool act = e0 + pair < e_end;
+        const bool act = e0 < e_end;
         const uint4 ent = ent_c;
         const int crow = (int)ent.x;
         hb = hscr + (size_t)ent.y * 3 * SIB_HB_FLOATS;
@@ -1435,6 +1442,11 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
     }
     if (TPROF && lane == 0 && (wv == 0 || wv == 5))
         for (int i = 0; i < 9; ++i) atomicAdd(&tprof[(wv ? 16 : 0) + i], tp_acc[i]);
+    if (TPROF && lane == 0 && (wv & 1) == 0) { // per pair: cycles in the loop (all phases)
+        unsigned long long t = 0;
+        for (int i = 0; i < 9; ++i) t += tp_acc[i];
+        atomicAdd(&tprof[28 + (wv >> 1)], t);
+    }
 }
 
 // ===============================================================================================
@@ -2516,6 +2528,8 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
                 for (int i = 0; i < 9; ++i) fprintf(stderr, "%s %.1f%%  ", names[i], 100.0 * (double)acc[16 * w + i] / tot);
                 fprintf(stderr, " | %.0f cycles per workgroup and launch\n", tot / 256.0 / launches);
             }
+            fprintf(stderr, "[sib prof] cycles in the loop per pair, workgroup and launch: %.0f %.0f %.0f %.0f\n", (double)acc[28] / 256.0 / launches,
+                    (double)acc[29] / 256.0 / launches, (double)acc[30] / 256.0 / launches, (double)acc[31] / 256.0 / launches);
         }
         return;
     }
