@@ -365,7 +365,9 @@ def main():
             alg_row = {"k_trunk": 2 * 18816.0 + miss * (2 * 384.0 * hw + 3 * hw * 128.0) / 15.0, "k_fc0_mx": 18816.0 + miss * 384.0 * hw / 15.0 + 2048}[kernel]
         else:
             alg_row = {"k_trunk": 2 * 8 * ((hw + 63) // 64) + 16 + 384.0 * hw, "k_fc0_mx": 384.0 * hw + 2048}[kernel]
-        return {"bound": "mfma", "kernel": kernel, "achieved": ach, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+        members = {"k_trunk": "k_sib_children + k_trunk<BASE> + k_trunk<rows> + k_group + k_bin_prefix (N = 15 search rounds); k_trunk otherwise",
+                   "k_fc0_mx": "k_fc0_mx<full rows, split-K> + k_facc_reduce + k_fc0_mx<window tiles> + k_win_finish (N = 15 search rounds); k_fc0_mx (+ k_splitk_finish) otherwise"}[kernel]
+        return {"bound": "mfma", "kernel": kernel, "kernel_members": members, "achieved": ach, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / F16_DENSE_PEAK_TFLOPS, "traffic": per_row * rows / launches if per_row else None,
                 "traffic_uncalibrated_x2": per_row_x2 * rows / launches if per_row_x2 else None,
                 "traffic_unit": "HBM bytes per (average) launch: per-row bytes of the committed rocprofv3 --pmc pass (profiles/pmc_bytes.json: "
