@@ -253,7 +253,8 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                                                                     uint4* __restrict__ a_out, size_t row_u4, int max_count,
                                                                     const int32_t* __restrict__ row_list, const int32_t* __restrict__ d_nrows,
                                                                     const uint2* __restrict__ groups, float* __restrict__ hscr,
-                                                                    const int32_t* __restrict__ d_out_base, uint4* __restrict__ a_base) {
+                                                                    const int32_t* __restrict__ d_out_base, uint4* __restrict__ a_base,
+                                                                    const int32_t* __restrict__ d_nrows2) {
     // row_list != NULL: the kernel evaluates the request rows row_list[0 .. d_nrows[0]) (the rows outside the sibling runs).
     // BASE: sample i is the BASE position of sibling run groups[i] -- the parent's board with the children's side to move; the
     // depthwise inputs of its three blocks go to hscr[i][blk][pixel][32] and its operand row into every child row of the run
@@ -280,9 +281,14 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
     for (int i = tid; i < TG::SPW * (TG::GRID_BYTES / 4); i += blockDim.x) ((float*)(smem + TR_WBYTES))[i] = 0.0f;
     __syncthreads();
     int count = (row_list || BASE) ? d_nrows[0] : d_count[0];
+    // BASE with d_nrows2: behind the runs' base positions the same launch evaluates the round's SINGLE rows (row_list, d_nrows2[0] of them: requests
+    // outside sibling runs -- their own board, no h grids, no base slot); a launch of their own cost 18 us per round for a handful of rows
+    const int n_base = count;
+    if (BASE && d_nrows2) count += d_nrows2[0];
     if (count > max_count) count = max_count;
+    auto single = [&](int i) { return BASE && i >= n_base; };
     auto rowof = [&](int i) { return BASE ? i : (row_list ? (int)row_list[i] : i); };                 // output row (and request row) of sample i
-    auto refof = [&](int i) { return BASE ? req_ref[groups[i].x] : req_ref[rowof(i)]; };              // BASE: the run's first child
+    auto refof = [&](int i) { return BASE ? (single(i) ? req_ref[row_list[i - n_base]] : req_ref[groups[i].x]) : req_ref[rowof(i)]; }; // BASE: the run's first child
     auto auxof = [&](int i) { return BASE ? 0xFFFFFFFFu : req_aux[rowof(i)]; };
     // depthwise work items are dealt to lanes in the order of the ds_read_b128 lane groups ({0-3,12-15,20-27},
     // {4-11,16-19,28-31} per half): each group then holds two strips 8 pixels apart = 16 distinct 16-B slots of the
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
         int turn;
         float f[3];
     };
-    auto load_in = [&](int b, uint32_t ref, uint32_t aux) {
+    auto load_in = [&](int b, uint32_t ref, uint32_t aux, bool own_board) {
         SampleIn in;
         in.aux = aux;
         in.turn = 0;
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
         } else {
             const size_t tn = (size_t)(ref >> 16) * (size_t)cap_nodes + (size_t)(ref & 0xFFFFu);
             size_t tb = tn;
-            if (BASE) tb = (size_t)(ref >> 16) * (size_t)cap_nodes + (size_t)(((const uint32_t*)hdr)[tn * 4] & 0xFFFFu); // NodeHdr::parent: the board without the child's stone
+            if (BASE && !own_board) tb = (size_t)(ref >> 16) * (size_t)cap_nodes + (size_t)(((const uint32_t*)hdr)[tn * 4] & 0xFFFFu); // NodeHdr::parent: the board without the child's stone
 #pragma unroll
             for (int i = 0; i < 2 * NW; ++i) in.bb[i] = board[tb * (2 * NW) + i];
             in.turn = (int)((((const uint32_t*)hdr)[tn * 4 + 2] >> 16) & 0xFFu); // NodeHdr::turn (byte 10) through a dword: scalar load
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
     const int b_stride = (int)gridDim.x * TG::SPW;
     uint32_t ref_n = 0, aux_n = 0xFFFFFFFFu;
     if (!FROM_F32 && b_first < count) { ref_n = refof(b_first); aux_n = auxof(b_first); }
-    SampleIn in = load_in(b_first < count ? rowof(b_first) : 0, ref_n, aux_n);
+    SampleIn in = load_in(b_first < count ? rowof(b_first) : 0, ref_n, aux_n, single(b_first));
 
     for (int b0 = (int)blockIdx.x * TG::SPW; b0 < count; b0 += b_stride) { // uniform trip count over the workgroup (barriers inside)
         const int bi = b0 + slot;
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                 }
             }
             lds_barrier(); // B2: h of the whole sample is in the halo grid
-            if (BASE && active) { // the base's depthwise input of this block -> scratch: the children's halo rings read it (225 pixels x 8 pieces of 16 B)
+            if (BASE && active && !single(bi)) { // the base's depthwise input of this block -> scratch: the children's halo rings read it (225 pixels x 8 pieces of 16 B)
                 for (int i = stid; i < HW * 8; i += TG::THREADS) {
                     const int p = i >> 3, piece = i & 7;
                     *(uint4*)(hscr + ((size_t)(DELTA ? (int)groups[bi].y : b) * 3 + blk) * (HW * NM) + p * NM + piece * 4) =
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                 LRELU16(x[m]);
             }
         }
-        in = load_in(has_next ? b_next : b, ref_n, aux_n); // next sample's inputs first (see load_in)
+        in = load_in(has_next ? b_next : b, ref_n, aux_n, single(has_next ? bi_next : bi)); // next sample's inputs first (see load_in)
         // ---- fc0 operand row (k_fc0_mx): per (tile, channel half q) one 6-KiB block: f16 hi pieces [pxl 32][piece
         //      (2j+h) 8][16 B] with j = 2*(m&1)+s, then fp8 residual (x - hi)*2^(SA+11) pieces [pxl 32][piece (2h+e) 4][16 B]
         //      (the fp8 copy of hi is derived inside k_fc0_mx).  One K=64 super-step of fc0 = one pixel of one block. ----
@@ -604,11 +610,12 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
             // BASE: the row is stored into EVERY child row of the run (the rows fc0 reads must exist; k_sib_children then overwrites
             // each child's 7x7 window): `row` = the first child's row, the others follow at the row stride
             uint32_t orow = (uint32_t)b;
-            if (BASE) orow = DELTA ? (uint32_t)(active ? bi : 0) : (active ? groups[bi].x : 0u);
+            const bool sgl = single(bi);
+            if (BASE) orow = DELTA ? (uint32_t)(active ? bi : 0) : (active ? (sgl ? (uint32_t)row_list[bi - n_base] : groups[bi].x) : 0u);
             else if (DELTA && row_list) orow = (uint32_t)(d_out_base[0] + (active ? bi : 0));
             uint4* row = a_out + (size_t)orow * row_u4;
-            uint4* row2 = (BASE && DELTA) ? a_base + (size_t)(active ? groups[bi].y : 0u) * row_u4 : nullptr; // the base slot
-            const int copies = (BASE && !DELTA) ? (active ? (int)groups[bi].y : 0) : 1;
+            uint4* row2 = (BASE && DELTA && !sgl) ? a_base + (size_t)(active ? groups[bi].y : 0u) * row_u4 : nullptr; // the base slot
+            const int copies = (BASE && !DELTA) ? (active ? (sgl ? 1 : (int)groups[bi].y) : 0) : 1;
             const float sc_lo_inv = __uint_as_float((uint32_t)(127 - MX_SA - 11) << 23); // fp8 = (x - hi) / 2^-(SA+11)
             uint4* stage_w = (uint4*)(grid + gi * GRID_STRIDE);          // this lane's pixel row (8 slots of 16 B)
             uint32_t p8l[2][8];
@@ -665,7 +672,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                         if (st_ok[i] && active) {
                             uint4* dst = &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + (8 * i + (lane >> 3)) * 8 + (lane & 7)];
                             if (BASE && !DELTA) for (int c = 0; c < copies; ++c) nt_store(v, dst + (size_t)c * row_u4);
-                            else if (DELTA) { *dst = v; if (BASE) row2[dst - row] = v; } // (read again right away: by fc0; by the children of the run)
+                            else if (DELTA) { *dst = v; if (BASE && row2) row2[dst - row] = v; } // (read again right away: by fc0; by the children of the run)
                             else nt_store(v, dst);
                         }
                     }
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                     if (st_ok[i] && active) {
                         uint4* dst = &row[(size_t)(tile * 2 + q) * OP_BLK_U4 + OP_LO_U4 + (8 * i + (lane >> 3)) * 4 + (lane & 3)];
                         if (BASE && !DELTA) for (int c = 0; c < copies; ++c) nt_store(v, dst + (size_t)c * row_u4);
-                        else if (DELTA) { *dst = v; if (BASE) row2[dst - row] = v; }
+                        else if (DELTA) { *dst = v; if (BASE && row2) row2[dst - row] = v; }
                         else nt_store(v, dst);
                     }
                 }
@@ -2422,7 +2429,7 @@ int net_commit(Net& net, hipStream_t st) {
 
 template <int N, bool FROM_F32, int ABL = 0>
 static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st, const int32_t* row_list = nullptr, const int32_t* d_nrows = nullptr,
-                         const int32_t* d_out_base = nullptr) {
+                         const int32_t* d_out_base = nullptr, const int32_t* d_nrows2 = nullptr) {
     using TG = TrunkGeo<N>;
     static bool attr_done[64] = {}; // per device: the attribute belongs to the device's copy of the code object
     auto kern = k_trunk<N, FROM_F32, ABL>;
@@ -2434,7 +2441,8 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
     const int grid = wgs < 256 ? wgs : 256;
     kern<<<grid, TG::WG_THREADS, TG::LDS_BYTES, st>>>(S.req_ref, S.req_aux, S.board, S.hdr, S.d_count, S.cap_nodes, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first,
                                                        (uint4*)net.a_fc0, net.row_u4, max_count, row_list, d_nrows,
-                                                       (ABL & 48) == 48 ? (const uint2*)net.d_comp : (const uint2*)net.d_groups, net.sib_h, d_out_base, (uint4*)net.a_base);
+                                                       (ABL & 48) == 48 ? (const uint2*)net.d_comp : (const uint2*)net.d_groups, net.sib_h, d_out_base, (uint4*)net.a_base,
+                                                       d_nrows2);
 }
 
 template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
@@ -2478,12 +2486,10 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
     }
     k_group<<<(S.games + GROUP_TREES - 1) / GROUP_TREES, 64 * GROUP_TREES, 0, st>>>(S, side, (uint2*)net.d_groups, net.d_singles, (uint4*)net.d_sib_rows, net.d_gcnt,
                                                                                      delta ? net.d_sib_slot : nullptr, net.d_tags, (uint2*)net.d_comp);
-    const int max_groups = max_count / SIB_MIN + 1;
     if (!delta) {
-        launch_trunk<15, false, 16>(net, S, max_groups, st, nullptr, net.d_gcnt);                 // base positions of the runs
+        launch_trunk<15, false, 16>(net, S, max_count, st, net.d_singles, net.d_gcnt, nullptr, net.d_gcnt + 1); // base positions of the runs, then the rows outside runs
         k_sib_children<false><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
                                                       (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, nullptr, nullptr, nullptr, nullptr, nullptr);
-        launch_trunk<15, false>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1);            // the rows outside the runs
         return;
     }
     k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu,
@@ -2505,8 +2511,8 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
             for (int i = 0; i < 8; ++i) acc[i] = 0;
         }
     }
-    launch_trunk<15, false, 48>(net, S, max_groups, st, nullptr, net.d_gcnt + 96);                         // runs without a cached base -> compact rows [0, misses) + their base slots
-    launch_trunk<15, false, 32>(net, S, max_count, st, net.d_singles, net.d_gcnt + 1, net.d_gcnt + 96);    // single rows -> compact rows [misses, misses + singles)
+    // runs without a cached base -> compact rows [0, misses) + their base slots; then the single rows -> compact rows [misses, misses + singles)
+    launch_trunk<15, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1);
     static const bool tprof = getenv("OMOK_SIB_PROF") && atoi(getenv("OMOK_SIB_PROF")); // timing experiments only
     if (tprof) {
         static unsigned long long* d_tp = nullptr;
