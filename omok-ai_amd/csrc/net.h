@@ -65,6 +65,7 @@ struct Net {
     float* part_w = nullptr;         // fp32 partials of the K-split window tiles: [7][part_w_rows][512]
     size_t part_w_rows = 0;
     int n_cu = 256;                  // compute units of the device
+    int n_cu_all = 256;              // the same, set for every board size (n_cu above only with the sibling buffers)
     int mx_sw = 0;            // fc0 weights: fp8 copies are w * 2^mx_sw (hi) and (w - f16(w)) * 2^(mx_sw + 11) (lo)
     size_t bytes = 0;         // device bytes held
 };

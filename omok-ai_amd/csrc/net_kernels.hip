@@ -1608,6 +1608,10 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
         } else {
             if (b0 >= count) return;
             ubeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksup : 0;
+            if (EPI == EPI_PARTIAL) { // (uneven split: the last split takes what is left; the host never makes it empty)
+                const int nsup = full_tiles * 64 + 2 * last_cnt;
+                ksup = nsup - ubeg < ksup ? nsup - ubeg : ksup;
+            }
         }
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2098,6 +2102,27 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__
     row[2 + h] = *(const uint4*)&lo;
 }
 
+// split-K finish of the heads: partials in split order + bias -> logits rows
+__global__ __launch_bounds__(256) void k_splitk_logits(const float* __restrict__ part, int nsplit, size_t cap_rows, int width, const float* __restrict__ bias,
+                                                       float* __restrict__ logits, const int32_t* __restrict__ d_count, int max_count) {
+    int count = d_count[0];
+    if (count > max_count) count = max_count;
+    const size_t per_row = (size_t)width / 4, total = (size_t)count * per_row;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / per_row, col = (i % per_row) * 4;
+        f32x4 a = *(const f32x4*)(part + row * width + col);
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const f32x4 b = *(const f32x4*)(part + ((size_t)sp * cap_rows + row) * width + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += b[j];
+        }
+        const f32x4 bv = *(const f32x4*)(bias + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] += bv[j];
+        *(f32x4*)(logits + row * width + col) = a;
+    }
+}
+
 // policy softmax (network.rs:236-247) + value tanh (network.rs:197-200); one wave per sample
 __global__ __launch_bounds__(64) void k_softmax(const float* __restrict__ logits, int lrow, int hw, int rowp, float* __restrict__ p,
                                                 float* __restrict__ v, float* __restrict__ vpre, const int32_t* __restrict__ d_count, int max_count) {
@@ -2271,6 +2296,10 @@ size_t net_alloc(Net& net) {
             ok = ok && A((void**)&net.part_w, sizeof(float) * net.part_w_rows * 7 * NF);
         }
         net.part_rows = mb * 8 > 32768 ? mb * 8 : 32768;                                // split-K partials: rows x split ways (2 KiB each)
+        {
+            hipDeviceProp_t prop;
+            net.n_cu_all = (hipGetDeviceProperties(&prop, net.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
         ok = ok && A((void**)&net.part, sizeof(float) * net.part_rows * NF);
     }
     if (!ok) { net_free(net); return 0; }
@@ -2619,11 +2648,13 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
                 n_cu = (hipGetDeviceProperties(&prop, net.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
             }
             double best = 1e30;
-            for (int d = 1; d <= 16; ++d) {
-                if (nsup % d) continue;
+            for (int d = 1; d <= 16; ++d) { // (uneven splits: ceil(nsup / d) super-steps per split, the last one shorter but never empty; 30 ways
+                                            //  measured slower than 15 at 8 tiles: 100 vs 80 us -- every split writes and re-reads a 256-KB partial tile)
+                const int per = (nsup + d - 1) / d;
+                if ((d - 1) * per >= nsup) continue;
                 if (d > 1 && (size_t)d * (size_t)(tiles128 * GT_BS) > net.part_rows) continue;
                 const double waves = (double)(((size_t)tiles128 * d + n_cu - 1) / n_cu);
-                const double cost = waves / d * (d > 1 ? 1.04 : 1.0); // (partials round trip + shorter K loops)
+                const double cost = waves * (per + 4) * (d > 1 ? 1.04 : 1.0); // (+ pipeline fill and epilogue of a workgroup; partials round trip)
                 if (cost < best - 1e-9) { best = cost; nsplit = d; }
             }
         }
@@ -2638,7 +2669,7 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
         } else {
             const size_t cap_rows = (size_t)tiles128 * GT_BS;
             k_fc0_mx<EPI_PARTIAL><<<dim3(tiles128, nsplit), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0,
-                                                                            nsup / nsplit, net.row_u4, hw / 32, (hw % 32) ? (hw % 32) : 1, sc,
+                                                                            (nsup + nsplit - 1) / nsplit, net.row_u4, hw / 32, (hw % 32) ? (hw % 32) : 1, sc,
                                                                             bias_fc0, nullptr, cap_rows, net.part, S.d_count, max_count, nullptr, nullptr,
                                                                             nullptr);
             const size_t threads = (size_t)max_count * 64;
@@ -2647,10 +2678,26 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
         }
     }
     if (prof) { prof->end(st); prof->begin(PC_TAIL, st); }
-    launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st, net.device);
+    // fc1 and heads: 32 k-steps in a row per 128-sample tile; a batch of few tiles (thin rounds) leaves most CUs idle behind a chain of 32 dependent
+    // stages, so K is split over blockIdx.y (a power of two of the 32 k-steps, >= 4 k-steps each) into the fp32 partial slab and finished as fc0 is
     const int MT = heads_mt(hw);
-    if (MT == 8) launch_gemm<8, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
-    else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
+    const int tiles_t = (max_count + GT_BS - 1) / GT_BS;
+    int tsplit = 1;
+    while (tsplit < 8 && tiles_t * tsplit * 2 <= net.n_cu_all && (size_t)(tsplit * 2) * (size_t)(tiles_t * GT_BS) <= net.part_rows) tsplit *= 2;
+    const size_t cap_t = (size_t)tiles_t * GT_BS;
+    const size_t fin_threads = (size_t)max_count * 64;
+    if (tsplit == 1) {
+        launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st, net.device);
+        if (MT == 8) launch_gemm<8, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
+        else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
+    } else {
+        launch_gemm<16, EPI_PARTIAL, 1>(net.wt_fc1, h0, 32 / tsplit, 128, 32, 1, 2, bias_fc1, nullptr, cap_t, net.part, S, max_count, st, net.device, tsplit);
+        k_splitk_finish<<<(unsigned)((fin_threads + 255) / 256), 256, 0, st>>>(net.part, tsplit, cap_t, bias_fc1, h1, 128, S.d_count, max_count);
+        if (MT == 8) launch_gemm<8, EPI_PARTIAL, 2>(net.wt_heads, h1, 32 / tsplit, 128, 32, 1, 2, bias_heads, nullptr, cap_t, net.part, S, max_count, st, net.device, tsplit);
+        else launch_gemm<4, EPI_PARTIAL, 2>(net.wt_heads, h1, 32 / tsplit, 128, 32, 1, 2, bias_heads, nullptr, cap_t, net.part, S, max_count, st, net.device, tsplit);
+        const unsigned lg = (unsigned)(((size_t)max_count * (MT * 8) + 255) / 256);
+        k_splitk_logits<<<lg < 2048 ? lg : 2048, 256, 0, st>>>(net.part, tsplit, cap_t, MT * 32, bias_heads, net.s0, S.d_count, max_count);
+    }
     const int sg = max_count < 32768 ? max_count : 32768; // one wave per row up to 32 waves per SIMD: the row loop is a chain of dependent loads
     if (!skip_softmax) k_softmax<<<sg, 64, 0, st>>>(net.s0, MT * 32, hw, net.rowp, net.p, net.v, net.vpre, S.d_count, max_count);
     if (prof) prof->end(st);
