@@ -266,6 +266,10 @@ def test_net_precision_after_training_steps(n):
     assert r["dv_oracle"] < 2e-3 and r["dv_f32"] < 2e-3, r
     chk = oa.precision.measure(trained, n, x)
     assert abs(chk["max_dv"] - float(r["dv_f32"])) < 1e-6 and chk["within_contract"] == (r["dp_f32"] < TOL and r["dv_f32"] < TOL)
+    if n == 15:  # the search rounds' own path (base + window differences) with the trained weights, on the rows of real rounds
+        rounds = oa.precision.measure_search_rounds(trained, n, games=256, batch_k=16, rounds=4, plies=2, seed=9)
+        print(f"n=15 trained, search rounds: {rounds}")
+        assert rounds["rows"] > 20000 and rounds["max_dp"] < TOL and rounds["max_dv"] < 2e-3, rounds
 
 
 # ---- self-play: tree arithmetic bit-exact ---------------------------------------------------------
