@@ -65,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--precision-rows", type=int, default=4096, help="rows of the in-run precision check (0 = skip)")
     ap.add_argument("--budget-seconds", type=float, default=float(os.environ.get("OMOK_BENCH_BUDGET_S", "540")),
                     help="wall-clock budget of the whole process: the extra legs only run while there is room")
+    ap.add_argument("--window-plies", type=int, default=20, help="extra leg: time the first N plies of one more episode (SURVEY 8d's fixed-length window; 0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -163,15 +164,18 @@ def cpu_baseline(args, mean_plies, budget_s):
     # "All threads" for torch-CPU means intra-op threads of each GEMM: on a 256-thread host the 16..1024-row forwards of this
     # path run SLOWER on 256 threads than on 1 (measured: 176 vs 1620 sims/s), so the multi-thread legs use the fastest of a few
     # thread counts, found by a short calibration (the reference's rayon + libtensorflow pools size themselves the same way).
-    share = budget_s / 5.0
+    # Budget: 10 % thread calibration, 12 % per C1 leg, 33 % per C2' leg.  C2' plays 16 games (12800 simulations per ply at 800 sims/move):
+    # with 64 games no leg finished a ply inside its share (round 2: `plies_completed: 0`, i.e. only first-ply shallow trees were timed)
     cand = sorted({t for t in (8, 16, 32, 64, cores) if t <= cores})
-    calib = {t: leg(64, args.sims, t, min(1.5, share / len(cand)), 1)["sims_per_s"] for t in cand}
+    g2 = 16
+    calib = {t: leg(g2, args.sims, t, min(1.5, 0.10 * budget_s / len(cand)), 1)["sims_per_s"] for t in cand}
     best_t = max(calib, key=calib.get)
+    share = 0.33 * budget_s
     legs = {
-        "c1_best_threads": leg(1, 100, best_t, share, 10 ** 6),
-        "c1_one_thread": leg(1, 100, 1, share, 10 ** 6),
-        "c2p_best_threads": leg(64, args.sims, best_t, share, 5),
-        "c2p_one_thread": leg(64, args.sims, 1, share, 5),
+        "c1_best_threads": leg(1, 100, best_t, 0.12 * budget_s, 10 ** 6),
+        "c1_one_thread": leg(1, 100, 1, 0.12 * budget_s, 10 ** 6),
+        "c2p_best_threads": leg(g2, args.sims, best_t, share, 5),
+        "c2p_one_thread": leg(g2, args.sims, 1, share, 5),
     }
     torch.set_num_threads(cores)
     best = legs["c2p_best_threads"]
@@ -186,9 +190,9 @@ def cpu_baseline(args, mean_plies, budget_s):
     rounds_up = (args.sims + k - 1) // k * k
     return {"value": best["sims_per_s"] / (rounds_up * mean_plies), "unit": "games/s", "cores": best_t, "host_threads": cores, "kind": "port",
             "thread_calibration_sims_per_s": {str(t): v for t, v in calib.items()},
-            "sample": f"C2' = 64 games x {rounds_up} sims/move x up to 5 plies (bounded to {share:.0f} s) on {best_t} of {cores} threads (fastest of {cand}): oracle C tree "
+            "sample": f"C2' = {g2} games x {rounds_up} sims/move x up to 5 plies (bounded to {share:.0f} s; {best['plies_completed']} plies completed) on {best_t} of {cores} threads (fastest of {cand}): oracle C tree "
                       f"code + torch-CPU fp32 forward (BLAS); {best['sims_per_s']:.0f} sims/s, converted with {mean_plies:.1f} plies/game "
-                      f"from the GPU run.  Also C1 (1 game, 100->112 sims/move, whole game or {share:.0f} s) and both again on 1 thread: see legs",
+                      f"from the GPU run.  Also C1 (1 game, 100->112 sims/move, whole game or {0.12 * budget_s:.0f} s) and both again on 1 thread: see legs",
             "cpu_model": model, "sims_per_s": best["sims_per_s"],
             "one_thread_value": legs["c2p_one_thread"]["sims_per_s"] / (rounds_up * mean_plies),
             "c1_games_per_s": {kk: (1.0 / v["seconds"] if v["finished"] else v["sims_per_s"] / (112 * mean_plies)) for kk, v in legs.items() if kk.startswith("c1")},
@@ -231,6 +235,10 @@ def precision_check(args, rows, device):
     out["search_rounds"] = oa.precision.measure_search_rounds(oa.weights.init_random(n, seed=0), n, games=512, batch_k=k,
                                                               rounds=4, plies=2, device=device, seed=args.seed + 2)  # (8192-row rounds)
     out["within_contract"] = bool(out["within_contract"] and out["search_rounds"]["within_contract"])
+    if args.games * k > 8192:  # one ply of rounds at the size that is TIMED (configs[1]: 65536 rows per round: multi-tile window bins, the K-split set)
+        out["search_rounds_timed_size"] = oa.precision.measure_search_rounds(oa.weights.init_random(n, seed=0), n, games=args.games, batch_k=k,
+                                                                             rounds=3, plies=1, device=device, seed=args.seed + 3)
+        out["within_contract"] = bool(out["within_contract"] and out["search_rounds_timed_size"]["within_contract"])
     out["reference"] = "OMOK_NET_F32 kernels on the same GPU (fp32 VALU, k-ascending sums)"
     out["contract"] = "1e-3 on the outputs of AgentModel::evaluate_pv (p after softmax, v after tanh)"
     return out
@@ -391,6 +399,7 @@ def main():
                 "fp6 MFMAs (split operands) = 1.5x the pipe time of a plain-f16 product (frac <= 0.67 for a dense fc0).  At N = 15 a search round "
                 "runs the dense fc0 only on one full row per run of siblings and 98 of the 450 K-steps (the 7x7 window) on each child's difference "
                 "row, i.e. ~0.28x of the algorithmic work is EXECUTED: `achieved` counts useful work and can exceed what a dense kernel could reach")
+    fc0_fmt = {0: "block-scaled fp6 (e2m3)", 1: "f16"}.get(int(st.get("fc0_format", 0)), "f32")
     net_s = (st["ms_trunk"] + st["ms_fc0"] + st["ms_tail"]) * 1e-3
     tree_s = st["ms_tree"] * 1e-3
     tree_traffic = pmc.get("tree_hbm_bytes_per_sim")
@@ -398,7 +407,13 @@ def main():
         "metric": "self-play games/sec (15x15, 800 sims/move); MCTS nodes/sec",
         "value": games_per_s, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 (split hi+lo MFMA operands; fc0 correction terms in block-scaled fp6), fp32 accumulate" if args.net_mode == "f16x3" else "f32",
+        "dtype": (f"f16 (split hi+lo MFMA operands: f16 main term + two correction terms, fp32 accumulate; fc0's correction terms in {fc0_fmt}, "
+                  "chosen by omok_net_commit's probe)") if args.net_mode == "f16x3" else "f32",
+        "fc0_format": {"in_use": fc0_fmt, "probe_rows": st.get("probe_rows"), "probe_limit": st.get("probe_limit"),
+                       "fp6_max_dp_dv": [st.get("probe_dp_fp6"), st.get("probe_dv_fp6")], "f16_max_dp_dv": [st.get("probe_dp_f16"), st.get("probe_dv_f16")],
+                       "probe_logit_abs_max": st.get("probe_logit_max"),
+                       "rule": "fp6 correction terms are kept while the probe's worst |dp| and |dv| against the fp32 kernels are <= probe_limit (half the 1e-3 "
+                               "contract); otherwise f16 correction terms (DESIGN 3.4)"} if args.net_mode == "f16x3" else None,
         "data": "synthetic (games from the empty board, random-init net seed 0, one RNG stream per step)",
         "config": {"workload": f"{games} concurrent {n}x{n} games per GPU, {args.sims} sims/move, K={k}, two trees per game"
                                + ("" if complete else f", first {args.max_plies} plies only (games/s extrapolated)"),
@@ -479,6 +494,27 @@ def main():
                 del buf
             except Exception as ex:  # an extra line of the report must never cost the bench line itself
                 out["replay_postprocess_error"] = repr(ex)
+            extras = True
+        if args.window_plies > 0 and room(8 + 0.5 * dt / max(args.steps, 1)):
+            # a fixed-length window (the first 20 plies: every game is still alive, every round is full) for run-to-run stability
+            try:
+                sp.set_episode(args.warmup + args.steps)
+                sp.reset()
+                eng.set_profiling(0)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                wst = sp.run(args.sims, k, 0.25, 0.03, 1.0, 30, args.window_plies)
+                torch.cuda.synchronize()
+                dt_w = time.perf_counter() - t1
+                rounds_up = (args.sims + k - 1) // k * k
+                out["window_first_plies"] = {"plies": args.window_plies, "seconds": dt_w, "ply_games_per_s": games * args.window_plies / dt_w,
+                                             "mcts_sims_per_s": games * args.window_plies * rounds_up / dt_w, "ms_per_full_round": 1e3 * dt_w / (args.window_plies * rounds_up / k),
+                                             "games_per_s_at_mean_length": games * args.window_plies / dt_w / max(mean_plies, 1.0),
+                                             "note": "untimed-region extra leg, no profiling events: the same engine plays the first plies of one more episode "
+                                                     "(all games alive, all rounds full); games_per_s_at_mean_length = what the episode would reach if every round were full"}
+                eng.set_profiling(max(1, args.profile_every))
+            except Exception as ex:
+                out["window_first_plies"] = {"error": repr(ex)}
             extras = True
         if args.slots_multiple > 0 and args.max_plies == 0 and hasattr(sp, "run_slots") and room(20 + 1.2 * args.slots_multiple * dt / max(args.steps, 1)):
             # Slots mode: the same games (by index) as an episode of slots_multiple x games, but a slot whose game is over takes the next

@@ -37,12 +37,19 @@ extern "C" {
 #define OMOK_MODE_PLAYER 0   /* EnvTurnMode::Player   (alpha-zero/src/encoder.rs:4-8) */
 #define OMOK_MODE_OPPONENT 1 /* EnvTurnMode::Opponent */
 
-#define OMOK_NET_F16X3 0 /* split-operand MFMA (hi+lo: f16 main term, f16 / block-scaled fp6 correction terms, fp32 accumulate) */
+#define OMOK_NET_F16X3 0 /* split-operand MFMA (x = hi + lo, hi = f16(x): f16 main term + two correction terms, fp32 accumulate).  The
+                            correction terms of trunk, fc1 and heads are f16; those of fc0 (68 % of the flops) are block-scaled fp6 (products good to
+                            ~2^-15) or f16 (~2^-22, ~2x the fc0 time): omok_net_commit evaluates a fixed probe set of 1152 positions in both
+                            formats and with the fp32 kernels and keeps fp6 only while its worst |dp|, |dv| stay within 5e-4 = half the
+                            1e-3 contract on AgentModel::evaluate_pv's outputs (OMOK_STAT_FC0_FORMAT / OMOK_STAT_PROBE_*) */
 #define OMOK_NET_F32 1   /* plain fp32 VALU kernels (debug / A-B reference on the GPU) */
 #define OMOK_NET_F16X3_ROWS 2 /* OMOK_NET_F16X3 with every request row evaluated on its own: at board_size 15 the search rounds of
-                                 OMOK_NET_F16X3 evaluate sibling requests as one base position + per-child differences (DESIGN 3.4), so a
+                                 OMOK_NET_F16X3 evaluate sibling requests as one base position + per-child differences (DESIGN 3.3), so a
                                  row's p / v carry rounding that depends on its siblings (~5e-5, inside the 1e-3 contract); _ROWS switches
                                  that off (results bit-identical to omok_evaluate_pv of the same position), at ~1.7x the net time */
+
+#define OMOK_NET_F16X3_FP6 3 /* OMOK_NET_F16X3 with fc0's correction terms forced to block-scaled fp6 (no probe) */
+#define OMOK_NET_F16X3_F16 4 /* ... forced to f16 */
 
 #define OMOK_MAX_ARENA 16384 /* largest max_nodes / max_tables: node and table indices are 16-bit, and the re-rooting kernel keeps
                                3 B per node + 2 B per table of scratch in LDS (82 KiB at the maximum, inside gfx950's 160 KiB) */
@@ -153,7 +160,7 @@ int omok_play_actions(omok_engine* e, const int32_t* actions);
 int omok_set_actions(omok_engine* e, const int32_t* actions);
 /* whole self-play phase of one trainer iteration (trainer.rs:95-205): repeats
  * execute/sample/advance until every game is finished or max_plies (>0) plies were played.
- * stats (may be NULL, 16 doubles): see OMOK_STAT_* */
+ * stats (may be NULL, OMOK_STAT_COUNT doubles): see OMOK_STAT_* */
 int omok_selfplay_run(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha,
                       float temperature, int32_t threshold, int32_t max_plies, double* stats);
 
@@ -220,6 +227,16 @@ int64_t omok_replay_augment_dev(omok_engine* e, void* dst_dev, int64_t cap_recor
 int omok_replay_augmented_game(omok_engine* e, int32_t game, uint8_t* boards, uint8_t* turns, float* pi, float* z,
                                int32_t cap_records);
 
+/* Debugging aid of the parity tests (no reference counterpart): the fc0 operand rows -- the trunk's output in the layout fc0 reads,
+ * DESIGN 3.1 / 3.4 -- that the LAST forward left for request rows [first_row, first_row + rows), omok_operand_row_bytes each
+ * (split-precision modes; on the copy path of sibling rounds they must equal the rows of a row-by-row evaluation bit for bit). */
+int64_t omok_operand_row_bytes(const omok_engine* e);
+int omok_debug_operand_rows(omok_engine* e, int32_t first_row, int32_t rows, void* out);
+/* Debugging aid: enabled = 0 switches the base cache of the sibling rounds off (board_size 15, DESIGN 3.3: every run's base position is
+ * then evaluated in full in every round instead of being kept while its leaf stays the tree's expansion target).  Results must not
+ * change by a bit (tests). */
+int omok_debug_set_base_cache(omok_engine* e, int32_t enabled);
+
 #define OMOK_STAT_SIMS 0        /* simulations run (incl. terminal hits / no-action sims) */
 #define OMOK_STAT_EVALS 1       /* net evaluations (search requests + mirror evals + root) */
 #define OMOK_STAT_PLY_GAMES 2   /* sum over plies of live games */
@@ -236,7 +253,15 @@ int omok_replay_augmented_game(omok_engine* e, int32_t game, uint8_t* boards, ui
 #define OMOK_STAT_MS_ROUND 13   /* HIP-event ms in the round (select/expand/backup) kernel only */
 #define OMOK_STAT_PEAK_NODES 14  /* largest node / table arena use seen so far */
 #define OMOK_STAT_PEAK_TABLES 15
-#define OMOK_STAT_COUNT 16
+#define OMOK_STAT_FC0_FORMAT 16  /* operand format of fc0's correction terms in use: 0 = block-scaled fp6, 1 = f16 (-1: OMOK_NET_F32) */
+#define OMOK_STAT_PROBE_ROWS 17  /* rows of the last omok_net_commit's probe (0: no probe: forced format / OMOK_NET_F32) */
+#define OMOK_STAT_PROBE_DP_FP6 18 /* the probe's max |dp|, |dv| against the fp32 kernels: fp6 correction terms ... */
+#define OMOK_STAT_PROBE_DV_FP6 19
+#define OMOK_STAT_PROBE_DP_F16 20 /* ... f16 correction terms */
+#define OMOK_STAT_PROBE_DV_F16 21
+#define OMOK_STAT_PROBE_LIMIT 22  /* fp6 is kept while both of its figures are <= this (5e-4) */
+#define OMOK_STAT_PROBE_LOGIT_MAX 23 /* largest |policy logit| of the probe rows (fp32 kernels) */
+#define OMOK_STAT_COUNT 24
 int omok_get_stats(omok_engine* e, double* stats /* [OMOK_STAT_COUNT] */);
 int omok_reset_stats(omok_engine* e);
 /* Per-category HIP-event timing of the kernels on the engine's stream (off by default).  enabled = 1: every launch; enabled = N > 1:

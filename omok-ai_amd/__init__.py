@@ -6,4 +6,5 @@ from . import weights  # noqa: F401
 from . import binding  # noqa: F401
 from . import dist  # noqa: F401
 from . import precision  # noqa: F401
+from . import model_file  # noqa: F401
 from .api import Engine, Environment, SelfPlay  # noqa: F401

@@ -125,12 +125,24 @@ class Engine:
         return out.reshape(-1, self.n, self.n, 3)
 
     # ---- stats ------------------------------------------------------------------------------
+    def operand_rows(self, first_row, rows):
+        """uint8 [rows][omok_operand_row_bytes]: the fc0 operand rows the last forward left (omok_debug_operand_rows)."""
+        nb = int(B.lib().omok_operand_row_bytes(self.h))
+        if nb < 0:
+            raise B.OmokError(nb, "no operand rows in this net mode")
+        out = np.empty((rows, nb), dtype=np.uint8)
+        self._chk(B.lib().omok_debug_operand_rows(self.h, first_row, rows, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_base_cache(self, on=True):
+        self._chk(B.lib().omok_debug_set_base_cache(self.h, int(bool(on))))
+
     def set_profiling(self, on=True):
         """True / 1: time every launch; N > 1: time one search round in N (stats are scaled); False: off."""
         self._chk(B.lib().omok_set_profiling(self.h, int(on)))
 
     def stats(self):
-        s = (C.c_double * 16)()
+        s = (C.c_double * len(B.STAT_NAMES))()
         self._chk(B.lib().omok_get_stats(self.h, s))
         return dict(zip(B.STAT_NAMES, list(s)))
 
@@ -238,7 +250,7 @@ class SelfPlay:
         self._chk(B.lib().omok_advance(self.h))
 
     def run(self, count, batch_size, epsilon=0.25, alpha=0.03, temperature=1.0, threshold=30, max_plies=0):
-        s = (C.c_double * 16)()
+        s = (C.c_double * len(B.STAT_NAMES))()
         self._chk(B.lib().omok_selfplay_run(self.h, count, batch_size, epsilon, alpha, temperature, threshold, max_plies, s))
         return dict(zip(B.STAT_NAMES, list(s)))
 
@@ -246,7 +258,7 @@ class SelfPlay:
         """Slots mode (omok_selfplay_run_slots): `total_games` games on the engine's slots, finished slots restarted with the next game
         index.  `records_ptr` = device buffer of cap_records x replay_record_bytes (e.g. a torch uint8 tensor's data_ptr()).
         Returns (stats, n_records, offsets[int64], lengths[int32], status[int32]) indexed by game index."""
-        s = (C.c_double * 16)()
+        s = (C.c_double * len(B.STAT_NAMES))()
         off = np.zeros(total_games, dtype=np.int64)
         ln = np.zeros(total_games, dtype=np.int32)
         stt = np.zeros(total_games, dtype=np.int32)

@@ -199,7 +199,8 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     if (cfg->max_nodes < 2 || cfg->max_nodes > OMOK_MAX_ARENA || cfg->max_tables < 1 || cfg->max_tables > OMOK_MAX_ARENA)
         return fail(nullptr, OMOK_ERR_INVALID, "max_nodes must be in [2, %d] and max_tables in [1, %d]", OMOK_MAX_ARENA, OMOK_MAX_ARENA);
     if (cfg->max_batch_k < 1 || cfg->max_batch_k > KMAX) return fail(nullptr, OMOK_ERR_INVALID, "max_batch_k must be in [1, 64]");
-    if (cfg->net_mode != OMOK_NET_F16X3 && cfg->net_mode != OMOK_NET_F32 && cfg->net_mode != OMOK_NET_F16X3_ROWS)
+    if (cfg->net_mode != OMOK_NET_F16X3 && cfg->net_mode != OMOK_NET_F32 && cfg->net_mode != OMOK_NET_F16X3_ROWS && cfg->net_mode != OMOK_NET_F16X3_FP6 &&
+        cfg->net_mode != OMOK_NET_F16X3_F16)
         return fail(nullptr, OMOK_ERR_INVALID, "bad net_mode");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -287,8 +288,9 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     e->net.n = e->n;
     e->net.hw = e->hw;
     e->net.rowp = e->rowp;
-    e->net.mode = cfg->net_mode == OMOK_NET_F16X3_ROWS ? OMOK_NET_F16X3 : cfg->net_mode;
-    e->net.siblings = cfg->net_mode == OMOK_NET_F16X3;
+    e->net.mode = cfg->net_mode == OMOK_NET_F32 ? OMOK_NET_F32 : OMOK_NET_F16X3;
+    e->net.siblings = cfg->net_mode != OMOK_NET_F16X3_ROWS;
+    e->net.fc0_policy = cfg->net_mode == OMOK_NET_F16X3_FP6 ? FC0_FP6 : cfg->net_mode == OMOK_NET_F16X3_F16 ? FC0_F16 : FC0_AUTO;
     e->net.max_b = (int)max_b;
     e->net.games = cfg->games;
     for (int i = 0; i < NET_TENSORS; ++i) e->net.wsize[i] = net_tensor_size(e->n, i);
@@ -327,7 +329,8 @@ extern "C" int omok_net_commit(omok_engine* e) {
     for (int i = 0; i < NET_TENSORS; ++i)
         if (!e->net.loaded[i]) return fail(e, OMOK_ERR_STATE, "tensor %d was never loaded", i);
     HIPCHK(e, hipSetDevice(e->cfg.device));
-    if (net_commit(e->net, e->st) != 0) return fail(e, OMOK_ERR_HIP, "weight packing failed");
+    if (e->round_reqs >= 0 || e->mirror_reqs >= 0) return fail(e, OMOK_ERR_STATE, "omok_net_commit while a round / mirror batch is pending");
+    if (net_commit(e->net, e->S, e->st) != 0) return fail(e, OMOK_ERR_HIP, "weight packing / format probe failed");
     net_invalidate_sibling_cache(e->net); // (new weights: cached base evaluations are void)
     HIPCHK(e, hipStreamSynchronize(e->st));
     e->net.committed = true;
@@ -1264,6 +1267,22 @@ extern "C" int omok_replay_augmented_game(omok_engine* e, int32_t game, uint8_t*
     return total;
 }
 
+// fc0 operand rows (the trunk's output as fc0 reads it) of the LAST forward: `rows` rows from `first_row`, omok_operand_row_bytes each
+extern "C" int64_t omok_operand_row_bytes(const omok_engine* e) { return e && e->net.mode != OMOK_NET_F32 ? (int64_t)e->net.row_u4 * 16 : OMOK_ERR_INVALID; }
+extern "C" int omok_debug_operand_rows(omok_engine* e, int32_t first_row, int32_t rows, void* out) {
+    if (!e || !out || first_row < 0 || rows < 0 || first_row + rows > e->net.max_b || e->net.mode == OMOK_NET_F32) return OMOK_ERR_INVALID;
+    ENTER(e);
+    HIPCHK(e, hipMemcpyAsync(out, (const char*)e->net.a_fc0 + (size_t)first_row * e->net.row_u4 * 16, (size_t)rows * e->net.row_u4 * 16, hipMemcpyDeviceToHost, e->st));
+    return sync_and_check(e, "debug_operand_rows") ? OMOK_ERR_HIP : OMOK_OK;
+}
+
+extern "C" int omok_debug_set_base_cache(omok_engine* e, int32_t enabled) {
+    if (!e) return OMOK_ERR_INVALID;
+    e->net.base_cache = enabled != 0;
+    net_invalidate_sibling_cache(e->net);
+    return OMOK_OK;
+}
+
 extern "C" int omok_get_stats(omok_engine* e, double* stats) {
     if (!e || !stats) return OMOK_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->cfg.device));
@@ -1289,6 +1308,14 @@ extern "C" int omok_get_stats(omok_engine* e, double* stats) {
     stats[OMOK_STAT_MS_ROUND] = e->prof.total_ms(PC_ROUND);
     stats[OMOK_STAT_PEAK_NODES] = (double)e->peak_nodes;
     stats[OMOK_STAT_PEAK_TABLES] = (double)e->peak_tables;
+    stats[OMOK_STAT_FC0_FORMAT] = e->net.mode == OMOK_NET_F32 ? -1.0 : (double)e->net.fc0_fmt;
+    stats[OMOK_STAT_PROBE_ROWS] = e->net.probe[6] != 0.0f ? (double)e->net.probe[0] : 0.0;
+    stats[OMOK_STAT_PROBE_DP_FP6] = e->net.probe[1];
+    stats[OMOK_STAT_PROBE_DV_FP6] = e->net.probe[2];
+    stats[OMOK_STAT_PROBE_DP_F16] = e->net.probe[3];
+    stats[OMOK_STAT_PROBE_DV_F16] = e->net.probe[4];
+    stats[OMOK_STAT_PROBE_LIMIT] = NET_PROBE_LIMIT;
+    stats[OMOK_STAT_PROBE_LOGIT_MAX] = e->net.probe[5];
     return OMOK_OK;
 }
 

@@ -9,6 +9,9 @@ constexpr int NET_TENSORS = 31;
 constexpr int NC = 128; // RESIDUAL_CHANNELS (alpha-zero/src/network.rs:24)
 constexpr int NM = 32;  // RESIDUAL_MIDDLE_CHANNELS (:25)
 constexpr int NF = 512; // FC_0_SIZE / FC_1_SIZE (:29-30)
+enum { FC0_AUTO = -1, FC0_FP6 = 0, FC0_F16 = 1 };
+constexpr float NET_PROBE_LIMIT = 5e-4f; // fp6 correction terms are kept only while the probe's worst |dp|, |dv| stay below this (2x margin to the 1e-3 contract)
+constexpr int NET_PROBE_ROWS = 1152;
 
 struct Net {
     int n = 0, hw = 0, rowp = 0, mode = 0;
@@ -46,7 +49,7 @@ struct Net {
     int32_t* d_gcnt = nullptr;  // [0] runs, [1] rows outside runs, [2] rows inside runs, [3] full rows (runs + singles), [4] fc0 window tiles,
                                 // [8 + b] children whose window is bin b (SIB_CNT_INTS in all)
     float* sib_h = nullptr;     // [run][3 blocks][225][32] the base passes' depthwise inputs
-    // difference path (DESIGN 3.4): a child's fc0 input = its run's base row + a 7x7-window difference row
+    // difference path (DESIGN 3.3): a child's fc0 input = its run's base row + a 7x7-window difference row
     uint32_t* d_sib_slot = nullptr;  // per row inside a run: window bin << 24 | rank inside the bin
     int32_t* d_bin_start = nullptr;  // first slot of every bin (bins padded to whole 128-sample tiles); [81] = the single rows
     int32_t* d_tile_info = nullptr;  // per fc0 window tile: bin | live slots << 8
@@ -61,12 +64,22 @@ struct Net {
     float* facc = nullptr;           // [base_slots + max_b][512] fp32 fc0 rows: base slots, then the round's single rows
     int32_t* d_tags = nullptr;       // [games][2] (leaf node | slot << 16) of the bases in the game's two slots, most recently used first; -1 = none
     void* d_comp = nullptr;          // the round's positions to evaluate in full: (request row of the first child, base slot)
+    bool base_cache = true;          // false (omok_debug_set_base_cache): every run's base is evaluated in full every round (A-B check: same p / v bit for bit)
     bool sib_cache_valid = false;    // false: the trees changed outside the search rounds (reset, advance, refill): tags are cleared first
     float* part_w = nullptr;         // fp32 partials of the K-split window tiles: [7][part_w_rows][512]
     size_t part_w_rows = 0;
     int n_cu = 256;                  // compute units of the device
     int n_cu_all = 256;              // the same, set for every board size (n_cu above only with the sibling buffers)
     int mx_sw = 0;            // fc0 weights: fp8 copies are w * 2^mx_sw (hi) and (w - f16(w)) * 2^(mx_sw + 11) (lo)
+    // fc0 operand format: the correction terms hi*lo + lo*hi of fc0 run either on block-scaled fp6 operands (FC0_FP6: 4
+    // significant bits, products good to ~2^-15) or on f16 operands (FC0_F16: three f16 MFMAs per product, ~2^-22).  net_commit packs the
+    // weights for both and, with fc0_policy = FC0_AUTO, measures both against the fp32 kernels on a fixed probe set and keeps the
+    // faster one (fp6) only if its worst |dp|, |dv| stay within NET_PROBE_LIMIT (half the 1e-3 contract).
+    int fc0_policy = FC0_AUTO; // FC0_AUTO / FC0_FP6 / FC0_F16 (forced)
+    int fc0_fmt = 0;          // format in use: FC0_FP6 or FC0_F16
+    void* wt_fc0x = nullptr;  // fc0 weights for FC0_F16: [half-step][stage g][m-tile i][hi s0, hi s1, lo s0, lo s1][lane][8] f16
+    size_t row_u4_fmt[2] = {0, 0}; // a_fc0 row stride per format (row_u4 = the one in use)
+    float probe[8] = {};      // commit-time probe: [0] rows, [1] |dp| fp6, [2] |dv| fp6, [3] |dp| f16, [4] |dv| f16, [5] max |logit| (fp32), [6] 1 = measured
     size_t bytes = 0;         // device bytes held
 };
 
@@ -106,8 +119,10 @@ void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t s
 void net_forward_inputs(Net& net, const Store& S, int count, hipStream_t st, struct Prof* prof);
 // The trees were changed outside the search rounds (reset, advance, refill, externally placed moves): cached base evaluations are void.
 inline void net_invalidate_sibling_cache(Net& net) { net.sib_cache_valid = false; }
-// Packs the raw tensors into the MFMA operand layouts (host-side repack + upload).
-int net_commit(Net& net, hipStream_t st);
+// Packs the raw tensors into the MFMA operand layouts (host-side repack + upload), then (split-precision modes) chooses fc0's operand
+// format: see Net::fc0_policy.  S: the engine's store (the probe forwards use S.d_count).
+int net_commit(Net& net, const Store& S, hipStream_t st);
+void net_set_fc0_format(Net& net, int fmt); // FC0_FP6 / FC0_F16: switches row strides and kernels (cached base evaluations are void)
 // pre-softmax policy logits of the LAST forward (rows of the last chunk in OMOK_NET_F32 mode): pointer and row stride in floats
 const float* net_logits(const Net& net, int* row_stride);
 size_t net_alloc(Net& net); // allocates buffers for net.max_b; returns bytes, 0 on failure

@@ -91,6 +91,11 @@ __device__ inline f32x2 lrelu2(float a, float b) {
             (X)[i_ + 1] = r_[1];                             \
         }                                                    \
     } while (0)
+// Lanes of ONE wave exchanging data through LDS (a lane stages its pixel's pieces, other lanes read them back): the hardware executes
+// a wave's LDS instructions in order, but the COMPILER reasons per lane -- on the path of a lane that skips the staging stores (a pad
+// pixel) it may take the read-back for a repeat of the previous pass's load of the same address and reuse that value (seen: hipcc 7.2
+// moved the ds_read into the `if (valid)` block of the stores).  A wavefront-scope fence costs no instruction and forbids exactly that.
+#define WAVE_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define MFMA3(ah, al, bh, bl, c)   \
     do {                           \
@@ -215,6 +220,10 @@ constexpr int GRID_STRIDE = 36; // floats per halo-grid row (32 + 4 pad: conflic
 // fc0 operand row: per (pixel tile, channel half q) one dense 6-KiB block = f16 part [32 pxl][128 B], then fp8 residual
 // part [32 pxl][64 B] (uint4 units below)
 constexpr int OP_BLK_U4 = 384, OP_LO_U4 = 256;
+// FC0_F16 format of the same row (Net::fc0_fmt): the residual part of a block holds f16 residuals f16(x - hi) in the layout of the
+// hi part ([32 pxl][piece (2j+h) 8][16 B]) instead of fp6 codes + scales: blocks of 8 KiB
+constexpr int OPX_BLK_U4 = 512;
+constexpr int fmt_blk_u4(bool f16lo) { return f16lo ? OPX_BLK_U4 : OP_BLK_U4; }
 constexpr bool MX6 = true;   // fc0 correction terms on fp6 (e2m3) operands with per-lane E8M0 block scales (false: fp8, global scales)
 constexpr bool LO_SCALE_FROM_BOUND = false; // true: -16 VALU per block in the trunk epilogue (trunk -2 %), N = 9 max|dv| 3.6e-4 -> 5.9e-4
 constexpr int MX_SA = 2;        // fp8 copies of the fc0 operand are x * 2^MX_SA (|x| <= 112 representable; clamped beyond)
@@ -262,6 +271,8 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
     // a_base (what the children read, this round and while the slot's tag stays: the h grids go to hscr[slot] likewise); with DELTA the rows
     // of a row list go to compact rows d_out_base[0] + i (behind the runs').
     constexpr bool BASE = (ABL & 16) != 0, DELTA = (ABL & 32) != 0;
+    constexpr bool F16LO = (ABL & 64) != 0; // operand rows in the FC0_F16 format (f16 residuals)
+    constexpr int BLK_U4 = fmt_blk_u4(F16LO);
     using TG = TrunkGeo<N>;
     constexpr int HW = TG::HW, NW = Geo<N>::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -616,8 +627,47 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
             uint4* row = a_out + (size_t)orow * row_u4;
             uint4* row2 = (BASE && DELTA && !sgl) ? a_base + (size_t)(active ? groups[bi].y : 0u) * row_u4 : nullptr; // the base slot
             const int copies = (BASE && !DELTA) ? (active ? (sgl ? 1 : (int)groups[bi].y) : 0) : 1;
-            const float sc_lo_inv = __uint_as_float((uint32_t)(127 - MX_SA - 11) << 23); // fp8 = (x - hi) / 2^-(SA+11)
             uint4* stage_w = (uint4*)(grid + gi * GRID_STRIDE);          // this lane's pixel row (8 slots of 16 B)
+            if constexpr (F16LO) {
+                // FC0_F16: four passes of 128 B per pixel through the same staging rows -- per channel half q the f16 hi pieces, then the
+                // f16 residual pieces (split8: 1.5 VALU per value, no block maxima, no fp6 packing)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    half8 hi8[4], lo8[4];
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                        for (int sx = 0; sx < 2; ++sx) {
+                            float v[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = x[2 * q + mm][8 * sx + j];
+                            split8(v, hi8[mm * 2 + sx], lo8[mm * 2 + sx]);
+                        }
+#pragma unroll
+                    for (int part = 0; part < 2; ++part) {
+                        if (valid) {
+#pragma unroll
+                            for (int p4 = 0; p4 < 4; ++p4) stage_w[p4 * 2 + h] = __builtin_bit_cast(uint4, part ? lo8[p4] : hi8[p4]);
+                        }
+                        WAVE_LDS_FENCE();
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint4 v = *(const uint4*)(grid + st_gi[i] * GRID_STRIDE + 4 * (lane & 7));
+                            if (i == 3) WAVE_LDS_FENCE();
+                            if (!(ABL & 8)) {
+                                if (st_ok[i] && active) {
+                                    uint4* dst = &row[(size_t)(tile * 2 + q) * BLK_U4 + part * OP_LO_U4 + (8 * i + (lane >> 3)) * 8 + (lane & 7)];
+                                    if (BASE && !DELTA) for (int c = 0; c < copies; ++c) nt_store(v, dst + (size_t)c * row_u4);
+                                    else if (DELTA) { *dst = v; if (BASE && row2) row2[dst - row] = v; }
+                                    else nt_store(v, dst);
+                                }
+                            }
+                            else if (v.x == 0x12345678u && v.y == 0x9abcdef0u) row[lane] = v;
+                        }
+                    }
+                }
+            } else {
+            const float sc_lo_inv = __uint_as_float((uint32_t)(127 - MX_SA - 11) << 23); // fp8 = (x - hi) / 2^-(SA+11)
             uint32_t p8l[2][8];
             u32x6 lo6[2];        // MX6: fp6 residuals of the lane's 32 values per channel half q, natural slot order 16*mm + reg
             uint32_t esc[2];     // MX6: E8M0 bytes of the two block scales (hi copy | residual << 8)
@@ -653,6 +703,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                         }
                         if (valid) stage_w[(mm * 2 + sx) * 2 + h] = H.v;
                     }
+                WAVE_LDS_FENCE();
                 if (MX6) { // block scales 2^(floor(log2 max) - 2) (e2m3 emax = 2) and the packed fp6 residuals
                     // (option: residual scale from the bound |x - f16(x)| <= 2^(floor(log2 |x|) - 11) instead of a second block maximum)
                     int eh = (int)((__float_as_uint(amax_v) >> 23) & 0xFFu) - 2, el = LO_SCALE_FROM_BOUND ? eh - 11 : (int)((__float_as_uint(amax_l) >> 23) & 0xFFu) - 2;
@@ -678,6 +729,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                     }
                     else if (v.x == 0x12345678u && v.y == 0x9abcdef0u) row[lane] = v; // timing only: keep the staging alive
                 }
+                WAVE_LDS_FENCE();
             }
             if (valid) {
 #pragma unroll
@@ -692,6 +744,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                     }
                 }
             }
+            WAVE_LDS_FENCE();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint4 v = *(const uint4*)(grid + st_gi[i] * GRID_STRIDE + 4 * (lane & 7));
@@ -706,6 +759,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                 }
                 else if (v.x == 0x12345678u && v.y == 0x9abcdef0u) row[lane] = v;
             }
+            } // (fp6 format)
         }
     }
 }
@@ -750,6 +804,7 @@ constexpr int SIB_CNT_INTS = 8 + SIB_BINS + 7 + 16;                       // d_g
 constexpr int SIB_WPX = SIB_WIN * SIB_WIN;                                // 49 window pixels = 98 fc0 super-steps
 constexpr int SIB_DROW_U4 = SIB_WPX * 2 * 12;                             // 1176 uint4 = 18816 B: [q][w] 128-B f16 parts, [q][w] 64-B residual parts
 constexpr int SIB_DLO_U4 = SIB_WPX * 2 * 8;                               // 784: first residual part
+constexpr int SIBX_DROW_U4 = SIB_WPX * 2 * 16;                            // FC0_F16: 1568 uint4 = 25088 B: [q][w] 128-B f16 parts, [q][w] 128-B f16 residual parts
 
 __device__ inline void sib_window(int action, int& wy0, int& wx0) { // the 7x7 window (clamped to the board) around the pixel the stone's float lands in
     const int pc = (2 * action + 1) / 3;
@@ -984,7 +1039,8 @@ __global__ __launch_bounds__(256) void k_facc_reduce(const float* __restrict__ p
 // DELTA (difference path): a_out holds the FULL rows (one per run, written by k_trunk<BASE | DELTA>); the child's window entries are
 // stored as DIFFERENCES to the base's entries (dequantised: f16 hi + fp6 residual * 2^scale, exactly what fc0 will multiply), in the
 // same entry format, into the child's slot row of d_rows: fc0(child) = fc0(base row) + W[window] * difference row.
-template <bool DELTA, bool TPROF = false> // TPROF (OMOK_SIB_PROF=1, timing only): shader-clock cycles per phase, summed over wave 0's passes, into tprof[]
+template <bool DELTA, bool TPROF = false, bool F16LO = false> // TPROF (OMOK_SIB_PROF=1, timing only): shader-clock cycles per phase, summed over wave 0's passes, into tprof[]
+                                                                // F16LO: operand / difference rows in the FC0_F16 format (f16 residuals)
 __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict__ board, const uint4* __restrict__ wt, const float* __restrict__ side,
                                                       uint4* __restrict__ a_out, size_t row_u4, const uint4* __restrict__ sib_rows,
                                                       const int32_t* __restrict__ d_cnt, const float* __restrict__ hscr,
@@ -992,6 +1048,8 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
                                                       uint4* __restrict__ d_rows, uint2* __restrict__ slot_desc,
                                                       unsigned long long* __restrict__ tprof) {
     constexpr int N = 15;
+    constexpr int BLK_U4 = fmt_blk_u4(F16LO);
+    constexpr int DROW_U4 = F16LO ? SIBX_DROW_U4 : SIB_DROW_U4;
     unsigned long long tp_acc[12] = {}, tp_last = 0;
     auto TP = [&](int phase) { // (phase = what ended here)
         if (TPROF) {
@@ -1157,6 +1215,39 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
     auto store_rows = [&](const f32x16 (&x)[4], uint4* row, bool lane_valid, float* stage_row, const int (&rd_gi)[4], const int (&rd_px)[4],
                           const bool (&rd_ok)[4], float* gbase) {
         uint4* stage_w = (uint4*)stage_row;
+        if constexpr (F16LO) { // four passes of 128 B per pixel: per channel half q the f16 hi pieces, then the f16 residual pieces
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                half8 hi8[4], lo8[4];
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = x[2 * q + mm][8 * sx + j];
+                        split8(v, hi8[mm * 2 + sx], lo8[mm * 2 + sx]);
+                    }
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    if (lane_valid) {
+#pragma unroll
+                        for (int p4 = 0; p4 < 4; ++p4) stage_w[p4 * 2 + h] = __builtin_bit_cast(uint4, part ? lo8[p4] : hi8[p4]);
+                    }
+                    WAVE_LDS_FENCE();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint4 v = *(const uint4*)(gbase + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
+                        if (i == 3) WAVE_LDS_FENCE();
+                        if (rd_ok[i]) {
+                            if (DELTA) nt_store(v, &row[part * SIB_DLO_U4 + (q * SIB_WPX + rd_px[i]) * 8 + (lane & 7)]);
+                            else nt_store(v, &row[(size_t)((rd_px[i] >> 5) * 2 + q) * BLK_U4 + part * OP_LO_U4 + (rd_px[i] & 31) * 8 + (lane & 7)]);
+                        }
+                    }
+                }
+            }
+            return;
+        }
         u32x6 lo6[2];
         uint32_t esc[2];
 #pragma unroll
@@ -1182,6 +1273,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
                     }
                     if (lane_valid) stage_w[(mm * 2 + sx) * 2 + h] = H.v;
                 }
+            WAVE_LDS_FENCE();
             int eh = (int)((__float_as_uint(amax_v) >> 23) & 0xFFu) - 2, el = (int)((__float_as_uint(amax_l) >> 23) & 0xFFu) - 2;
             eh = eh < 1 ? 1 : eh;
             el = el < 1 ? 1 : el;
@@ -1198,6 +1290,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
                     else nt_store(v, &row[(size_t)((rd_px[i] >> 5) * 2 + q) * OP_BLK_U4 + (rd_px[i] & 31) * 8 + (lane & 7)]);
                 }
             }
+            WAVE_LDS_FENCE();
         }
         if (lane_valid) {
 #pragma unroll
@@ -1207,6 +1300,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
                 ((uint16_t*)(stage_w + q * 4 + 3))[h] = (uint16_t)esc[q];
             }
         }
+        WAVE_LDS_FENCE();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint4 v = *(const uint4*)(gbase + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
@@ -1269,14 +1363,46 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
     auto base_fetch = [&](const uint4* frow, int px) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const uint4* bp = frow + (size_t)((px >> 5) * 2 + q) * OP_BLK_U4;
+            const uint4* bp = frow + (size_t)((px >> 5) * 2 + q) * BLK_U4;
 #pragma unroll
             for (int p4 = 0; p4 < 4; ++p4) bs_hi[q][p4] = bp[(px & 31) * 8 + p4 * 2 + h];
+            if (F16LO) continue; // (the f16 residual pieces: base_sub_f16lo, fetched behind the hi parts' subtraction -- 32 more registers do not fit beside L1L2)
             const uint4* lp = bp + OP_LO_U4 + (px & 31) * 4;
             bs_lo[q] = lp[h];
             bs_lt[q] = ((const uint2*)(lp + 2))[h];
             bs_sc[q] = ((const uint16_t*)(lp + 3))[h];
         }
+    };
+    // x -= the f16 pieces `pc` (the lane's 4 pieces of channel half q: hi or residual part of the base's entries)
+    auto sub_pieces = [&](f32x16 (&x)[4], int q, const uint4 (&pc)[4]) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                const uint4 hq = pc[mm * 2 + sx];
+                const uint32_t hu[4] = {hq.x, hq.y, hq.z, hq.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float v0 = x[2 * q + mm][8 * sx + 2 * jj], v1 = x[2 * q + mm][8 * sx + 2 * jj + 1];
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(v0) : "v"(hu[jj]));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v1) : "v"(hu[jj]));
+                    x[2 * q + mm][8 * sx + 2 * jj] = v0;
+                    x[2 * q + mm][8 * sx + 2 * jj + 1] = v1;
+                }
+            }
+    };
+    auto base_sub_f16lo = [&](f32x16 (&x)[4], const uint4* frow, int px) { // FC0_F16: x - hi - lo, exactly the base as fc0 multiplies it
+        uint4 lo[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint4* bp = frow + (size_t)((px >> 5) * 2 + q) * BLK_U4 + OP_LO_U4;
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) lo[q][p4] = bp[(px & 31) * 8 + p4 * 2 + h];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) sub_pieces(x, q, bs_hi[q]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) sub_pieces(x, q, lo[q]);
     };
     auto base_subtract = [&](f32x16 (&x)[4]) {
 #pragma unroll
@@ -1390,7 +1516,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
         const int q = (wy0 + c_wy) * N + (wx0 + c_wx);                                      // this lane's board pixel
         int slot = 0;
         if (DELTA) slot = bin_start[slot_c >> 24] + (int)(slot_c & 0xFFFFFFu);
-        uint4* crow_p = DELTA ? d_rows + (size_t)slot * SIB_DROW_U4 : a_out + (size_t)crow * row_u4;
+        uint4* crow_p = DELTA ? d_rows + (size_t)slot * DROW_U4 : a_out + (size_t)crow * row_u4;
         uint64_t* cw = (uint64_t*)(cgrid + (SIB_CGRID_ROWS - 1) * GRID_STRIDE) + wt2 * 8; // the child's 8 board words: the grid's pad row, one copy per wave
         if (lane < 2 * NW) cw[lane] = word_c;
         // the next pass's board words (its descriptor arrived a pass ago) and the descriptor of the pass after that
@@ -1428,7 +1554,8 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
                 rd_ok[i] = w < SIB_WPX && act;
             }
             if (DELTA) {
-                base_subtract(x);
+                if constexpr (F16LO) base_sub_f16lo(x, a_out + (size_t)ent.y * row_u4, q);
+                else base_subtract(x);
                 if (act && wt2 == 0 && lane == 0) slot_desc[slot] = make_uint2((uint32_t)crow, ent.y);
             }
             TP(6);
@@ -1907,6 +2034,283 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
 }
 
 // ===============================================================================================
+// OMOK_NET_F16X3, FC0_F16 operand format: fc0 with f16 correction terms
+// ===============================================================================================
+// x*w = hi*hi + lo*hi + hi*lo with hi = f16(x), lo = f16(x - hi) on BOTH sides: three f16 MFMAs per product, the arithmetic of the trunk,
+// fc1 and the heads (products good to ~2^-22; the fp6 correction terms of k_fc0_mx stop at ~2^-15, which is what the 1e-3 contract
+// feels on nets whose head outputs are large: net_commit measures and chooses, Net::fc0_policy).  Same tile and the same machinery as
+// k_fc0_mx -- 512 features x 128 samples per workgroup, one wave per SIMD with 16 accumulator tiles, wave-private weight rings filled by
+// LDS-DMA and ordered by counted vmcnt waits, double-buffered sample operands, one workgroup barrier per step -- but a step is a HALF
+// super-step: K = 32 = one pixel x 32 channels (m = 2q + mm), so that a weight stage (4 m-tiles x {hi s0, hi s1, lo s0, lo s1} =
+// 16 KiB) and a sample buffer (128 samples x (64 B hi + 64 B lo) = 16 KiB) keep the LDS at 96 KiB.  Per stage and wave: 24 MFMAs, 4-6 DMA
+// pieces, 4 weight reads; no converts at all.  Same arguments as k_fc0_mx (ksup / ubeg count K = 64 super-steps).
+constexpr int X3_FR = 16;
+constexpr int X3_U4 = X3_FR * 64; // uint4 per weight stage and per sample buffer
+template <int EPI, bool WIN>
+__global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksup, size_t act_row_u4, int full_tiles,
+                                                int last_cnt, const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
+                                                float* __restrict__ out_part, const int32_t* __restrict__ d_count, int max_count,
+                                                const int32_t* __restrict__ tile_info, const uint2* __restrict__ slot_desc,
+                                                const float* __restrict__ facc) {
+    __shared__ uint4 ldsA[2 * X3_U4];         // [2]{ hi [128 samples][4 pieces] | lo [128 samples][4 pieces] }
+    __shared__ uint4 ldsW0[X3_U4], ldsW1[X3_U4], ldsW2[X3_U4], ldsW3[X3_U4]; // one object per ring slot (see k_fc0_mx)
+    auto ring = [&](int slot) -> uint4* { return slot == 0 ? ldsW0 : slot == 1 ? ldsW1 : slot == 2 ? ldsW2 : ldsW3; };
+    // ---- which tile, which part of K: exactly k_fc0_mx's mapping ----
+    int b0 = blockIdx.x * GT_BS;
+    int count, win_oy = 0, win_ox = 0, ubeg = 0, part_row0 = 0, split_y = (int)blockIdx.y;
+    if (WIN) {
+        const int nt = d_count[4], t_split = d_count[5];
+        const int n_here = EPI == EPI_PARTIAL ? nt - t_split : t_split, eighth = (n_here + 7) >> 3;
+        int tile, ways = 1;
+        if (EPI == EPI_PARTIAL) {
+            ways = d_count[6];
+            const int total = n_here * ways, per_xcd = (total + 7) >> 3;
+            const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+            if (n_here <= 0 || ((int)blockIdx.x >> 3) >= per_xcd || item >= total) return;
+            split_y = item % ways;
+            tile = t_split + item / ways;
+            part_row0 = t_split * GT_BS;
+            out_row_u4 = (size_t)n_here * GT_BS;
+        } else {
+            tile = ((int)blockIdx.x & 7) * eighth + ((int)blockIdx.x >> 3);
+            if (((int)blockIdx.x >> 3) >= eighth || tile >= n_here) return;
+        }
+        b0 = tile * GT_BS;
+        const int ti = tile_info[tile], bin = ti & 0xFF;
+        count = b0 + (ti >> 8);
+        const int nsup = bin < SIB_BINS ? 2 * SIB_WPX : 0, per = (nsup + ways - 1) / ways;
+        ubeg = split_y * per;
+        ksup = nsup - ubeg < per ? nsup - ubeg : per;
+        if (ksup < 0) ksup = 0;
+        win_oy = bin / SIB_ORG;
+        win_ox = bin % SIB_ORG;
+    } else {
+        count = d_count[0];
+        if (count > max_count) count = max_count;
+        if (EPI == EPI_PARTIAL && tile_info) {
+            const int ways = tile_info[0], nsup = full_tiles * 64 + 2 * last_cnt, per = (nsup + ways - 1) / ways;
+            const int tiles = (count + GT_BS - 1) / GT_BS;
+            if (tiles == 0 || (int)blockIdx.x >= tiles * ways) return;
+            split_y = (int)blockIdx.x / tiles;
+            b0 = ((int)blockIdx.x % tiles) * GT_BS;
+            out_row_u4 = (size_t)tile_info[1];
+            ubeg = split_y * per;
+            ksup = nsup - ubeg < per ? nsup - ubeg : per;
+        } else {
+            if (b0 >= count) return;
+            ubeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksup : 0;
+            if (EPI == EPI_PARTIAL) {
+                const int nsup = full_tiles * 64 + 2 * last_cnt;
+                ksup = nsup - ubeg < ksup ? nsup - ubeg : ksup;
+            }
+        }
+        if (ksup < 0) ksup = 0;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int kh = 2 * ksup; // half-steps of this workgroup; local half-step vl = 2 * (local super-step) + mm
+
+    // uint4 offset of the hi part of local half-step vl inside a sample row (the residual part follows at `lo_off`); half-steps past the
+    // end (prefetches) re-read the last one
+    const int lo_off = WIN ? SIB_DLO_U4 : OP_LO_U4;
+    auto a_off = [&](int vl) {
+        vl = vl < kh ? vl : kh - 1;
+        vl = vl < 0 ? 0 : vl;
+        const int u = ubeg + (vl >> 1), mm = vl & 1;
+        if (WIN) {
+            const int uc = u < 2 * SIB_WPX ? u : 2 * SIB_WPX - 1;
+            return ((uc & 1) * SIB_WPX + (uc >> 1)) * 8 + 4 * mm; // difference row: [q][w] parts, super-step u = 2 w + q
+        }
+        const int full = full_tiles * 64;
+        int tile, q, pl;
+        if (u < full) { tile = u >> 6; q = (u >> 5) & 1; pl = u & 31; }
+        else { const int r = u - full; tile = full_tiles; q = r / last_cnt; pl = r % last_cnt; if (q > 1) { q = 1; pl = last_cnt - 1; } }
+        return (tile * 2 + q) * OPX_BLK_U4 + pl * 8 + 4 * mm;
+    };
+    // weight stage group (4 stages) of local half-step vl: absolute half-step of the packed matrix
+    auto w_half = [&](int vl) {
+        vl = vl < 0 ? 0 : vl;
+        const int ul = vl >> 1, mm = vl & 1;
+        int us;
+        if (!WIN) us = ubeg + ul;
+        else {
+            const int u = ubeg + ul < 2 * SIB_WPX ? ubeg + ul : 2 * SIB_WPX - 1;
+            const int w = u >> 1, qq = u & 1, wy = w / SIB_WIN, wx = w - wy * SIB_WIN;
+            const int px = (win_oy + wy) * 15 + win_ox + wx;
+            us = px < full_tiles * 32 ? (px >> 5) * 64 + qq * 32 + (px & 31) : full_tiles * 64 + qq * last_cnt + (px - full_tiles * 32);
+        }
+        return us * 2 + mm;
+    };
+    const uint4* wsrc = wp + (size_t)(wave * 4) * 64; // this wave's 4 fragments of a stage (m-tile 4g + wave); lanes add lane * 16 B
+    const uint32_t w_voff = lane * 16;
+    int w_dma_off = wave * 4 * 64, w_rd_off = wave * 4 * 64 + lane;
+    asm volatile("" : "+s"(w_dma_off));
+    asm volatile("" : "+v"(w_rd_off));
+    auto issue_w = [&](int habs, int g, int slot, int k) { dma16s(wsrc + ((size_t)habs * 4 + g) * X3_U4 + k * 64, w_voff, ring(slot) + w_dma_off + k * 64); };
+    // sample operands of a half-step: per sample 64 B of hi pieces (2s+h) and 64 B of residual pieces, fetched with 4 adjacent lanes on
+    // the 4 adjacent pieces of one sample; wave w stages sample tile w: piece k = 2 * part + half = samples 16 half .. +15 of the tile.
+    // LDS slot (sample, p) holds piece p ^ ((sample >> 2) & 3): the MFMA-fragment ds_read_b128 (lane = sample, 64-B stride) is then
+    // conflict-free (the layout of k_fc0_mx's residual part)
+    const uint4* abase = act + (size_t)(b0 + 32 * wave) * act_row_u4;
+    uint32_t a_voff[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int st = 16 * half + (lane >> 2);
+        a_voff[half] = (uint32_t)(((size_t)st * act_row_u4 + (size_t)((lane & 3) ^ ((st >> 2) & 3))) * 16);
+    }
+    auto issue_a = [&](int aoff, int buf, int k) {
+        const int part = k >> 1, half = k & 1;
+        dma16s<A_NT>(abase + aoff + part * lo_off, a_voff[half], ldsA + buf * X3_U4 + part * 512 + (wave * 2 + half) * 64);
+    };
+    const int sl = lane & 31;
+    int a_rd[2]; // uint4 index of this lane's piece 2s + h inside sample tile 0 of a buffer's hi part (tile c adds 128, the residual part 512)
+#pragma unroll
+    for (int sx = 0; sx < 2; ++sx) a_rd[sx] = sl * 4 + ((2 * sx + h) ^ ((sl >> 2) & 3));
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
+    half8 bh[4][2], bl[4][2]; // sample operands of the current half-step: [sample tile][k-step s]
+    uint4 wc[4];              // this wave's weight fragments of the current stage: hi s0, hi s1, lo s0, lo s1
+    { // prologue, in the issue order of the steady state's last four stages (the counted waits below assume it): A(0), weight stages 0..2,
+      // the first two pieces of A(1), weight stage 3: 22 DMA instructions per wave
+        const int a0 = a_off(0), a1 = a_off(1), h0 = w_half(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) issue_a(a0, 0, k);
+#pragma unroll
+        for (int st = 0; st < 3; ++st)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) issue_w(h0, st, st, k);
+        issue_a(a1, 1, 0);
+        issue_a(a1, 1, 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) issue_w(h0, 3, 3, k);
+        asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); // A(0) and W(0, 0) landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                bh[c][sx] = *(const half8*)(ldsA + c * 128 + a_rd[sx]);
+                bl[c][sx] = *(const half8*)(ldsA + 512 + c * 128 + a_rd[sx]);
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wc[k] = ldsW0[w_rd_off + k * 64];
+    }
+#define GAP() __builtin_amdgcn_sched_barrier(0)
+    // Stage q = (vl, g) lives in ring slot g; its DMA refills slot g with stage q + 4 = (vl + 1, g) (the slot's fragments went to registers
+    // during stage q - 1).  DMA pieces per stage, in issue order: g = 0: A(vl + 1) pieces 2, 3 + 4 weights; g = 1, 2: 4 weights; g = 3
+    // (behind the barrier that proves every wave has read A(vl)'s buffer): A(vl + 2) pieces 0, 1 + 4 weights.  Counted waits: the next
+    // stage's weights (issued three stages ago) have landed when at most {16, 16, 14, 14} younger pieces are outstanding at gap 17 of
+    // g = 0..3; A(vl + 1) has landed at the top of g = 3 when at most 12 are.
+    for (int vl = 0; vl < kh; ++vl) {
+        const int vb = vl & 1;
+        const int a_next = a_off(vl + 1), a_next2 = a_off(vl + 2);
+        const int h_next = w_half(vl + 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            half8 ah[2], al[2];
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) { ah[sx] = __builtin_bit_cast(half8, wc[sx]); al[sx] = __builtin_bit_cast(half8, wc[2 + sx]); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the reads of slot g, issued one stage ago, have returned: its refill may start)
+            if (g == 3) {
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            const uint4* LAn = ldsA + (vb ^ 1) * X3_U4;
+            uint4 wn[4];
+            auto dma_piece = [&](int d) {
+                if (g == 0 || g == 3) {
+                    if (d < 2) { if (g == 3) issue_a(a_next2, vb, d); else issue_a(a_next, vb ^ 1, 2 + d); }
+                    else if (d < 6) issue_w(h_next, g, g, d - 2);
+                } else if (d < 4) issue_w(h_next, g, g, d);
+            };
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int term = 0; term < 3; ++term) {
+                        const int t = (sx * 4 + c) * 3 + term; // MFMA gap 0..23 of the stage
+                        acc[g][c] = MFMA16(term == 1 ? al[sx] : ah[sx], term == 2 ? bl[c][sx] : bh[c][sx], acc[g][c]);
+                        if (t % 3 == 1 && t <= 16) dma_piece(t / 3);
+                        if (t == 17) {
+                            if (g < 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                        }
+                        if (t >= 18 && t < 22) wn[t - 18] = ring((g + 1) & 3)[w_rd_off + (t - 18) * 64];
+                        if (g == 3 && term == 2) { // the next half-step's operands replace this pair right behind its last MFMA
+                            bh[c][sx] = *(const half8*)(LAn + c * 128 + a_rd[sx]);
+                            bl[c][sx] = *(const half8*)(LAn + 512 + c * 128 + a_rd[sx]);
+                        }
+                        GAP();
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wc[k] = wn[k];
+        }
+    }
+#undef GAP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue (accumulator g = m-tile 4g + wave): k_fc0_mx's ----
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int sample = b0 + 32 * c + (lane & 31);
+        if (sample >= count) continue;
+        const float* fa = nullptr;
+        if (WIN && EPI == EPI_PARTIAL) sample -= part_row0;
+        if (WIN && EPI != EPI_PARTIAL) {
+            const uint2 dsc = slot_desc[sample];
+            sample = (int)dsc.x;
+            fa = facc + (size_t)dsc.y * NF;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int mt = 4 * g + wave;
+            if (EPI == EPI_PARTIAL) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = acc[g][c][4 * q4 + q];
+                    *(f32x4*)(out_part + ((size_t)split_y * out_row_u4 + sample) * NF + 32 * mt + 8 * q4 + 4 * h) = o;
+                }
+            } else {
+                float y[16];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 bv = *(const f32x4*)(bias + 32 * mt + 8 * q4 + 4 * h);
+                    f32x4 fv = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (WIN) fv = *(const f32x4*)(fa + 32 * mt + 8 * q4 + 4 * h);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) y[4 * q4 + q] = WIN ? (acc[g][c][4 * q4 + q] + fv[q]) + bv[q] : acc[g][c][4 * q4 + q] + bv[q];
+                }
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = lrelu(y[8 * sx + j]);
+                    half8 hi, lo;
+                    split8(v, hi, lo);
+                    uint4* row = out_split + (size_t)sample * out_row_u4 + (size_t)(2 * mt + sx) * 4;
+                    row[h] = *(const uint4*)&hi;
+                    row[2 + h] = *(const uint4*)&lo;
+                }
+            }
+        }
+    }
+}
+
+// ===============================================================================================
 // OMOK_NET_F16X3: transposed GEMM  D^T[MT*32 x 128 samples] = Wp * Act^T
 // ===============================================================================================
 // Wp : [ksteps][MT][hi|lo][lane][8] f16 (1 KiB fragments), Act: rows of [ksteps][hi h0|hi h1|lo h0|lo h1]
@@ -2262,14 +2666,18 @@ size_t net_alloc(Net& net) {
         ok = ok && A((void**)&net.s1, sizeof(float) * c * NF);
     } else {
         const size_t ks0 = hw * 8;
-        net.row_u4 = (size_t)((hw + 31) / 32) * 2 * OP_BLK_U4 + (getenv("OMOK_ROWPAD_U4") ? atoi(getenv("OMOK_ROWPAD_U4")) : 80);
-        const size_t row_u4 = net.row_u4;
+        const size_t row_pad = getenv("OMOK_ROWPAD_U4") ? atoi(getenv("OMOK_ROWPAD_U4")) : 80;
+        net.row_u4_fmt[FC0_FP6] = (size_t)((hw + 31) / 32) * 2 * OP_BLK_U4 + row_pad;
+        net.row_u4_fmt[FC0_F16] = (size_t)((hw + 31) / 32) * 2 * OPX_BLK_U4 + row_pad;
+        net.row_u4 = net.row_u4_fmt[net.fc0_fmt];
+        const size_t row_u4 = net.row_u4_fmt[FC0_F16]; // buffers are sized for the larger format: the format can change at every commit
         ok = ok && A(&net.wt_trunk, TR_WBYTES + TR_CONV_FRAGS * 1024);
         ok = ok && A((void**)&net.wt_first, sizeof(float) * (TR_SIDE_FLOATS + 2 * NF + heads_mt(net.hw) * 32));
         ok = ok && A(&net.wt_fc0, (ks0 + 4) * (size_t)MXS_FR * 1024); // hw*2 super-steps x 4 stages (= ks0) + 4 stages of padding (prefetch depth)
+        ok = ok && A(&net.wt_fc0x, (2 * ks0 + 8) * (size_t)X3_FR * 1024); // FC0_F16: hw*4 half-steps x 4 stages + 8 stages of padding
         ok = ok && A(&net.wt_fc1, (size_t)32 * 16 * 2 * 1024);
         ok = ok && A(&net.wt_heads, (size_t)32 * heads_mt(net.hw) * 2 * 1024);
-        ok = ok && A(&net.a_fc0, mb * row_u4 * 16 + 2 * OP_BLK_U4 * 16); // + slack: the prefetch of the super-step past the last one reads one block beyond the row
+        ok = ok && A(&net.a_fc0, mb * row_u4 * 16 + 2 * OPX_BLK_U4 * 16); // + slack: the prefetch of the super-step past the last one reads one block beyond the row
         ok = ok && A(&net.h0, mb * 32 * 64 * 2);       // h0 and h1 rows (2 KiB each)
         ok = ok && A((void**)&net.s0, sizeof(float) * mb * heads_mt(net.hw) * 32); // logits
         if (net.n == 15) { // sibling path of the trunk (k_group / k_trunk_sib): run lists and the per-workgroup base scratch
@@ -2285,7 +2693,7 @@ size_t net_alloc(Net& net) {
             ok = ok && A((void**)&net.d_bin_start, sizeof(int32_t) * 96);
             ok = ok && A((void**)&net.d_tile_info, sizeof(int32_t) * (net.d_slots / GT_BS));
             ok = ok && A(&net.d_slot_desc, sizeof(uint2) * net.d_slots);
-            ok = ok && A(&net.d_rows, net.d_slots * (size_t)SIB_DROW_U4 * 16);
+            ok = ok && A(&net.d_rows, net.d_slots * (size_t)SIBX_DROW_U4 * 16);
             ok = ok && A(&net.a_base, net.base_slots * row_u4 * 16);
             ok = ok && A((void**)&net.facc, sizeof(float) * (net.base_slots + mb) * NF);
             ok = ok && A((void**)&net.d_tags, sizeof(int32_t) * (size_t)(net.games > 0 ? 2 * net.games : 2));
@@ -2310,15 +2718,36 @@ size_t net_alloc(Net& net) {
 void net_free(Net& net) {
     void** ptrs[] = {(void**)&net.p, (void**)&net.v, (void**)&net.vpre, (void**)&net.in_f32, (void**)&net.sx, (void**)&net.sh, (void**)&net.sd,
                      (void**)&net.sg, (void**)&net.s0, (void**)&net.s1, &net.wt_trunk, (void**)&net.wt_first, &net.wt_fc0,
-                     &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part, (void**)&net.d_chunk, (void**)&net.d_groups,
+                     &net.wt_fc0x, &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part, (void**)&net.d_chunk, (void**)&net.d_groups,
                      (void**)&net.d_singles, (void**)&net.d_gcnt, (void**)&net.sib_h, (void**)&net.d_sib_rows, (void**)&net.d_sib_slot,
                      (void**)&net.d_bin_start, (void**)&net.d_tile_info, &net.d_slot_desc, &net.d_rows, (void**)&net.part_w, &net.a_base, (void**)&net.facc, (void**)&net.d_tags, &net.d_comp};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     for (int i = 0; i < NET_TENSORS; ++i) { if (net.w[i]) hipFree(net.w[i]); net.w[i] = nullptr; }
 }
 
-int net_commit(Net& net, hipStream_t st) {
+static int net_probe(Net& net, const Store& S, hipStream_t st);
+static int net_pack(Net& net, hipStream_t st);
+
+void net_set_fc0_format(Net& net, int fmt) {
+    net.fc0_fmt = fmt == FC0_F16 ? FC0_F16 : FC0_FP6;
+    net.row_u4 = net.row_u4_fmt[net.fc0_fmt];
+    net.sib_cache_valid = false; // (cached base rows are in the other format)
+}
+
+int net_commit(Net& net, const Store& S, hipStream_t st) {
     if (net.mode == OMOK_NET_F32) return 0;
+    const int rc = net_pack(net, st);
+    if (rc != 0) return rc;
+    static const char* force = getenv("OMOK_FC0_FMT"); // fp6 | f16: overrides the engine's policy (A-B runs)
+    int policy = net.fc0_policy;
+    if (force && !strcmp(force, "fp6")) policy = FC0_FP6;
+    if (force && !strcmp(force, "f16")) policy = FC0_F16;
+    for (int i = 0; i < 8; ++i) net.probe[i] = 0.0f;
+    if (policy != FC0_AUTO) { net_set_fc0_format(net, policy); return 0; }
+    return net_probe(net, S, st);
+}
+
+static int net_pack(Net& net, hipStream_t st) {
     const int hw = net.hw;
     std::vector<std::vector<float>> T(NET_TENSORS);
     for (int i = 0; i < NET_TENSORS; ++i) {
@@ -2434,6 +2863,29 @@ int net_commit(Net& net, hipStream_t st) {
                 }
         if (hipMemcpyAsync(net.wt_fc0, buf.data(), buf.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
         hipStreamSynchronize(st);
+        // ---- fc0, FC0_F16 format (k_fc0_x3): half-step v = 2 u + mm (K = 32: m = 2 q + mm of super-step u's pixel); stage (v, g) = 16 fragments
+        //      [i: m-tile 4g+i][hi s0 | hi s1 | lo s0 | lo s1], fragment = [lane (r, hh)][8]: k = px*128 + kperm(m, s, hh, j), lo = f16(w - f16(w)) ----
+        std::vector<_Float16> xb(((size_t)nsup * 2 * 4 + 8) * X3_FR * 512, (_Float16)0.0f);
+        for (size_t u = 0; u < nsup; ++u)
+            for (int mm = 0; mm < 2; ++mm)
+                for (int g = 0; g < 4; ++g)
+                    for (int i = 0; i < 4; ++i) {
+                        _Float16* stg = xb.data() + ((((size_t)u * 2 + mm) * 4 + g) * X3_FR + (size_t)i * 4) * 512;
+                        const int mt = 4 * g + i, m = 2 * uq[u] + mm;
+                        for (int sx = 0; sx < 2; ++sx)
+                            for (int l = 0; l < 64; ++l) {
+                                const int r = l & 31, hh = l >> 5, n = 32 * mt + r;
+                                for (int j = 0; j < 8; ++j) {
+                                    const size_t k = (size_t)upx[u] * NC + kperm(m, sx, hh, j);
+                                    _Float16 wh, wl;
+                                    split_h(w[k * NF + n], wh, wl);
+                                    stg[(size_t)sx * 512 + l * 8 + j] = wh;
+                                    stg[(size_t)(2 + sx) * 512 + l * 8 + j] = wl;
+                                }
+                            }
+                    }
+        if (hipMemcpyAsync(net.wt_fc0x, xb.data(), xb.size() * 2, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+        hipStreamSynchronize(st);
     }
     {
         const float* w = T[25].data();
@@ -2474,6 +2926,14 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
                                                        d_nrows2);
 }
 
+// the same in the engine's current operand format (ABL bit 64 = FC0_F16 rows)
+template <int N, bool FROM_F32, int ABL = 0>
+static void launch_trunk_fmt(Net& net, const Store& S, int max_count, hipStream_t st, const int32_t* row_list = nullptr, const int32_t* d_nrows = nullptr,
+                             const int32_t* d_out_base = nullptr, const int32_t* d_nrows2 = nullptr) {
+    if (net.fc0_fmt == FC0_F16) launch_trunk<N, FROM_F32, ABL | 64>(net, S, max_count, st, row_list, d_nrows, d_out_base, d_nrows2);
+    else launch_trunk<N, FROM_F32, ABL>(net, S, max_count, st, row_list, d_nrows, d_out_base, d_nrows2);
+}
+
 template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
 static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_row_u4, int k_full, int last_cnt, int lo_off,
                         const float* bias, void* out_split, size_t out_row_u4, float* out_logits, const Store& S, int max_count,
@@ -2506,19 +2966,25 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
     if (!attr_done[net.device & 63]) {
         hipFuncSetAttribute((const void*)k_sib_children<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         hipFuncSetAttribute((const void*)k_sib_children<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute((const void*)k_sib_children<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute((const void*)k_sib_children<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done[net.device & 63] = true;
     }
+    const bool x16 = net.fc0_fmt == FC0_F16;
     k_zero_ints<<<1, 128, 0, st>>>(net.d_gcnt, SIB_CNT_INTS); // (a hipMemsetAsync of these 448 bytes is a 13-us fill kernel)
-    if (delta && !net.sib_cache_valid) { // the trees changed since the last search round: no cached base is valid
+    if (delta && (!net.sib_cache_valid || !net.base_cache)) { // the trees changed since the last search round: no cached base is valid
         hipMemsetAsync(net.d_tags, 0xFF, sizeof(int32_t) * (size_t)net.games * 2, st);
         net.sib_cache_valid = true;
     }
     k_group<<<(S.games + GROUP_TREES - 1) / GROUP_TREES, 64 * GROUP_TREES, 0, st>>>(S, side, (uint2*)net.d_groups, net.d_singles, (uint4*)net.d_sib_rows, net.d_gcnt,
                                                                                      delta ? net.d_sib_slot : nullptr, net.d_tags, (uint2*)net.d_comp);
     if (!delta) {
-        launch_trunk<15, false, 16>(net, S, max_count, st, net.d_singles, net.d_gcnt, nullptr, net.d_gcnt + 1); // base positions of the runs, then the rows outside runs
-        k_sib_children<false><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
-                                                      (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, nullptr, nullptr, nullptr, nullptr, nullptr);
+        // (the copy path keeps the runs' h grids in sib_h[run index]: the slots the difference path caches bases in -- cached bases are void)
+        net.sib_cache_valid = false;
+        launch_trunk_fmt<15, false, 16>(net, S, max_count, st, net.d_singles, net.d_gcnt, nullptr, net.d_gcnt + 1); // base positions of the runs, then the rows outside runs
+        auto kern = x16 ? k_sib_children<false, false, true> : k_sib_children<false>;
+        kern<<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
+                                    (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, nullptr, nullptr, nullptr, nullptr, nullptr);
         return;
     }
     k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu,
@@ -2541,7 +3007,13 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         }
     }
     // runs without a cached base -> compact rows [0, misses) + their base slots; then the single rows -> compact rows [misses, misses + singles)
-    launch_trunk<15, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1);
+    launch_trunk_fmt<15, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1);
+    if (x16) {
+        k_sib_children<true, false, true><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_base, net.row_u4,
+                                                                  (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, net.d_sib_slot, net.d_bin_start,
+                                                                  (uint4*)net.d_rows, (uint2*)net.d_slot_desc, nullptr);
+        return;
+    }
     static const bool tprof = getenv("OMOK_SIB_PROF") && atoi(getenv("OMOK_SIB_PROF")); // timing experiments only
     if (tprof) {
         static unsigned long long* d_tp = nullptr;
@@ -2582,6 +3054,21 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
     const int n_cu = net.n_cu;
     // the live count of full rows is only known on the device: k_bin_prefix chose the K split and the partial slab's row stride (d_gcnt[98], [99])
     const int fgrid = tiles_max > n_cu ? tiles_max : n_cu; // (tiles x ways <= CUs by construction unless there are more tiles than CUs: then 1 way)
+    if (net.fc0_fmt == FC0_F16) { // the same four launches on f16 residuals (k_fc0_x3)
+        const int lc = (hw % 32) ? (hw % 32) : 1;
+        k_fc0_x3<EPI_PARTIAL, false><<<dim3(fgrid, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32, lc, bias_fc0, nullptr,
+                                                                     cap_rows, net.part, net.d_gcnt + 3, max_count, net.d_gcnt + 98, nullptr, nullptr);
+        k_facc_reduce<<<512, 256, 0, st>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 98, net.facc, (const uint2*)net.d_comp, net.d_gcnt + 96, (int)net.base_slots);
+        const int wtiles_max = (tiles_max + SIB_BINS + 1 + 7) / 8 * 8 + 8;
+        k_fc0_x3<EPI_SPLIT, true><<<dim3(wtiles_max, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.d_rows, 0, (size_t)SIBX_DROW_U4, hw / 32, lc, bias_fc0, h0, 128,
+                                                                       nullptr, net.d_gcnt, max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, net.facc);
+        const int stiles = wtiles_max < n_cu + 8 ? wtiles_max : n_cu + 8;
+        k_fc0_x3<EPI_PARTIAL, true><<<dim3(n_cu + 8, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.d_rows, 0, (size_t)SIBX_DROW_U4, hw / 32, lc, bias_fc0, nullptr,
+                                                                       net.part_w_rows, net.part_w, net.d_gcnt, max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, nullptr);
+        k_win_finish<<<(unsigned)(((size_t)stiles * GT_BS * 64 + 255) / 256), 256, 0, st>>>(net.part_w, net.part_w_rows, net.d_gcnt, net.d_tile_info,
+                                                                                             (const uint2*)net.d_slot_desc, net.facc, bias_fc0, h0, 128);
+        return;
+    }
     k_fc0_mx<EPI_PARTIAL><<<dim3(fgrid, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32,
                                                                (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, cap_rows, net.part, net.d_gcnt + 3,
                                                                max_count, net.d_gcnt + 98, nullptr, nullptr);
@@ -2610,7 +3097,7 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     const bool delta = sib && use_sib >= 2 && max_count >= delta_min_rows;
     if (prof) prof->begin(PC_TRUNK, st);
     if (sib) launch_trunk_siblings(net, S, sib_side, max_count, st, delta);
-    else if (net.n == 9) { if (from_f32) launch_trunk<9, true>(net, S, max_count, st); else launch_trunk<9, false>(net, S, max_count, st); }
+    else if (net.n == 9) { if (from_f32) launch_trunk_fmt<9, true>(net, S, max_count, st); else launch_trunk_fmt<9, false>(net, S, max_count, st); }
     else {
         static const int abl = getenv("OMOK_ABL_TRUNK") ? atoi(getenv("OMOK_ABL_TRUNK")) : 0; // timing experiments only
         if (from_f32 && abl == 1) launch_trunk<15, true, 1>(net, S, max_count, st);
@@ -2618,8 +3105,8 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
         else if (from_f32 && abl == 3) launch_trunk<15, true, 3>(net, S, max_count, st);
         else if (from_f32 && abl == 7) launch_trunk<15, true, 7>(net, S, max_count, st);
         else if (from_f32 && abl == 8) launch_trunk<15, true, 8>(net, S, max_count, st);
-        else if (from_f32) launch_trunk<15, true>(net, S, max_count, st);
-        else launch_trunk<15, false>(net, S, max_count, st);
+        else if (from_f32) launch_trunk_fmt<15, true>(net, S, max_count, st);
+        else launch_trunk_fmt<15, false>(net, S, max_count, st);
     }
     if (prof) { prof->end(st); prof->begin(PC_FC0, st); }
     const float* bias_fc0 = net.wt_first + TR_SIDE_FLOATS;
@@ -2659,6 +3146,19 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
             }
         }
         constexpr int LDS = 0; // static LDS objects: (2 + MXS_SLOTS) x 24 KiB
+        if (net.fc0_fmt == FC0_F16) {
+            const int lc = (hw % 32) ? (hw % 32) : 1;
+            if (nsplit == 1)
+                k_fc0_x3<EPI_SPLIT, false><<<dim3(tiles128, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32, lc, bias_fc0, h0, 128,
+                                                                              nullptr, S.d_count, max_count, nullptr, nullptr, nullptr);
+            else {
+                const size_t cap_rows = (size_t)tiles128 * GT_BS;
+                k_fc0_x3<EPI_PARTIAL, false><<<dim3(tiles128, nsplit), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.a_fc0, (nsup + nsplit - 1) / nsplit, net.row_u4,
+                                                                                     hw / 32, lc, bias_fc0, nullptr, cap_rows, net.part, S.d_count, max_count, nullptr, nullptr, nullptr);
+                const size_t threads = (size_t)max_count * 64;
+                k_splitk_finish<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(net.part, nsplit, cap_rows, bias_fc0, h0, 128, S.d_count, max_count);
+            }
+        } else
         if (nsplit == 1) {
             static const int dbg = getenv("OMOK_DBG_FC0") ? atoi(getenv("OMOK_DBG_FC0")) : 0; // timing experiments only
             auto kern = dbg == 1 ? k_fc0_mx<EPI_SPLIT, 1> : dbg == 2 ? k_fc0_mx<EPI_SPLIT, 2> : dbg == 3 ? k_fc0_mx<EPI_SPLIT, 3>
@@ -2743,6 +3243,87 @@ static void forward_chunked(Net& net, const Store& S, int max_count, bool from_f
         v.in_f32 += (size_t)base * 3 * net.hw;
         forward_f16x3(v, S2, mc, from_f32, st, prof);
     }
+}
+
+// ===============================================================================================
+// commit-time probe: which operand format fc0 may use (Net::fc0_policy = FC0_AUTO)
+// ===============================================================================================
+// NET_PROBE_ROWS deterministic positions in the encoder.rs layout (Player mode): a third nearly empty boards (the positions search rounds
+// of the first plies see), a third up to ~60 % full, a third of any density; both sides to move; stones by a hash of (row, cell).
+__device__ inline uint32_t probe_mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+__global__ void k_probe_inputs(float* __restrict__ in, int hw, int rows, int row0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * hw) return;
+    const int r = i / hw, a = i % hw, gr = row0 + r;
+    const uint32_t hr = probe_mix(0x9E3779B9u * (uint32_t)(gr + 1));
+    const uint32_t kind = (uint32_t)gr % 3u;                                      // occupied share of the board in 1 / 1024:
+    const uint32_t dens = kind == 0 ? (hr >> 8) % 40u : kind == 1 ? (hr >> 8) % 600u : (hr >> 8) % 1024u; // < 4 %, < 59 %, any
+    const uint32_t hc = probe_mix(hr ^ (0x85EBCA6Bu * (uint32_t)(a + 1)));
+    const bool occ = (hc & 1023u) < dens, black = (hc >> 10) & 1u;
+    const int turn = (int)(hr & 1u);                                             // 0 = Black to move
+    const bool mine = black == (turn == 0);
+    float* o = in + (size_t)r * 3 * hw;
+    o[2 * a] = occ && mine ? 1.0f : 0.0f;
+    o[2 * a + 1] = occ && !mine ? 1.0f : 0.0f;
+    o[2 * hw + a] = turn == 0 ? 1.0f : 0.0f;
+}
+
+static int net_probe(Net& net, const Store& S, hipStream_t st) {
+    const int hw = net.hw, rp = net.rowp, R = NET_PROBE_ROWS;
+    const int CH = net.max_b < 128 ? net.max_b : 128;
+    Net f32 = net; // a view whose fp32 scratch pointers are temporaries (forward_f32 reads in_f32 and writes p / v / vpre of the engine)
+    f32.mode = OMOK_NET_F32;
+    f32.chunk = CH;
+    float* tmp[6] = {};
+    const size_t sz[6] = {(size_t)CH * hw * NC, (size_t)CH * hw * NM, (size_t)CH * hw * NM, (size_t)CH * hw * NM, (size_t)CH * NF, (size_t)CH * NF};
+    bool ok = true;
+    for (int i = 0; i < 6 && ok; ++i) ok = hipMalloc((void**)&tmp[i], sizeof(float) * sz[i]) == hipSuccess;
+    f32.sx = tmp[0]; f32.sh = tmp[1]; f32.sd = tmp[2]; f32.sg = tmp[3]; f32.s0 = tmp[4]; f32.s1 = tmp[5];
+    std::vector<float> hp[3], hv[3], hl((size_t)CH * hw);
+    for (int k = 0; k < 3; ++k) { hp[k].resize((size_t)CH * rp); hv[k].resize(CH); }
+    float dmax[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, lmax = 0.0f;
+    const int fmt_before = net.fc0_fmt;
+    for (int base = 0; base < R && ok; base += CH) {
+        const int b = R - base < CH ? R - base : CH;
+        k_probe_inputs<<<(b * hw + 255) / 256, 256, 0, st>>>(net.in_f32, hw, b, base);
+        ok = ok && hipMemcpyAsync(S.d_count, &b, sizeof(int32_t), hipMemcpyHostToDevice, st) == hipSuccess;
+        forward_f32(f32, S, b, st, nullptr);
+        ok = ok && hipMemcpyAsync(hp[2].data(), net.p, sizeof(float) * (size_t)b * rp, hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(hv[2].data(), net.v, sizeof(float) * b, hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && hipMemcpyAsync(hl.data(), f32.sh, sizeof(float) * (size_t)b * hw, hipMemcpyDeviceToHost, st) == hipSuccess;
+        for (int fmt = 0; fmt < 2 && ok; ++fmt) {
+            net_set_fc0_format(net, fmt);
+            forward_f16x3(net, S, b, true, st, nullptr);
+            ok = ok && hipMemcpyAsync(hp[fmt].data(), net.p, sizeof(float) * (size_t)b * rp, hipMemcpyDeviceToHost, st) == hipSuccess;
+            ok = ok && hipMemcpyAsync(hv[fmt].data(), net.v, sizeof(float) * b, hipMemcpyDeviceToHost, st) == hipSuccess;
+        }
+        ok = ok && hipStreamSynchronize(st) == hipSuccess && hipGetLastError() == hipSuccess;
+        if (!ok) break;
+        for (int fmt = 0; fmt < 2; ++fmt)
+            for (int r = 0; r < b; ++r) {
+                for (int a = 0; a < hw; ++a) {
+                    const float d = fabsf(hp[fmt][(size_t)r * rp + a] - hp[2][(size_t)r * rp + a]);
+                    if (!(d <= dmax[fmt][0])) dmax[fmt][0] = d == d ? d : INFINITY; // (a NaN counts as a miss)
+                }
+                const float d = fabsf(hv[fmt][r] - hv[2][r]);
+                if (!(d <= dmax[fmt][1])) dmax[fmt][1] = d == d ? d : INFINITY;
+            }
+        for (size_t i = 0; i < (size_t)b * hw; ++i) lmax = fmaxf(lmax, fabsf(hl[i]));
+    }
+    for (int i = 0; i < 6; ++i) if (tmp[i]) hipFree(tmp[i]);
+    if (!ok) { net_set_fc0_format(net, fmt_before); return -1; }
+    net.probe[0] = (float)R;
+    net.probe[1] = dmax[0][0]; net.probe[2] = dmax[0][1];
+    net.probe[3] = dmax[1][0]; net.probe[4] = dmax[1][1];
+    net.probe[5] = lmax;
+    net.probe[6] = 1.0f;
+    const bool fp6_ok = dmax[0][0] <= NET_PROBE_LIMIT && dmax[0][1] <= NET_PROBE_LIMIT;
+    net_set_fc0_format(net, fp6_ok ? FC0_FP6 : FC0_F16);
+    static const bool verbose = getenv("OMOK_PROBE_LOG") && atoi(getenv("OMOK_PROBE_LOG"));
+    if (verbose)
+        fprintf(stderr, "[net probe] N=%d rows=%d: fp6 |dp| %.2e |dv| %.2e, f16 |dp| %.2e |dv| %.2e (max |logit| %.1f) -> %s\n", net.n, R, dmax[0][0], dmax[0][1],
+                dmax[1][0], dmax[1][1], lmax, fp6_ok ? "fp6" : "f16");
+    return 0;
 }
 
 bool net_logits_cover_batch(const Net& net, int max_count) {

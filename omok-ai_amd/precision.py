@@ -1,13 +1,14 @@
-"""Precision of the product net path (split-operand MFMA, fp6 correction terms in fc0) against the OMOK_NET_F32 kernels of the
-same library on the same GPU, for a given set of weights and input rows.  The contract (BASELINE.json north_star) is 1e-3 on
-the outputs of AgentModel::evaluate_pv (alpha-zero/src/agent_model.rs:116-134): p after softmax, v after tanh.  fc0's
-correction terms carry 4 significant bits (block-scaled fp6), i.e. products are good to ~2^-16: with random-init weights the
-outputs agree to 1e-4 .. 7e-4, with trained weights the value head has been seen at 1.05e-3 (N = 9, 200 Adadelta steps).  A
-caller that needs the bound unconditionally runs this check after every weight update (`Trainer` does and logs it) and can fall
-back to `net_mode = OMOK_NET_F32`.
+"""Precision of the product net path (split-operand MFMA) against the OMOK_NET_F32 kernels of the same library on the same GPU, for a
+given set of weights and input rows.  The contract (BASELINE.json north_star) is 1e-3 on the outputs of AgentModel::evaluate_pv
+(alpha-zero/src/agent_model.rs:116-134): p after softmax, v after tanh.
+
+The engine keeps the contract BY ITSELF: `omok_net_commit` measures fc0's fast operand format (block-scaled fp6 correction terms,
+products good to ~2^-15) on a fixed probe set against the fp32 kernels and falls back to f16 correction terms (~2^-22, ~1.5x the fc0
+time) when its worst |dp| or |dv| exceeds 5e-4 (`Engine.stats()`: fc0_format, probe_*).  The functions below are the
+independent check of that choice on rows of the caller's choosing: tests, bench.py and `Trainer` use them.
 
 At board_size 15 the SEARCH ROUNDS take a different path through the first two stages of the net (sibling requests = one base row
-+ 7x7-window difference rows, DESIGN 3.4) than `omok_evaluate_pv`; `measure_search_rounds` checks that path on the request rows of
++ 7x7-window difference rows, DESIGN 3.3) than `omok_evaluate_pv`; `measure_search_rounds` checks that path on the request rows of
 real rounds."""
 import numpy as np
 
@@ -23,6 +24,8 @@ def measure(tensors, n, inputs, device=0, batch_k=16):
     for mode in (B.NET_F16X3, B.NET_F32):
         eng = api.Engine(board_size=n, games=64, max_nodes=8, max_tables=4, max_batch_k=batch_k, device=device, net_mode=mode)
         eng.load_weights(tensors)
+        if mode == B.NET_F16X3:
+            fmt = B.FC0_FORMATS[int(eng.stats()["fc0_format"])]
         p, v = eng.evaluate_pv(x)
         lg, vp = eng.evaluate_logits(x)
         eng.close()
@@ -36,6 +39,7 @@ def measure(tensors, n, inputs, device=0, batch_k=16):
     out["logit_abs_max"] = float(np.abs(lg32).max())
     out["logit_std"] = float(lg32.std())
     out["within_contract"] = bool(out["max_dp"] < 1e-3 and out["max_dv"] < 1e-3)
+    out["fc0_format"] = fmt
     return out
 
 

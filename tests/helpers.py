@@ -27,3 +27,41 @@ def tree_shape(ints):
     for i in range(1, len(ints)):
         depth[i] = depth[parent[i]] + 1  # creation order: parent index < child index
     return int(full.sum()), int(full[1:].sum()), int(depth.max()) if len(ints) else 0
+
+
+def random_positions(n, count, seed):
+    """`count` positions in the encoder.rs input layout [count][3 n n]: random stones (0 .. n*n - 2 of them) placed through the
+    oracle's rules, random side to move."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    out = np.zeros((count, 3 * n * n), dtype=np.float32)
+    for i in range(count):
+        env = O.Environment(n)
+        for c in rng.permutation(n * n)[: int(rng.integers(0, n * n - 1))]:
+            env.place_stone(int(c))
+        out[i] = env.encode_nn_input(int(rng.integers(0, 2)))
+    return out
+
+
+def trained_tensors(n, seed, steps=200):
+    """Weights after `steps` TrainPhase steps (Adadelta on the augmented replay records of a short self-play episode of the
+    random-init net `seed`), on the GPU.  Returns (trained tensors, initial tensors)."""
+    import torch
+    import omok_ai_amd as oa
+    from omok_ai_amd import train as T
+    tensors = oa.weights.init_random(n, seed=seed)
+    eng = oa.Engine(board_size=n, games=32, max_nodes=512, max_tables=256, max_batch_k=8, seed=4 + seed)
+    eng.load_weights(tensors)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    sp.run(32, 8)
+    _, _, plies = sp.game_info()
+    rec = sp.replay_record_bytes()
+    total = 6 * int(plies.sum())
+    buf = torch.empty(total * rec, dtype=torch.uint8, device="cuda")
+    assert sp.replay_augment_into(buf.data_ptr(), total) == total
+    ph = T.TrainPhase(n, tensors, "cuda")
+    ph.run(buf, update_count=steps, batch_size=128, seed=seed)
+    trained = ph.net.tensors()
+    eng.close()
+    return trained, tensors

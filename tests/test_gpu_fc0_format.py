@@ -1,0 +1,165 @@
+"""GPU tests of fc0's operand format: the 1e-3 contract of BASELINE.json's north_star ("policy/value within 1e-3 of the
+reference CPU path") must hold BY DEFAULT -- on random-init, scaled, heavy-tailed and TRAINED weights, for both board sizes -- because
+omok_net_commit measures the fast format (block-scaled fp6 correction terms) on a probe set and falls back to f16 correction terms
+when its worst |dp|, |dv| exceed 5e-4.  The checker is the oracle's fp32 forward (oracle/net.c); the OMOK_NET_F32 kernels are a second
+reference.  Contract quantities: p after softmax, v after tanh (AgentModel::evaluate_pv, alpha-zero/src/agent_model.rs:116-134); the
+pre-softmax logits / pre-tanh value are reported beside them."""
+import os
+
+import numpy as np
+import pytest
+
+import omok_ai_amd as oa
+from omok_ai_amd import binding as B
+from oracle import oracle as O
+from helpers import random_positions, trained_tensors
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+LIMIT = 5e-4  # NET_PROBE_LIMIT
+
+
+def _report(n, tensors, x, tag, mode=B.NET_F16X3, via_file=None):
+    eng = oa.Engine(board_size=n, games=32, max_nodes=16, max_tables=8, max_batch_k=16, net_mode=mode)
+    ref = oa.Engine(board_size=n, games=32, max_nodes=16, max_tables=8, max_batch_k=16, net_mode=B.NET_F32)
+    if via_file:
+        eng.load(via_file)
+    else:
+        eng.load_weights(tensors)
+    ref.load_weights(tensors)
+    st = eng.stats()
+    p, v = eng.evaluate_pv(x)
+    lg, vp = eng.evaluate_logits(x)
+    p32, v32 = ref.evaluate_pv(x)
+    lg32, vp32 = ref.evaluate_logits(x)
+    pc, vc = O.Net(n, tensors).forward(x, threads=8)
+    p, p32 = p.reshape(len(x), -1), p32.reshape(len(x), -1)
+    out = {"dp_oracle": float(np.abs(p - pc).max()), "dv_oracle": float(np.abs(v.reshape(-1) - vc).max()),
+           "dp_f32": float(np.abs(p - p32).max()), "dv_f32": float(np.abs(v - v32).max()),
+           "dlogit": float(np.abs(lg - lg32).max()), "dvpre": float(np.abs(vp - vp32).max()), "logit_max": float(np.abs(lg32).max()),
+           "f32_vs_oracle_dp": float(np.abs(p32 - pc).max()), "format": B.FC0_FORMATS[int(st["fc0_format"])],
+           "probe": (st["probe_rows"], st["probe_dp_fp6"], st["probe_dv_fp6"], st["probe_dp_f16"], st["probe_dv_f16"])}
+    print(f"precision[{tag}] " + " ".join(f"{k}={val:.3e}" if isinstance(val, float) else f"{k}={val}" for k, val in out.items()))
+    eng.close()
+    ref.close()
+    return out
+
+
+def _assert_contract(r, tag):
+    assert r["dp_oracle"] < TOL and r["dv_oracle"] < TOL and r["dp_f32"] < TOL and r["dv_f32"] < TOL, (tag, r)
+
+
+def _assert_probe_rule(r):
+    rows, dp6, dv6, dp16, dv16 = r["probe"]
+    assert rows >= 512
+    assert r["format"] == ("fp6" if (dp6 <= LIMIT and dv6 <= LIMIT) else "f16"), r
+    if r["format"] == "fp6":  # what was kept has the 2x margin on the probe set
+        assert dp6 <= LIMIT and dv6 <= LIMIT
+    assert dp16 < LIMIT and dv16 < LIMIT, r  # the fallback itself is well inside
+
+
+@pytest.mark.parametrize("n", [9, 15])
+@pytest.mark.parametrize("mode,name", [(B.NET_F16X3_FP6, "fp6"), (B.NET_F16X3_F16, "f16")])
+def test_forced_formats_on_random_init(n, mode, name):
+    """Both formats against the oracle on the random initialiser; the f16 format with a 4x margin."""
+    x = random_positions(n, 192, 9)
+    r = _report(n, oa.weights.init_random(n, seed=1), x, f"n={n} forced {name}", mode)
+    assert r["format"] == name and r["probe"][0] == 0  # (no probe when the format is forced)
+    _assert_contract(r, name)
+    if name == "f16":
+        assert max(r["dp_oracle"], r["dv_oracle"], r["dp_f32"], r["dv_f32"]) < 2.5e-4, r
+
+
+@pytest.mark.parametrize("n", [9, 15])
+def test_commit_probe_chooses_by_measurement(n):
+    """omok_get_stats exposes the probe; the format in use follows the documented rule; the default mode then holds the contract on
+    other positions than the probe's (random-init seeds 0..2: at N = 9 seed 0 is a net the fp6 format does not pass)."""
+    x = random_positions(n, 192, 31)
+    formats = []
+    for seed in (0, 1, 2):
+        r = _report(n, oa.weights.init_random(n, seed=seed), x, f"n={n} seed {seed} auto")
+        _assert_probe_rule(r)
+        _assert_contract(r, f"seed {seed}")
+        formats.append(r["format"])
+    print(f"n={n}: formats chosen for seeds 0..2: {formats}")
+
+
+@pytest.mark.parametrize("n", [9, 15])
+def test_contract_on_scaled_and_heavy_tailed_weights(n):
+    """Away from the random initialiser: fc0 / policy-head weights x0.5 and x2 (logits scale with the square), a heavy-tailed fc0
+    (0.05 % of its entries x50: the worst case for a block-scaled low-precision correction term)."""
+    x = random_positions(n, 192, 9)
+    base = oa.weights.init_random(n, seed=1)
+    variants = {}
+    for name, f in (("x0.5", 0.5), ("x2", 2.0)):
+        t = [a.copy() for a in base]
+        t[23] = t[23] * f
+        t[29] = t[29] * f
+        variants[name] = t
+    heavy = [a.copy() for a in base]
+    rng = np.random.default_rng(0)
+    idx = rng.choice(heavy[23].size, size=heavy[23].size // 2000, replace=False)
+    heavy[23].reshape(-1)[idx] *= 50.0
+    variants["heavy-tailed fc0"] = heavy
+    for name, t in variants.items():
+        r = _report(n, t, x, f"n={n} {name}")
+        _assert_probe_rule(r)
+        _assert_contract(r, name)
+
+
+@pytest.mark.parametrize("n", [9, 15])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_contract_after_training_steps(n, seed):
+    """Weights after 200 Adadelta steps on self-play records of the same net, three training seeds per board size: the default
+    mode holds 1e-3 on p AND v against the oracle (round 2 measured 1.05e-3 on v at N = 9 with fp6 correction terms and had relaxed
+    this test to 2e-3: the bound is back, the kernel choice is what changed)."""
+    trained, initial = trained_tensors(n, seed)
+    moved = max(float(np.abs(a - b).max()) for a, b in zip(trained, initial))
+    assert moved > 1e-3, "training did not move the weights"
+    x = random_positions(n, 256, 21 + seed)
+    r = _report(n, trained, x, f"n={n} seed {seed} after 200 training steps")
+    _assert_probe_rule(r)
+    _assert_contract(r, "trained")
+    chk = oa.precision.measure(trained, n, x)
+    assert abs(chk["max_dv"] - r["dv_f32"]) < 1e-6 and chk["within_contract"]
+    if n == 15:  # the search rounds' own path (base + window differences) with the trained weights, on the rows of real rounds
+        rounds = oa.precision.measure_search_rounds(trained, n, games=256, batch_k=16, rounds=4, plies=2, seed=9 + seed)
+        print(f"n=15 seed {seed} trained, search rounds: {rounds}")
+        assert rounds["rows"] > 20000 and rounds["max_dp"] < TOL and rounds["max_dv"] < TOL, rounds
+
+
+@pytest.mark.parametrize("n", [9, 15])
+def test_weights_file_in_the_reference_format_with_larger_magnitudes(n, tmp_path):
+    """A weights file in ModelIO's format (alpha-zero/src/model_io.rs:20-24,59-120) whose tensors are larger than any initialiser
+    makes them (fc matrices x1.3, convolutions up to x1.1, non-zero biases): omok_net_load_file commits through the same probe."""
+    rng = np.random.default_rng(5)
+    t = oa.weights.init_random(n, seed=3)
+    for i, a in enumerate(t):
+        if a.ndim > 1:  # the fc matrices x1.3 (logits x2.2), the convolutions x1.0 .. x1.1; small non-zero biases everywhere
+            f = 1.3 if i >= 23 else 1.0 + 0.1 * rng.random()
+            t[i] = (a * np.float32(f)).astype(np.float32)
+        else:
+            t[i] = (0.02 * rng.standard_normal(a.shape)).astype(np.float32)
+    path = os.path.join(tmp_path, "alpha-zero")
+    oa.model_file.save(path, oa.weights.tensor_names(), t)
+    x = random_positions(n, 192, 77)
+    r = _report(n, t, x, f"n={n} weights file, larger magnitudes", via_file=path)
+    _assert_probe_rule(r)
+    _assert_contract(r, "file")
+
+
+def test_format_switch_between_commits_keeps_results_consistent():
+    """One engine, three commits (a net that keeps fp6, one that needs f16, the first again): the row strides, the sibling cache and
+    the kernels follow the format of the LAST commit; the results of the first and third commit are bit-identical."""
+    n = 9
+    x = random_positions(n, 64, 3)
+    eng = oa.Engine(board_size=n, games=32, max_nodes=16, max_tables=8, max_batch_k=16)
+    outs, fmts = [], []
+    for seed in (1, 0, 1):
+        eng.load_weights(oa.weights.init_random(n, seed=seed))
+        fmts.append(B.FC0_FORMATS[int(eng.stats()["fc0_format"])])
+        outs.append(eng.evaluate_pv(x))
+    print("formats:", fmts)
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[2][0].view(np.uint32)) and np.array_equal(outs[0][1].view(np.uint32), outs[2][1].view(np.uint32))
+    assert fmts[0] == fmts[2]
+    eng.close()

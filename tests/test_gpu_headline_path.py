@@ -1,0 +1,176 @@
+"""GPU tests of the path the headline number is measured on ("weak" #2): `omok_selfplay_run` / `omok_execute` fuse
+the net's softmax / tanh into the policy scatter (k_softmax_scatter_policy), defer a round's backups into the head of the next
+round's kernel, and at board_size 15 evaluate sibling requests as one base position + 7x7-window differences with a per-game cache of
+base evaluations.  The oracle tests drive the step-wise API (separate softmax, immediate backups); this file closes the chain:
+
+  (a) omok_execute == the step-wise path, tree dumps bit for bit, at 15x15 / 800 simulations (fully expanded nodes, depth >= 3)
+  (b) omok_selfplay_run twice at 15x15 on the difference path -> identical packed replay bytes (slots are handed out by atomics)
+  (c) the difference path's p / v of real rounds against the ORACLE's forward (not the fp32 kernels), random-init and trained weights
+  (d) base cache on / off -> bit-identical p / v and trees
+  (e) rounds of different sizes inside one ply (difference -> copy -> difference path) never read a stale base
+Reference: alpha-zero/src/parallel_mcts_executor.rs:194-265 (evaluate + scatter of a round), agent_model.rs:116-134."""
+import numpy as np
+import pytest
+
+import omok_ai_amd as oa
+from omok_ai_amd import binding as B
+from oracle import oracle as O
+from helpers import trained_tensors, tree_shape
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _dumps(sp, games):
+    return [sp.tree_dump(g, s) for g in range(games) for s in (0, 1)]
+
+
+def _same_dumps(a, b, tag):
+    for i, ((ai, af), (bi, bf)) in enumerate(zip(a, b)):
+        assert ai.shape == bi.shape and np.array_equal(ai, bi), f"{tag}: node records of tree {i} differ"
+        assert np.array_equal(af.view(np.uint32), bf.view(np.uint32)), f"{tag}: w / policy bits of tree {i} differ"
+
+
+@pytest.mark.parametrize("mode", [B.NET_F16X3_ROWS, B.NET_F32, B.NET_F16X3])
+def test_execute_equals_stepwise_in_the_benchmark_regime(mode):
+    """(a) N = 15, 2 games, 800 simulations per move, 2 plies: the run loop's rounds (fused softmax + scatter, backups deferred into
+    the next k_round) leave the trees the step-wise rounds leave, and those trees are in the regime the headline runs in."""
+    n, games, count, k = 15, 2, 800, 16
+    tensors = oa.weights.init_random(n, seed=0)
+    out = []
+    for variant in ("execute", "stepwise"):
+        eng = oa.Engine(board_size=n, games=games, max_nodes=4224, max_tables=1056, max_batch_k=k, seed=5, net_mode=mode)
+        eng.load_weights(tensors)
+        sp = oa.SelfPlay(eng)
+        sp.reset()
+        per_ply = []
+        for _ in range(2):
+            if variant == "execute":
+                sp.execute(count, k)
+                per_ply.append(_dumps(sp, games))
+                sp.sample_actions(1.0, 30)
+                sp.advance()
+            else:
+                for rnd in range(count // k):
+                    sp.round_generate(rnd, k)
+                    sp.round_eval()
+                    sp.round_scatter()
+                per_ply.append(_dumps(sp, games))
+                sp.sample_actions(1.0, 30)
+                sp.mirror_generate()
+                sp.mirror_eval()
+                sp.mirror_apply()
+        per_ply.append(_dumps(sp, games))
+        out.append(per_ply)
+        eng.close()
+    for ply, (a, b) in enumerate(zip(out[0], out[1])):
+        _same_dumps(a, b, f"mode {mode} after ply {ply}")
+    shapes = [tree_shape(ints) for ints, _ in out[0][0]]
+    full_nr, depth = max(s[1] for s in shapes), max(s[2] for s in shapes)
+    print(f"mode {mode}: fully expanded non-root nodes {full_nr}, depth {depth}")
+    assert full_nr >= 1 and depth >= 3
+
+
+def _packed_run(n, games, count, k, plies, seed, tensors, cache=True):
+    import torch
+    eng = oa.Engine(board_size=n, games=games, max_nodes=4 * count + 256, max_tables=count + 64, max_batch_k=k, seed=seed)
+    eng.load_weights(tensors)
+    eng.set_base_cache(cache)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    sp.run(count, k, max_plies=plies)
+    rec = sp.replay_record_bytes()
+    cap = games * plies
+    buf = torch.zeros(cap * rec, dtype=torch.uint8, device="cuda")
+    got = sp.replay_pack_into(buf.data_ptr(), cap)
+    data = buf[: got * rec].cpu().numpy().copy()
+    dumps = _dumps(sp, min(games, 8))
+    eng.close()
+    return got, data, dumps
+
+
+def test_selfplay_run_on_the_difference_path_is_reproducible_and_cache_independent():
+    """(b) + (d): two runs of omok_selfplay_run at N = 15 with 4096-row rounds (>= 3072: difference path, k_group hands out slots with
+    atomics) give the same packed replay bytes and trees; a third run with the base cache switched off gives them too (a cached base
+    evaluation == its recomputation, bit for bit)."""
+    n, games, count, k, plies = 15, 256, 96, 16, 4
+    tensors = oa.weights.init_random(n, seed=0)
+    a = _packed_run(n, games, count, k, plies, 3, tensors)
+    b = _packed_run(n, games, count, k, plies, 3, tensors)
+    c = _packed_run(n, games, count, k, plies, 3, tensors, cache=False)
+    assert a[0] == games * plies
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]), "two identical runs differ"
+    _same_dumps(a[2], b[2], "run vs run")
+    assert a[0] == c[0] and np.array_equal(a[1], c[1]), "base cache on / off differ"
+    _same_dumps(a[2], c[2], "cache on vs off")
+
+
+@pytest.mark.parametrize("weights", ["random-init", "trained"])
+def test_difference_path_outputs_against_the_oracle(weights):
+    """(c) the p / v that rounds on the difference path deliver, against the oracle's fp32 forward of the same request rows (>= 256
+    rows per weight set, taken across the rounds of two plies), in the default mode with its committed operand format."""
+    n, games, k = 15, 224, 16  # 3584 rows per round >= 3072
+    tensors = oa.weights.init_random(n, seed=2) if weights == "random-init" else trained_tensors(n, 1)[0]
+    eng = oa.Engine(board_size=n, games=games, max_nodes=512, max_tables=128, max_batch_k=k, seed=21)
+    eng.load_weights(tensors)
+    fmt = B.FC0_FORMATS[int(eng.stats()["fc0_format"])]
+    net = O.Net(n, tensors)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    rng = np.random.default_rng(0)
+    rows, dp, dv, differing = 0, 0.0, 0.0, 0
+    for ply in range(2):
+        for rnd in range(5):
+            nreq = sp.round_generate(rnd, k, 0.25, 0.03)
+            x = sp.round_inputs().copy()
+            p, v = sp.round_eval()
+            p, v = np.array(p).reshape(nreq, -1).copy(), np.array(v).reshape(-1).copy()
+            sp.round_scatter()
+            if rnd == 0:
+                continue
+            assert nreq == games * k
+            pick = rng.choice(nreq, size=48, replace=False)
+            pc, vc = net.forward(x[pick], threads=8)
+            dp, dv = max(dp, float(np.abs(p[pick] - pc).max())), max(dv, float(np.abs(v[pick] - vc).max()))
+            pp, _ = eng.evaluate_pv(x[pick])
+            differing += int((p[pick].view(np.uint32) != pp.reshape(len(pick), -1).view(np.uint32)).any(axis=1).sum())
+            rows += len(pick)
+        sp.sample_actions(1.0, 30)
+        sp.advance()
+    print(f"difference path vs the oracle, {weights} weights (format {fmt}): {rows} rows, max|dp| {dp:.2e} max|dv| {dv:.2e}; {differing} rows differ from row-by-row bits")
+    assert rows >= 256 and dp < TOL and dv < TOL
+    assert differing > rows // 2  # (the path under test really ran)
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", [B.NET_F16X3_FP6, B.NET_F16X3_F16])
+def test_rounds_of_different_sizes_in_one_ply_never_read_a_stale_base(mode):
+    """(e) K = 16, 4, 16 rounds inside one ply at 400 games: 6400 rows (difference path: bases cached per game), 1600 rows (copy
+    path: it keeps its h grids in the slots the cache uses), 6400 rows again.  Every round's p / v must be those of the requested
+    positions: the copy path equals row-by-row evaluation bit for bit, the difference path stays within 5e-4 of it.  Also: the copy
+    path's operand rows == the rows a row-by-row evaluation writes, byte for byte (both operand formats)."""
+    n, games = 15, 400
+    eng = oa.Engine(board_size=n, games=games, max_nodes=512, max_tables=128, max_batch_k=16, seed=8, net_mode=mode)
+    eng.load_random_weights(3)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    for ply in range(2):
+        for rnd, k in enumerate((16, 16, 4, 16, 4, 16)):
+            nreq = sp.round_generate(rnd, k, 0.25, 0.03)
+            x = sp.round_inputs().copy()
+            p, v = sp.round_eval()
+            p, v = np.array(p).reshape(nreq, -1).copy(), np.array(v).reshape(-1).copy()
+            copy_path = games * k < 3072
+            rows_round = eng.operand_rows(0, min(nreq, 640)).copy() if copy_path else None
+            sp.round_scatter()
+            pp, vp = eng.evaluate_pv(x)
+            pp, vp = pp.reshape(nreq, -1), vp.reshape(-1)
+            if copy_path:
+                assert np.array_equal(p.view(np.uint32), pp.view(np.uint32)) and np.array_equal(v.view(np.uint32), vp.view(np.uint32)), (ply, rnd)
+                live = rows_round.shape[1] - 80 * 16  # (the row pad is never written)
+                assert np.array_equal(rows_round[:, :live], eng.operand_rows(0, min(nreq, 640))[:, :live]), (ply, rnd)
+            else:
+                assert np.abs(p - pp).max() < 5e-4 and np.abs(v - vp).max() < 5e-4, (ply, rnd, float(np.abs(p - pp).max()), float(np.abs(v - vp).max()))
+        sp.sample_actions(1.0, 30)
+        sp.advance()
+    eng.close()
