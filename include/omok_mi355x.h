@@ -39,7 +39,7 @@ extern "C" {
 
 #define OMOK_NET_F16X3 0 /* split-operand MFMA (x = hi + lo, hi = f16(x): f16 main term + two correction terms, fp32 accumulate).  The
                             correction terms of trunk, fc1 and heads are f16; those of fc0 (68 % of the flops) are block-scaled fp6 (products good to
-                            ~2^-15) or f16 (~2^-22, ~2x the fc0 time): omok_net_commit evaluates a fixed probe set of 1152 positions in both
+                            ~2^-15) or f16 (~2^-22, ~2x the fc0 time): omok_net_commit evaluates a fixed probe set of 2048 positions in both
                             formats and with the fp32 kernels and keeps fp6 only while its worst |dp|, |dv| stay within 5e-4 = half the
                             1e-3 contract on AgentModel::evaluate_pv's outputs (OMOK_STAT_FC0_FORMAT / OMOK_STAT_PROBE_*) */
 #define OMOK_NET_F32 1   /* plain fp32 VALU kernels (debug / A-B reference on the GPU) */

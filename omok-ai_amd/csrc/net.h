@@ -11,7 +11,7 @@ constexpr int NM = 32;  // RESIDUAL_MIDDLE_CHANNELS (:25)
 constexpr int NF = 512; // FC_0_SIZE / FC_1_SIZE (:29-30)
 enum { FC0_AUTO = -1, FC0_FP6 = 0, FC0_F16 = 1 };
 constexpr float NET_PROBE_LIMIT = 5e-4f; // fp6 correction terms are kept only while the probe's worst |dp|, |dv| stay below this (2x margin to the 1e-3 contract)
-constexpr int NET_PROBE_ROWS = 1152;
+constexpr int NET_PROBE_ROWS = 2048;
 
 struct Net {
     int n = 0, hw = 0, rowp = 0, mode = 0;

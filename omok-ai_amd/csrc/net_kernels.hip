@@ -3248,16 +3248,16 @@ static void forward_chunked(Net& net, const Store& S, int max_count, bool from_f
 // ===============================================================================================
 // commit-time probe: which operand format fc0 may use (Net::fc0_policy = FC0_AUTO)
 // ===============================================================================================
-// NET_PROBE_ROWS deterministic positions in the encoder.rs layout (Player mode): a third nearly empty boards (the positions search rounds
-// of the first plies see), a third up to ~60 % full, a third of any density; both sides to move; stones by a hash of (row, cell).
+// NET_PROBE_ROWS deterministic positions in the encoder.rs layout (Player mode): two fifths nearly empty boards (the positions search rounds
+// of the first plies see: the largest errors were measured there), two fifths up to ~60 % full, a fifth of any density; both sides to move; stones by a hash of (row, cell).
 __device__ inline uint32_t probe_mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 __global__ void k_probe_inputs(float* __restrict__ in, int hw, int rows, int row0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * hw) return;
     const int r = i / hw, a = i % hw, gr = row0 + r;
     const uint32_t hr = probe_mix(0x9E3779B9u * (uint32_t)(gr + 1));
-    const uint32_t kind = (uint32_t)gr % 3u;                                      // occupied share of the board in 1 / 1024:
-    const uint32_t dens = kind == 0 ? (hr >> 8) % 40u : kind == 1 ? (hr >> 8) % 600u : (hr >> 8) % 1024u; // < 4 %, < 59 %, any
+    const uint32_t kind = (uint32_t)gr % 5u;                                      // occupied share of the board in 1 / 1024:
+    const uint32_t dens = kind < 2 ? (hr >> 8) % 40u : kind < 4 ? (hr >> 8) % 600u : (hr >> 8) % 1024u; // 40 % of the rows < 4 %, 40 % < 59 %, 20 % any
     const uint32_t hc = probe_mix(hr ^ (0x85EBCA6Bu * (uint32_t)(a + 1)));
     const bool occ = (hc & 1023u) < dens, black = (hc >> 10) & 1u;
     const int turn = (int)(hr & 1u);                                             // 0 = Black to move
