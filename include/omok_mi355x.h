@@ -136,6 +136,16 @@ int omok_execute(omok_engine* e, int32_t count, int32_t batch_size, float epsilo
  * are evaluated as one batch and scattered by the same wavefronts.  waves = 1 is the sequential schedule: identical, bit for
  * bit, to omok_execute.  With waves > 1 the result depends on the interleaving, as it does in the reference. */
 int omok_execute_shared(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha, int32_t waves);
+/* The same search under a RECORDED interleaving, for exact parity tests of waves > 1 (the reference's schedule is whatever its thread pool
+ * does): every whole simulation and every backup of a scatter phase runs under the tree lock, i.e. the run is a sequential interleaving of
+ * the waves' simulations -- one of the schedules the reference can produce -- and the lock order is reported so that a CPU restatement of
+ * MCTSExecutor::run (mcts_executor.rs:76-255) can replay it.  G = ceil(ceil(count / batch_size) / waves) groups of `waves` rounds;
+ * sim_order, backup_order [G][waves * batch_size]: wave index of the i-th simulation / backup of the group (0xFF beyond the group's
+ * count); group_counts [G][3] = simulations, backups, requests; p [cap_requests][N*N], v [cap_requests]: the net outputs of all requests
+ * in evaluation order (group by group, inside a group by wave then simulation); *n_groups, *n_requests. */
+int omok_execute_shared_recorded(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha, int32_t waves,
+                                 uint8_t* sim_order, uint8_t* backup_order, int32_t* group_counts, float* p, float* v,
+                                 int32_t cap_requests, int32_t* n_groups, int32_t* n_requests);
 /* Agent::sample_action for every live game (agent.rs:83-137) with the trainer's mode rule
  * (trainer.rs:138-146): Boltzmann(temperature) while the game's ply < threshold, else Best.
  * Records the transition (env before the move, pi) like trainer.rs:150-173.

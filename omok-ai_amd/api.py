@@ -241,6 +241,27 @@ class SelfPlay:
         """MCTSExecutor::run: one tree (games = 1) searched by `waves` wavefronts"""
         self._chk(B.lib().omok_execute_shared(self.h, count, batch_size, epsilon, alpha, waves))
 
+    def execute_shared_recorded(self, count, batch_size, epsilon=0.25, alpha=0.03, waves=8):
+        """omok_execute_shared_recorded: returns a list of groups, each (sim_order [wave ids], backup_order [wave ids], p [req][HW], v [req])."""
+        rounds = -(-count // batch_size)
+        groups = -(-rounds // waves)
+        per = waves * batch_size
+        so = np.zeros((groups, per), dtype=np.uint8)
+        bo = np.zeros((groups, per), dtype=np.uint8)
+        gc = np.zeros((groups, 3), dtype=np.int32)
+        cap = rounds * batch_size
+        p = np.zeros((cap, self.hw), dtype=np.float32)
+        v = np.zeros(cap, dtype=np.float32)
+        ng, nr = C.c_int32(), C.c_int32()
+        self._chk(B.lib().omok_execute_shared_recorded(self.h, count, batch_size, epsilon, alpha, waves, B.u8ptr(so), B.u8ptr(bo), B.iptr(gc), B.fptr(p), B.fptr(v),
+                                                       cap, C.byref(ng), C.byref(nr)))
+        out, base = [], 0
+        for g in range(ng.value):
+            ns, nb, nq = (int(x) for x in gc[g])
+            out.append((so[g, :ns].copy(), bo[g, :nb].copy(), p[base:base + nq].copy(), v[base:base + nq].copy()))
+            base += nq
+        return out
+
     def sample_actions(self, temperature=1.0, threshold=30):
         a = np.zeros(self.games, dtype=np.int32)
         self._chk(B.lib().omok_sample_actions(self.h, temperature, threshold, B.iptr(a)))

@@ -21,7 +21,7 @@ STAT_NAMES = ["sims", "evals", "ply_games", "finished", "ms_tree", "ms_trunk", "
 # every symbol include/omok_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "omok_create", "omok_destroy", "omok_last_error", "omok_net_num_tensors", "omok_net_tensor_size", "omok_net_load",
-    "omok_net_commit", "omok_net_load_file", "omok_net_save_file", "omok_evaluate_pv", "omok_evaluate_logits", "omok_env_play", "omok_env_place_stone", "omok_encode_nn_input", "omok_selfplay_reset", "omok_set_episode", "omok_execute", "omok_execute_shared",
+    "omok_net_commit", "omok_net_load_file", "omok_net_save_file", "omok_evaluate_pv", "omok_evaluate_logits", "omok_env_play", "omok_env_place_stone", "omok_encode_nn_input", "omok_selfplay_reset", "omok_set_episode", "omok_execute", "omok_execute_shared", "omok_execute_shared_recorded",
     "omok_compute_policy", "omok_play_actions", "omok_set_actions", "omok_root_children",
     "omok_sample_actions", "omok_advance", "omok_selfplay_run", "omok_selfplay_run_slots", "omok_round_generate", "omok_round_inputs",
     "omok_round_eval", "omok_round_outputs", "omok_round_inject", "omok_round_scatter", "omok_mirror_generate",
@@ -78,6 +78,7 @@ def lib():
     L.omok_env_play.argtypes = [H, ip, C.c_int32, C.c_int32, ip, u8p, u8p, C.POINTER(C.c_uint16)]
     L.omok_encode_nn_input.argtypes = [H, u8p, u8p, C.c_int32, C.c_int32, fp]
     L.omok_selfplay_reset.argtypes = [H]
+    L.omok_execute_shared_recorded.argtypes = [H, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, u8p, u8p, ip, fp, fp, C.c_int32, ip, ip]
     L.omok_operand_row_bytes.argtypes = [H]
     L.omok_operand_row_bytes.restype = C.c_int64
     L.omok_debug_operand_rows.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]

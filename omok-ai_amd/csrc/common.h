@@ -113,10 +113,12 @@ void launch_refill(int n, const Store& S, const float* root_policy_dev, int32_t*
 void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st);
 void launch_scan(int n, const Store& S, int side, int K, hipStream_t st, unsigned long long* evals_dev = nullptr); // evals_dev[0] += the round's requests
 // one tree searched by `waves` waves (MCTSExecutor::run): sh_req [waves][KMAX] u16, sh_cnt [2 * KMAX] u32 (counts | bases)
+// rec_order / rec_pos non-NULL: RECORDED mode -- every simulation (round kernel) / every backup (scatter kernel) runs under the tree lock and
+// appends its wave's index to rec_order[(*rec_pos)++]: an exactly replayable interleaving (omok_execute_shared_recorded)
 void launch_round_shared(int n, const Store& S, const RoundArgs& a, int rounds_total, int group, int waves, uint16_t* sh_req, uint32_t* sh_cnt,
-                         hipStream_t st);
+                         hipStream_t st, uint8_t* rec_order = nullptr, uint32_t* rec_pos = nullptr);
 void launch_scatter_shared(int n, const Store& S, int side, const float* p_dev, const float* v_dev, int max_count, int waves, const uint16_t* sh_req,
-                           const uint32_t* sh_cnt, hipStream_t st);
+                           const uint32_t* sh_cnt, hipStream_t st, uint8_t* rec_order = nullptr, uint32_t* rec_pos = nullptr);
 constexpr int MAX_TREE_WAVES = 16; // one workgroup of 1024 threads
 // backups = false: the policies only; the backups (k_scatter) are deferred to launch_backups or into the next round's kernel (RoundArgs::scatter_v)
 void launch_scatter(int n, const Store& S, int side, const float* p_dev, const float* v_dev, int max_count, hipStream_t st, bool backups = true);

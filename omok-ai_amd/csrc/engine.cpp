@@ -684,6 +684,69 @@ extern "C" int omok_execute_shared(omok_engine* e, int32_t count, int32_t batch_
     return tree_error(e, bits);
 }
 
+// The same search with a RECORDED interleaving (tests): every simulation and every backup of the scatter phase runs under the tree lock and
+// the lock order is written down, group by group, together with the net outputs of the group's requests -- everything a CPU restatement of
+// MCTSExecutor::run needs to replay the run exactly (tests/test_gpu_shared_tree.py).
+extern "C" int omok_execute_shared_recorded(omok_engine* e, int32_t count, int32_t batch_size, float epsilon, float alpha, int32_t waves,
+                                            uint8_t* sim_order, uint8_t* backup_order, int32_t* group_counts, float* p, float* v,
+                                            int32_t cap_requests, int32_t* n_groups, int32_t* n_requests) {
+    if (!e || !sim_order || !backup_order || !group_counts || !p || !v || !n_groups || !n_requests) return OMOK_ERR_INVALID;
+    if (need_net(e) || need_reset(e)) return OMOK_ERR_STATE;
+    if (check_exec_args(e, count, batch_size, epsilon, alpha)) return OMOK_ERR_INVALID;
+    if (e->cfg.games != 1) return fail(e, OMOK_ERR_INVALID, "omok_execute_shared_recorded searches ONE tree: create the engine with games = 1 (got %d)", e->cfg.games);
+    if (waves < 1 || waves > MAX_TREE_WAVES || waves * batch_size > e->net.max_b)
+        return fail(e, OMOK_ERR_INVALID, "waves must be in [1, max_tree_waves = %d] (and waves * batch_size <= %d)", e->cfg.max_tree_waves, e->net.max_b);
+    ENTER(e);
+    const size_t per = (size_t)waves * batch_size;
+    uint8_t* d_rec = nullptr;   // [2][per] wave ids: simulations, backups
+    uint32_t* d_pos = nullptr;  // [2]
+    if (hipMalloc((void**)&d_rec, 2 * per) != hipSuccess || hipMalloc((void**)&d_pos, 8) != hipSuccess) {
+        if (d_rec) hipFree(d_rec);
+        return fail(e, OMOK_ERR_HIP, "recorded mode: device allocation failed");
+    }
+    auto done = [&](int rc) { hipFree(d_rec); hipFree(d_pos); return rc; };
+    uint32_t bits = 0, alive = 0;
+    if (read_status(e, &bits, &alive)) return done(OMOK_ERR_HIP);
+    const int side = e->ply & 1;
+    RoundArgs a{side, 0, 0, e->ply, epsilon, alpha, e->key, e->cfg.game_offset};
+    launch_round(e->n, e->S, a, e->st); // K = 0, round 0: the root's Dirichlet noise only (mcts_executor.rs:38-68)
+    int exec_count = count / batch_size; // :70-74
+    if (exec_count * batch_size != count) exec_count += 1;
+    a.K = batch_size;
+    int groups = 0, total_req = 0;
+    std::vector<float> prow((size_t)per * e->rowp);
+    for (int group = 0; group * waves < exec_count; ++group, ++groups) {
+        hipMemsetAsync(d_rec, 0xFF, 2 * per, e->st);
+        hipMemsetAsync(d_pos, 0, 8, e->st);
+        launch_round_shared(e->n, e->S, a, exec_count, group, waves, e->d_sh_req, e->d_sh_cnt, e->st, d_rec, d_pos);
+        k_add_evals<<<1, 64, 0, e->st>>>(e->S.d_count, e->d_evals);
+        int32_t cnt = 0;
+        if (hipMemcpyAsync(&cnt, e->S.d_count, 4, hipMemcpyDeviceToHost, e->st) != hipSuccess || sync_and_check(e, "execute_shared_recorded")) return done(OMOK_ERR_HIP);
+        if (total_req + cnt > cap_requests) return done(fail(e, OMOK_ERR_INVALID, "recorded mode: more than cap_requests = %d requests", cap_requests));
+        if (cnt > 0) {
+            net_forward_requests(e->net, e->S, waves * batch_size, e->st, &e->prof);
+            hipMemcpyAsync(prow.data(), e->net.p, sizeof(float) * (size_t)cnt * e->rowp, hipMemcpyDeviceToHost, e->st);
+            hipMemcpyAsync(v + total_req, e->net.v, sizeof(float) * cnt, hipMemcpyDeviceToHost, e->st);
+        }
+        launch_scatter_shared(e->n, e->S, side, e->net.p, e->net.v, waves * batch_size, waves, e->d_sh_req, e->d_sh_cnt, e->st, d_rec + per, d_pos + 1);
+        uint32_t pos[2] = {0, 0};
+        hipMemcpyAsync(sim_order + (size_t)group * per, d_rec, per, hipMemcpyDeviceToHost, e->st);
+        hipMemcpyAsync(backup_order + (size_t)group * per, d_rec + per, per, hipMemcpyDeviceToHost, e->st);
+        hipMemcpyAsync(pos, d_pos, 8, hipMemcpyDeviceToHost, e->st);
+        if (sync_and_check(e, "execute_shared_recorded")) return done(OMOK_ERR_HIP);
+        for (int r = 0; r < cnt; ++r) memcpy(p + (size_t)(total_req + r) * e->hw, prow.data() + (size_t)r * e->rowp, sizeof(float) * e->hw);
+        group_counts[3 * group] = (int32_t)pos[0];
+        group_counts[3 * group + 1] = (int32_t)pos[1];
+        group_counts[3 * group + 2] = cnt;
+        total_req += cnt;
+    }
+    *n_groups = groups;
+    *n_requests = total_req;
+    e->sims += (double)exec_count * batch_size * alive;
+    if (read_status(e, &bits, &alive)) return done(OMOK_ERR_HIP);
+    return done(tree_error(e, bits));
+}
+
 static void enqueue_sample(omok_engine* e, float temperature, int threshold) {
     e->prof.begin(PC_PLY, e->st);
     launch_sample(e->n, e->S, e->ply & 1, e->ply, temperature, threshold, e->key, e->cfg.game_offset, e->d_actions, e->st);

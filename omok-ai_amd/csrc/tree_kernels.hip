@@ -616,13 +616,13 @@ __device__ inline void backup_shared(const Tree<N>& T, int x, float v) { // node
 // Node::expand under the tree lock; returns the node index, -1 on arena overflow, -2 if another wave expanded the action first
 template <int N>
 __device__ inline int add_child_shared(const Store& S, const Tree<N>& T, int* lock, int parent, int action, const uint64_t* bb,
-                                       int status, int turn) {
+                                       int status, int turn, bool lock_held = false) {
     using G = Geo<N>;
     const int lane = LANE;
     volatile NodeHdr* hdr = T.hdr;
     volatile TreeState* ts = T.ts;
     volatile uint8_t* corder = T.corder;
-    tree_lock(lock);
+    if (!lock_held) tree_lock(lock);
     int result;
     const uint16_t nch = hdr[parent].nch, legal = hdr[parent].legal;
     int tab = hdr[parent].table;
@@ -660,13 +660,38 @@ __device__ inline int add_child_shared(const Store& S, const Tree<N>& T, int* lo
         if (lane == 0) { corder[slot] = (uint8_t)nch; hdr[parent].nch = (uint16_t)(nch + 1); ts->n_nodes = n_nodes + 1u; }
         result = idx;
     }
-    tree_unlock(lock);
+    if (!lock_held) tree_unlock(lock);
     return result;
 }
 
+// RECORDED mode (rec_order != NULL; omok_execute_shared_recorded): a wave holds the tree lock for its WHOLE simulation -- descent,
+// expansion and a terminal backup -- and writes its index into rec_order at the position the lock order gives it.  The run is then a
+// sequential interleaving of the waves' simulations (one of the schedules the reference's pool can produce) that a CPU restatement can
+// replay exactly (tests/test_gpu_shared_tree.py), so trees of W > 1 searches compare bit for bit instead of statistically.
+template <int N>
+__device__ void run_sim_shared_body(const Store& S, const Tree<N>& T, int* lock, const RoundArgs& A, uint32_t sim_index, uint32_t tree_global,
+                                    uint16_t* my_req, uint32_t& n_req, bool lock_held);
+__device__ inline void record_turn(uint8_t* rec_order, uint32_t* rec_pos, int wave) { // (under the tree lock)
+    if (LANE == 0) {
+        volatile uint32_t* pos = rec_pos;
+        const uint32_t p = *pos;
+        ((volatile uint8_t*)rec_order)[p] = (uint8_t)wave;
+        *pos = p + 1u;
+    }
+}
 template <int N>
 __device__ void run_sim_shared(const Store& S, const Tree<N>& T, int* lock, const RoundArgs& A, uint32_t sim_index, uint32_t tree_global,
-                               uint16_t* my_req, uint32_t& n_req) {
+                               uint16_t* my_req, uint32_t& n_req, uint8_t* rec_order, uint32_t* rec_pos, int wave) {
+    if (rec_order) {
+        tree_lock(lock);
+        record_turn(rec_order, rec_pos, wave);
+    }
+    run_sim_shared_body<N>(S, T, lock, A, sim_index, tree_global, my_req, n_req, rec_order != nullptr);
+    if (rec_order) tree_unlock(lock);
+}
+template <int N>
+__device__ void run_sim_shared_body(const Store& S, const Tree<N>& T, int* lock, const RoundArgs& A, uint32_t sim_index, uint32_t tree_global,
+                                    uint16_t* my_req, uint32_t& n_req, bool lock_held) {
     using G = Geo<N>;
     constexpr int ROWP = G::ROWP, NW = G::NW;
     const int lane = LANE;
@@ -739,7 +764,7 @@ __device__ void run_sim_shared(const Store& S, const Tree<N>& T, int* lock, cons
         }
     }
     const int status = place_and_status<N>(bb, h_turn, h_legal, action);
-    const int child = add_child_shared<N>(S, T, lock, node, action, bb, status, 1 - h_turn);
+    const int child = add_child_shared<N>(S, T, lock, node, action, bb, status, 1 - h_turn, lock_held);
     if (child < 0) return; // None: "already expanded by other thread" (mcts_executor.rs:171-178), or the arena is full
     if (status != ST_IN_PROGRESS) backup_shared<N>(T, child, status == ST_DRAW ? 0.0f : 1.0f);
     else { if (lane == 0) my_req[n_req] = (uint16_t)child; n_req += 1u; }
@@ -748,7 +773,7 @@ __device__ void run_sim_shared(const Store& S, const Tree<N>& T, int* lock, cons
 // W waves (one workgroup) x one round each: wave w runs round `group * W + w` of the execute call
 template <int N>
 __global__ __launch_bounds__(1024) void k_round_shared(Store S, RoundArgs A, int rounds_total, int group, uint16_t* __restrict__ sh_req,
-                                                       uint32_t* __restrict__ sh_cnt) {
+                                                       uint32_t* __restrict__ sh_cnt, uint8_t* rec_order, uint32_t* rec_pos) {
     __shared__ int s_lock;
     if (threadIdx.x == 0) s_lock = 0;
     __syncthreads();
@@ -759,7 +784,8 @@ __global__ __launch_bounds__(1024) void k_round_shared(Store S, RoundArgs A, int
     const int round = group * W + wave;
     uint32_t n_req = 0;
     if (S.gs[0].alive && round < rounds_total)
-        for (int i = 0; i < A.K; ++i) run_sim_shared<N>(S, T, &s_lock, A, (uint32_t)(round * A.K + i), tree_global, sh_req + (size_t)wave * KMAX, n_req);
+        for (int i = 0; i < A.K; ++i)
+            run_sim_shared<N>(S, T, &s_lock, A, (uint32_t)(round * A.K + i), tree_global, sh_req + (size_t)wave * KMAX, n_req, rec_order, rec_pos, wave);
     if (LANE == 0) sh_cnt[wave] = n_req;
 }
 
@@ -782,11 +808,21 @@ __global__ __launch_bounds__(64) void k_scan_shared(Store S, int side, int W, co
 // the scatter halves of the W rounds (mcts_executor.rs:206-250): every wave backs its own requests up, fetch_add like propagate
 template <int N>
 __global__ __launch_bounds__(1024) void k_scatter_shared(Store S, int side, const float* __restrict__ V, const uint16_t* __restrict__ sh_req,
-                                                         const uint32_t* __restrict__ sh_cnt) {
+                                                         const uint32_t* __restrict__ sh_cnt, uint8_t* rec_order, uint32_t* rec_pos) {
+    __shared__ int s_lock;
+    if (threadIdx.x == 0) s_lock = 0;
+    __syncthreads();
     const int wave = threadIdx.x >> 6;
     const Tree<N> T(S, side * S.games);
     const uint32_t c = sh_cnt[wave], base = sh_cnt[KMAX + wave];
-    for (uint32_t r = 0; r < c; ++r) backup_shared<N>(T, sh_req[(size_t)wave * KMAX + r], -V[base + r]);
+    for (uint32_t r = 0; r < c; ++r) {
+        if (rec_order) { // recorded mode: one backup at a time, in the recorded order (float sums depend on it)
+            tree_lock(&s_lock);
+            record_turn(rec_order, rec_pos, wave);
+        }
+        backup_shared<N>(T, sh_req[(size_t)wave * KMAX + r], -V[base + r]);
+        if (rec_order) tree_unlock(&s_lock);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1849,17 +1885,17 @@ void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st) {
     DISPATCH_N(n, (k_round<9><<<S.games, 64, 0, st>>>(S, a)), (k_round<15><<<S.games, 64, 0, st>>>(S, a)));
 }
 void launch_round_shared(int n, const Store& S, const RoundArgs& a, int rounds_total, int group, int waves, uint16_t* sh_req, uint32_t* sh_cnt,
-                         hipStream_t st) {
-    DISPATCH_N(n, (k_round_shared<9><<<1, waves * 64, 0, st>>>(S, a, rounds_total, group, sh_req, sh_cnt)),
-               (k_round_shared<15><<<1, waves * 64, 0, st>>>(S, a, rounds_total, group, sh_req, sh_cnt)));
+                         hipStream_t st, uint8_t* rec_order, uint32_t* rec_pos) {
+    DISPATCH_N(n, (k_round_shared<9><<<1, waves * 64, 0, st>>>(S, a, rounds_total, group, sh_req, sh_cnt, rec_order, rec_pos)),
+               (k_round_shared<15><<<1, waves * 64, 0, st>>>(S, a, rounds_total, group, sh_req, sh_cnt, rec_order, rec_pos)));
     k_scan_shared<<<1, 64, 0, st>>>(S, a.side, waves, sh_req, sh_cnt);
 }
 void launch_scatter_shared(int n, const Store& S, int side, const float* p, const float* v, int max_count, int waves, const uint16_t* sh_req,
-                           const uint32_t* sh_cnt, hipStream_t st) {
+                           const uint32_t* sh_cnt, hipStream_t st, uint8_t* rec_order, uint32_t* rec_pos) {
     const int grid = max_count > 0 ? max_count : 1;
     DISPATCH_N(n, (k_scatter_policy<9><<<grid, 64, 0, st>>>(S, p, max_count)), (k_scatter_policy<15><<<grid, 64, 0, st>>>(S, p, max_count)));
-    DISPATCH_N(n, (k_scatter_shared<9><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt)),
-               (k_scatter_shared<15><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt)));
+    DISPATCH_N(n, (k_scatter_shared<9><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt, rec_order, rec_pos)),
+               (k_scatter_shared<15><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt, rec_order, rec_pos)));
 }
 void launch_scan(int n, const Store& S, int side, int K, hipStream_t st, unsigned long long* evals) {
     k_scan<<<1, 1024, 0, st>>>(S, side, evals);

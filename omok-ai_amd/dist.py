@@ -62,7 +62,9 @@ def gather_replay(records):
         if counts[rank] > 0:
             ops.append(dist.P2POp(dist.isend, mine, peer))
         if counts[peer] > 0:
-            ops.append(dist.P2POp(dist.irecv, out[offs[peer]:offs[peer + 1]], peer))
+            dst = out[offs[peer]:offs[peer + 1]]  # whole rows of a contiguous matrix: a contiguous view (ncclRecv writes it in place)
+            assert dst.is_contiguous()
+            ops.append(dist.P2POp(dist.irecv, dst, peer))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()

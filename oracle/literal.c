@@ -241,68 +241,81 @@ static int play_action(lagent* ag, int action) { /* agent.rs:206-232; -1 = None 
 }
 
 /* ---- ParallelMCTSExecutor::execute, one round (pme.rs:44-192) for one agent ---------------------- */
-static void generate_requests(lit_sp* sp, lagent* ag, int game, int side, int round, int batch_size, float epsilon, float alpha) {
+/* Dirichlet noise on the root (pme.rs:48-76; the same statements open MCTSExecutor::run, mcts_executor.rs:38-68) */
+static void root_noise(lit_sp* sp, lagent* ag, uint32_t tree_global, float epsilon, float alpha) {
     const int hw = sp->hw;
-    const uint32_t tree_global = (uint32_t)((sp->game_offset + game) * 2 + side);
-    if (round == 0) { /* processed_count == 0: Dirichlet noise on the root (:48-76) */
-        float noise[ORC_MAX_HW];
-        float total = 0.0f;
-        for (int a = 0; a < hw; ++a) {
-            noise[a] = orc_gamma(alpha, sp->key, (uint32_t)a, (uint32_t)sp->ply, tree_global);
-            total += noise[a];
-        }
-        if (total > 0.0f) {
-            const float inv = 1.0f / total;
-            for (int a = 0; a < hw; ++a) noise[a] *= inv;
-        } else {
-            for (int a = 0; a < hw; ++a) noise[a] = 1.0f / (float)hw;
-        }
-        float* policy = ag->root->policy;
-        for (int a = 0; a < hw; ++a) policy[a] = (1.0f - epsilon) * policy[a] + epsilon * noise[a];
-        float sum = 0.0f;
-        for (int a = 0; a < hw; ++a) sum += policy[a];
+    float noise[ORC_MAX_HW];
+    float total = 0.0f;
+    for (int a = 0; a < hw; ++a) {
+        noise[a] = orc_gamma(alpha, sp->key, (uint32_t)a, (uint32_t)sp->ply, tree_global);
+        total += noise[a];
+    }
+    if (total > 0.0f) {
+        const float inv = 1.0f / total;
+        for (int a = 0; a < hw; ++a) noise[a] *= inv;
+    } else {
+        for (int a = 0; a < hw; ++a) noise[a] = 1.0f / (float)hw;
+    }
+    float* policy = ag->root->policy;
+    for (int a = 0; a < hw; ++a) policy[a] = (1.0f - epsilon) * policy[a] + epsilon * noise[a];
+    float sum = 0.0f;
+    for (int a = 0; a < hw; ++a) sum += policy[a];
+    const float sum_inv = 1.0f / sum;
+    for (int a = 0; a < hw; ++a) policy[a] *= sum_inv;
+    for (int i = 0; i < ag->root->len; ++i) { /* update children's prior probability */
+        lnode* child = ag->root->children[i];
+        child->p = policy[child->action];
+    }
+}
+
+/* one iteration of the simulation loop (pme.rs:80-189 == mcts_executor.rs:83-192); returns the node to evaluate or NULL */
+static lnode* one_simulation(lit_sp* sp, lagent* ag, uint32_t sim_index, uint32_t tree_global) {
+    const int hw = sp->hw;
+    sp->sims += 1;
+    lnode* node = select_leaf(ag->root);
+    if (node->status != ORC_IN_PROGRESS) { /* :92-97 */
+        propagate(node, node->z);
+        return NULL;
+    }
+    uint8_t bits[ORC_MAX_HW];
+    memset(bits, 0, sizeof(bits));
+    for (int i = 0; i < node->len; ++i) bits[node->children[i]->action] = 1;
+    int available[ORC_MAX_HW], n_available = 0;
+    for (int a = 0; a < hw; ++a)
+        if (node->env.board[a] == ORC_EMPTY && !bits[a]) available[n_available++] = a;
+    if (n_available == 0) return NULL; /* "There's no action for now." */
+    uint32_t o[4];
+    orc_philox(sp->key, sim_index, (uint32_t)sp->ply, tree_global, ORC_RNG_EXPAND, o);
+    const int action = available[(uint32_t)(((uint64_t)o[0] * (uint64_t)n_available) >> 32)];
+    orc_env env = node->env;
+    const int status = orc_env_place_stone(&env, action);
+    const int has_reward = status != ORC_IN_PROGRESS;
+    const float terminal_reward = status == ORC_DRAW ? 0.0f : 1.0f;
+    float policy[ORC_MAX_HW]; /* the uniform placeholder, :140-156 */
+    for (int a = 0; a < hw; ++a) policy[a] = env.board[a] != ORC_EMPTY ? 0.0f : 1.0f;
+    float sum = 0.0f;
+    for (int a = 0; a < hw; ++a) sum += policy[a];
+    if (ORC_EPS <= sum) {
         const float sum_inv = 1.0f / sum;
         for (int a = 0; a < hw; ++a) policy[a] *= sum_inv;
-        for (int i = 0; i < ag->root->len; ++i) { /* update children's prior probability */
-            lnode* child = ag->root->children[i];
-            child->p = policy[child->action];
-        }
     }
+    lnode* expanded_child = expand(ag, node, action, &env, status, policy, has_reward ? terminal_reward : 0.0f, hw);
+    if (!expanded_child) return NULL;
+    if (has_reward) {
+        propagate(expanded_child, terminal_reward);
+        return NULL;
+    }
+    return expanded_child;
+}
+
+static void generate_requests(lit_sp* sp, lagent* ag, int game, int side, int round, int batch_size, float epsilon, float alpha) {
+    const uint32_t tree_global = (uint32_t)((sp->game_offset + game) * 2 + side);
+    if (round == 0) root_noise(sp, ag, tree_global, epsilon, alpha); /* processed_count == 0 (:48-76) */
     for (int it = 0; it < batch_size; ++it) {
-        sp->sims += 1;
-        lnode* node = select_leaf(ag->root);
-        if (node->status != ORC_IN_PROGRESS) { /* :92-97 */
-            propagate(node, node->z);
-            continue;
-        }
-        uint8_t bits[ORC_MAX_HW];
-        memset(bits, 0, sizeof(bits));
-        for (int i = 0; i < node->len; ++i) bits[node->children[i]->action] = 1;
-        int available[ORC_MAX_HW], n_available = 0;
-        for (int a = 0; a < hw; ++a)
-            if (node->env.board[a] == ORC_EMPTY && !bits[a]) available[n_available++] = a;
-        if (n_available == 0) continue; /* "There's no action for now." */
-        uint32_t o[4];
-        orc_philox(sp->key, (uint32_t)(round * batch_size + it), (uint32_t)sp->ply, tree_global, ORC_RNG_EXPAND, o);
-        const int action = available[(uint32_t)(((uint64_t)o[0] * (uint64_t)n_available) >> 32)];
-        orc_env env = node->env;
-        const int status = orc_env_place_stone(&env, action);
-        const int has_reward = status != ORC_IN_PROGRESS;
-        const float terminal_reward = status == ORC_DRAW ? 0.0f : 1.0f;
-        float policy[ORC_MAX_HW]; /* the uniform placeholder, :140-156 */
-        for (int a = 0; a < hw; ++a) policy[a] = env.board[a] != ORC_EMPTY ? 0.0f : 1.0f;
-        float sum = 0.0f;
-        for (int a = 0; a < hw; ++a) sum += policy[a];
-        if (ORC_EPS <= sum) {
-            const float sum_inv = 1.0f / sum;
-            for (int a = 0; a < hw; ++a) policy[a] *= sum_inv;
-        }
-        lnode* expanded_child = expand(ag, node, action, &env, status, policy, has_reward ? terminal_reward : 0.0f, hw);
-        if (!expanded_child) continue;
-        if (has_reward) {
-            propagate(expanded_child, terminal_reward);
-        } else if (sp->n_req < sp->cap_req) {
-            sp->req_node[sp->n_req] = expanded_child;
+        lnode* child = one_simulation(sp, ag, (uint32_t)(round * batch_size + it), tree_global);
+        if (!child) continue;
+        if (sp->n_req < sp->cap_req) {
+            sp->req_node[sp->n_req] = child;
             sp->req_game[sp->n_req] = game;
             sp->n_req++;
         } else {
@@ -435,6 +448,88 @@ void lit_round_scatter(lit_sp* sp, const float* p, const float* v) { /* pme.rs:2
             child->p = policy[child->action];
         }
         propagate(node, value);
+    }
+    sp->n_req = 0;
+}
+
+/* ---- MCTSExecutor::run (alpha-zero/src/mcts_executor.rs:29-255) under a GIVEN interleaving ----------------------------------------
+ * The reference runs its ceil(count / batch_size) rounds as rayon tasks on one tree; which task's simulation touches the tree next is up
+ * to the thread pool.  These functions run game 0's side-to-move agent with the tasks' simulations interleaved in a caller-given order
+ * (the lock order an engine recorded): `order[i]` = index w of the task (round group * waves + w) whose next simulation runs i-th.  Every
+ * simulation is the loop body of :83-192 executed alone, i.e. the schedule in which the pool never overlaps two simulations.  The
+ * requests of the group's tasks are evaluated as one batch, rows in task order then simulation order; the scatter (:206-250) writes all
+ * policies, then runs the propagate calls in `order` of the second list (a request's policy is only read by later descents, so policy
+ * writes and backups commute while no descent runs). */
+void lit_shared_noise(lit_sp* sp, float epsilon, float alpha) { /* mcts_executor.rs:38-68 */
+    if (sp->live < 1) return;
+    const int side = sp->ply & 1;
+    lagent* ag = side_agents(sp, side)[0];
+    root_noise(sp, ag, (uint32_t)((sp->game_offset + sp->transition_indices[0]) * 2 + side), epsilon, alpha);
+}
+
+int lit_shared_group_generate(lit_sp* sp, int group, int waves, int rounds_total, int batch_size, const uint8_t* order, int n_order,
+                              float* inputs, int max_req) {
+    if (sp->live < 1 || waves < 1 || waves > 64) return -1;
+    const int side = sp->ply & 1, game = sp->transition_indices[0];
+    lagent* ag = side_agents(sp, side)[0];
+    const uint32_t tree_global = (uint32_t)((sp->game_offset + game) * 2 + side);
+    int done[64];
+    memset(done, 0, sizeof(done));
+    lnode** per = (lnode**)calloc((size_t)waves * (size_t)batch_size, sizeof(lnode*));
+    int n_per[64];
+    memset(n_per, 0, sizeof(n_per));
+    for (int i = 0; i < n_order; ++i) {
+        const int w = order[i];
+        const int round = group * waves + w;
+        if (w >= waves || round >= rounds_total || done[w] >= batch_size) { sp->error = 4; free(per); return -1; }
+        lnode* child = one_simulation(sp, ag, (uint32_t)(round * batch_size + done[w]), tree_global);
+        done[w] += 1;
+        if (child) per[(size_t)w * (size_t)batch_size + (size_t)n_per[w]++] = child;
+    }
+    for (int w = 0; w < waves; ++w) /* every live task runs all its simulations (:83) */
+        if (group * waves + w < rounds_total && done[w] != batch_size) { sp->error = 4; free(per); return -1; }
+    sp->n_req = 0;
+    for (int w = 0; w < waves; ++w)
+        for (int r = 0; r < n_per[w]; ++r) {
+            if (sp->n_req >= sp->cap_req || sp->n_req >= max_req) { sp->error = 3; free(per); return -1; }
+            sp->req_node[sp->n_req] = per[(size_t)w * (size_t)batch_size + (size_t)r];
+            sp->req_game[sp->n_req] = w; /* (the task the request belongs to) */
+            if (inputs) orc_encode_nn_input(&sp->req_node[sp->n_req]->env, ORC_MODE_PLAYER, inputs + (size_t)sp->n_req * 3 * (size_t)sp->hw);
+            sp->n_req++;
+        }
+    free(per);
+    return sp->n_req;
+}
+
+void lit_shared_group_scatter(lit_sp* sp, const float* p, const float* v, const uint8_t* order, int n_order) {
+    const int hw = sp->hw;
+    if (n_order != sp->n_req) { sp->error = 4; return; }
+    for (int r = 0; r < sp->n_req; ++r) { /* :212-243 */
+        lnode* node = sp->req_node[r];
+        float policy[ORC_MAX_HW];
+        memcpy(policy, p + (size_t)r * (size_t)hw, sizeof(float) * (size_t)hw);
+        for (int a = 0; a < hw; ++a)
+            if (node->env.board[a] != ORC_EMPTY) policy[a] = 0.0f;
+        float sum = 0.0f;
+        for (int a = 0; a < hw; ++a) sum += policy[a];
+        if (ORC_EPS <= sum) {
+            const float sum_inv = 1.0f / sum;
+            for (int a = 0; a < hw; ++a) policy[a] *= sum_inv;
+        }
+        memcpy(node->policy, policy, sizeof(float) * (size_t)hw);
+        for (int i = 0; i < node->len; ++i) node->children[i]->p = policy[node->children[i]->action];
+    }
+    int next[64], first[64];
+    memset(next, 0, sizeof(next));
+    for (int w = 0; w < 64; ++w) first[w] = -1;
+    for (int r = 0; r < sp->n_req; ++r)
+        if (first[sp->req_game[r]] < 0) first[sp->req_game[r]] = r;
+    for (int i = 0; i < n_order; ++i) { /* :246-247 in the recorded order */
+        const int w = order[i];
+        if (w >= 64 || first[w] < 0) { sp->error = 4; return; }
+        const int r = first[w] + next[w]++;
+        if (r >= sp->n_req || sp->req_game[r] != w) { sp->error = 4; return; }
+        propagate(sp->req_node[r], -v[r]);
     }
     sp->n_req = 0;
 }

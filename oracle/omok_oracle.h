@@ -158,6 +158,13 @@ int lit_game_plies(const lit_sp* sp, int game);
 long lit_live_nodes(const lit_sp* sp);
 int lit_round_generate(lit_sp* sp, int round, int batch_size, float epsilon, float alpha, float* inputs, int32_t* req_games, int max_req);
 void lit_round_scatter(lit_sp* sp, const float* p, const float* v);
+/* MCTSExecutor::run (alpha-zero/src/mcts_executor.rs:29-255) on game 0's side-to-move agent under a GIVEN interleaving of its tasks'
+ * simulations: order[i] = task w (round group * waves + w) whose next simulation runs i-th; requests come back in task order then
+ * simulation order; the scatter writes all policies, then propagates in the order of its own list.  See oracle/literal.c. */
+void lit_shared_noise(lit_sp* sp, float epsilon, float alpha);
+int lit_shared_group_generate(lit_sp* sp, int group, int waves, int rounds_total, int batch_size, const uint8_t* order, int n_order,
+                              float* inputs /*[max_req][3 HW] or NULL*/, int max_req);
+void lit_shared_group_scatter(lit_sp* sp, const float* p, const float* v, const uint8_t* order, int n_order);
 void lit_sample(lit_sp* sp, float temperature, int threshold, int32_t* actions /*G, by game id*/);
 void lit_set_actions(lit_sp* sp, const int32_t* actions /*G, by game id*/);
 int lit_mirror_generate(lit_sp* sp, float* inputs, int32_t* row_games, int max_req);

@@ -95,6 +95,9 @@ def lib():
     L.lit_round_generate.restype = C.c_int
     L.lit_round_scatter.argtypes = [C.c_void_p, fp, fp]
     L.lit_sample.argtypes = [C.c_void_p, C.c_float, C.c_int, i32p]
+    L.lit_shared_noise.argtypes = [C.c_void_p, C.c_float, C.c_float]
+    L.lit_shared_group_generate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, fp, C.c_int]
+    L.lit_shared_group_scatter.argtypes = [C.c_void_p, fp, fp, C.POINTER(C.c_uint8), C.c_int]
     L.lit_set_actions.argtypes = [C.c_void_p, i32p]
     L.lit_mirror_generate.argtypes = [C.c_void_p, fp, i32p, C.c_int]
     L.lit_mirror_generate.restype = C.c_int
@@ -358,6 +361,28 @@ class Literal:
         p = np.ascontiguousarray(p, dtype=np.float32)
         v = np.ascontiguousarray(v, dtype=np.float32)
         lib().lit_round_scatter(self.h, _fp(p), _fp(v))
+
+    def shared_run(self, count, batch_size, epsilon, alpha, waves, groups):
+        """MCTSExecutor::run on game 0 under a recorded interleaving: `groups` = [(sim_order, backup_order, p, v), ...] as returned by the
+        engine's execute_shared_recorded.  Returns the request inputs of every group (for comparison with the engine's)."""
+        rounds = -(-count // batch_size)
+        lib().lit_shared_noise(self.h, epsilon, alpha)
+        inputs = []
+        u8p = C.POINTER(C.c_uint8)
+        for g, (so, bo, p, v) in enumerate(groups):
+            so = np.ascontiguousarray(so, dtype=np.uint8)
+            bo = np.ascontiguousarray(bo, dtype=np.uint8)
+            cap = waves * batch_size
+            inp = np.zeros((cap, 3 * self.hw), dtype=np.float32)
+            n = lib().lit_shared_group_generate(self.h, g, waves, rounds, batch_size, so.ctypes.data_as(u8p), len(so), _fp(inp), cap)
+            assert n >= 0 and self.error == 0, f"group {g}: schedule rejected (error {self.error})"
+            assert n == len(v) == len(bo), f"group {g}: {n} requests, the recording has {len(v)} outputs / {len(bo)} backups"
+            inputs.append(inp[:n].copy())
+            p = np.ascontiguousarray(p, dtype=np.float32).reshape(n, self.hw) if n else np.zeros((0, self.hw), dtype=np.float32)
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            lib().lit_shared_group_scatter(self.h, _fp(p), _fp(v), bo.ctypes.data_as(u8p), len(bo))
+            assert self.error == 0, f"group {g}: backup order rejected"
+        return inputs
 
     def sample(self, temperature, threshold):
         a = np.zeros(self.games, dtype=np.int32)

@@ -1,13 +1,18 @@
 """One tree searched by many wavefronts (omok_execute_shared = MCTSExecutor::run, alpha-zero/src/mcts_executor.rs:29-255;
 SURVEY 8f rank 4).  The reference's version is nondeterministic by design (rayon tasks racing on one tree), so parity is:
   - waves = 1 is the sequential schedule: identical to omok_execute bit for bit, ply after ply;
-  - waves > 1: every structural invariant of the tree holds, visit counts are conserved (node n >= sum of its children's n),
+  - waves >= 1 under a RECORDED interleaving (omok_execute_shared_recorded: every simulation / backup under the tree lock, the lock
+    order written down): the literal oracle replays exactly that schedule (oracle/literal.c lit_shared_*) and the trees, moves and
+    request boards are identical bit for bit, ply after ply -- an independent check of MCTSExecutor::run's arithmetic
+    (mcts_executor.rs:76-255: shared n / w, expansion, terminal shortcuts, batch evaluation, scatter) for W = 1, 8 and 16;
+  - waves > 1, free-running: every structural invariant of the tree holds, visit counts are conserved (node n >= sum of its children's n),
     nothing is lost or duplicated in the arena, every non-terminal node got its evaluation, and the search still concentrates
     on the same moves as the sequential one (loose statistical bound, printed)."""
 import numpy as np
 import pytest
 
 import omok_ai_amd as oa
+from oracle import oracle as O
 from test_oracle_selfplay import check_tree_invariants
 
 pytestmark = pytest.mark.gpu
@@ -118,3 +123,77 @@ def test_many_waves_search_like_the_sequential_search():
           f"mass on the sequential K=8 top-10: 8 waves {np.mean(mass_par):.3f}, sequential K=64 {np.mean(mass_seq):.3f}")
     assert np.mean(tv_same) < 0.35
     assert np.mean(mass_par) > 0.6 * np.mean(mass_seq)
+
+
+def _dump(sp, side):
+    ints, floats = sp.tree_dump(0, side)
+    ints = ints.copy()
+    ints[:, 7] &= 0xFFFF  # (the literal oracle's dump has no has_policy bit: its placeholder rows are explicit)
+    return ints, floats
+
+
+@pytest.mark.parametrize("n,count,k,waves,plies", [(9, 96, 8, 1, 6), (9, 256, 8, 8, 8), (9, 250, 4, 16, 6), (15, 800, 16, 16, 3)])
+def test_recorded_interleaving_replays_exactly_on_the_literal_oracle(n, count, k, waves, plies):
+    """The engine searches one tree with `waves` wavefronts in recorded mode; the literal oracle (pointer nodes, stored p, explicit
+    refresh loops) replays the recorded lock order with the engine's net outputs: canonical tree dumps, root statistics, request
+    boards, sampled moves and the mirror step must be identical.  count = 250 with K = 4 also covers a last group with fewer rounds
+    than waves and a count that is not a multiple of K."""
+    seed = 13
+    eng, sp = _engine(n, k, seed, waves, max_nodes=8192)
+    lit = O.Literal(n, 1, seed=seed, cap_nodes=8192)
+    lit.reset(eng.evaluate_p(O.Environment(n).encode_nn_input(0)[None]).reshape(-1))
+    interleaved = 0
+    for ply in range(plies):
+        if sp.alive_count == 0:
+            break
+        side = sp.ply & 1
+        groups = sp.execute_shared_recorded(count, k, waves=waves)
+        rounds = -(-count // k)
+        assert len(groups) == -(-rounds // waves)
+        assert sum(len(g[0]) for g in groups) == rounds * k  # every simulation of every round took its turn
+        for so, bo, p, v in groups:
+            assert len(bo) == len(v) == len(p)
+            if np.any(np.diff(so.astype(np.int32)) < 0):
+                interleaved += 1  # (a wave with a larger index ran before one with a smaller index: the rounds really interleave)
+        lit.shared_run(count, k, 0.25, 0.03, waves, groups)
+        gi, gf = _dump(sp, side)
+        li, lf = lit.tree_dump(0, side)
+        assert gi.shape == li.shape, f"ply {ply}: {gi.shape[0]} vs {li.shape[0]} nodes"
+        assert np.array_equal(gi, li), f"ply {ply}: node records differ"
+        assert np.array_equal(gf.view(np.uint32), lf.view(np.uint32)), f"ply {ply}: w / policy bits differ"
+        a = sp.sample_actions(1.0, 4)
+        assert np.array_equal(a, lit.sample(1.0, 4)), f"ply {ply}: moves"
+        nm = sp.mirror_generate()
+        lm, _ = lit.mirror_generate()
+        assert nm == len(lm) and np.array_equal(sp.mirror_inputs(), lm)
+        pm = sp.mirror_eval()
+        sp.mirror_apply()
+        lit.advance(pm)
+        for s2 in (0, 1):
+            gi, gf = _dump(sp, s2)
+            li, lf = lit.tree_dump(0, s2)
+            assert np.array_equal(gi, li) and np.array_equal(gf.view(np.uint32), lf.view(np.uint32)), f"ply {ply} after advance, side {s2}"
+    if waves > 1:
+        assert interleaved > 0, "the recorded schedules were all sequential: nothing concurrent was tested"
+    assert lit.error == 0
+    eng.close()
+
+
+def test_recorded_single_wave_equals_the_free_running_one():
+    """waves = 1: recorded mode is the same sequential schedule as omok_execute_shared(waves = 1) -- which the first test of this file
+    ties to omok_execute -- so the oracle-replayed arithmetic is the arithmetic of the unrecorded kernels too."""
+    n, count, k = 15, 112, 16
+    a_eng, a = _engine(n, k, 5, 1)
+    b_eng, b = _engine(n, k, 5, 1)
+    for ply in range(4):
+        a.execute_shared(count, k, waves=1)
+        b.execute_shared_recorded(count, k, waves=1)
+        for side in (0, 1):
+            ai, af = a.tree_dump(0, side)
+            bi, bf = b.tree_dump(0, side)
+            assert np.array_equal(ai, bi) and np.array_equal(af.view(np.uint32), bf.view(np.uint32)), f"ply {ply} side {side}"
+        assert np.array_equal(a.sample_actions(1.0, 4), b.sample_actions(1.0, 4))
+        a.advance()
+        b.advance()
+    a_eng.close()
+    b_eng.close()

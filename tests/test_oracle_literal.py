@@ -176,3 +176,59 @@ def test_external_moves_on_both_oracles():
     ensure_action_exists + play_action on BOTH agents (agent.rs:144-232), no transition recorded."""
     shape, plies = _drive(9, 4, 32, 8, 24, FakeNet(9, seed=2), external_every=3, ext_seed=1)
     assert plies >= 6
+
+
+@pytest.mark.parametrize("n,count,k", [(9, 64, 8), (15, 48, 16)])
+def test_shared_run_with_one_task_at_a_time_is_the_round_loop(n, count, k):
+    """MCTSExecutor::run with the tasks run one after the other (waves = 1: every group is one round, its K simulations in order, its
+    requests scattered in order) is ParallelMCTSExecutor::execute on one agent: the two entry points of oracle/literal.c must leave
+    identical trees (they share one_simulation / propagate; this pins the scheduling code around them)."""
+    net = FakeNet(n, seed=2)
+    root_p = net.forward(O.Environment(n).encode_nn_input(0)[None])[0][0]
+    a = O.Literal(n, 1, seed=9)
+    b = O.Literal(n, 1, seed=9)
+    a.reset(root_p)
+    b.reset(root_p)
+    lib, u8p = O.lib(), O.C.POINTER(O.C.c_uint8)
+    for ply in range(5):
+        rounds = -(-count // k)
+        for rnd in range(rounds):
+            x, _ = a.round_generate(rnd, k, 0.25, 0.03)
+            p, v = net.forward(x) if len(x) else (np.zeros((0, n * n), np.float32), np.zeros(0, np.float32))
+            a.round_scatter(p, v)
+        lib.lit_shared_noise(b.h, 0.25, 0.03)
+        for g in range(rounds):
+            so = np.zeros(k, dtype=np.uint8)
+            inp = np.zeros((k, 3 * n * n), dtype=np.float32)
+            m = lib.lit_shared_group_generate(b.h, g, 1, rounds, k, so.ctypes.data_as(u8p), k, O._fp(inp), k)
+            assert m >= 0 and b.error == 0
+            p, v = net.forward(inp[:m]) if m else (np.zeros((0, n * n), np.float32), np.zeros(0, np.float32))
+            bo = np.zeros(m, dtype=np.uint8)
+            lib.lit_shared_group_scatter(b.h, O._fp(np.ascontiguousarray(p, dtype=np.float32)), O._fp(np.ascontiguousarray(v, dtype=np.float32)),
+                                         bo.ctypes.data_as(u8p), m)
+            assert b.error == 0
+        side = ply & 1
+        ai, af = a.tree_dump(0, side)
+        bi, bf = b.tree_dump(0, side)
+        assert np.array_equal(ai, bi) and np.array_equal(af.view(np.uint32), bf.view(np.uint32)), f"ply {ply}"
+        act = a.sample(1.0, 3)
+        assert np.array_equal(act, b.sample(1.0, 3))
+        xa, _ = a.mirror_generate()
+        xb, _ = b.mirror_generate()
+        assert np.array_equal(xa, xb)
+        pm = net.forward(xa)[0] if len(xa) else np.zeros((0, n * n), np.float32)
+        a.advance(pm)
+        b.advance(pm)
+        if a.alive_count == 0:
+            break
+    assert a.live_nodes == b.live_nodes
+
+
+def test_shared_run_rejects_a_bad_schedule():
+    n, k = 9, 4
+    net = FakeNet(n, seed=1)
+    lit = O.Literal(n, 1, seed=1)
+    lit.reset(net.forward(O.Environment(n).encode_nn_input(0)[None])[0][0])
+    lib, u8p = O.lib(), O.C.POINTER(O.C.c_uint8)
+    so = np.array([0, 1, 0, 1, 0, 1, 0], dtype=np.uint8)  # task 1 runs 3 of its 4 simulations
+    assert lib.lit_shared_group_generate(lit.h, 0, 2, 2, k, so.ctypes.data_as(u8p), len(so), None, 8) == -1 and lit.error == 4
