@@ -470,6 +470,11 @@ void lit_shared_noise(lit_sp* sp, float epsilon, float alpha) { /* mcts_executor
 int lit_shared_group_generate(lit_sp* sp, int group, int waves, int rounds_total, int batch_size, const uint8_t* order, int n_order,
                               float* inputs, int max_req) {
     if (sp->live < 1 || waves < 1 || waves > 64) return -1;
+    if (waves * batch_size > sp->cap_req) { /* (the request list was sized for one round per game) */
+        sp->cap_req = waves * batch_size;
+        sp->req_node = (lnode**)realloc(sp->req_node, (size_t)sp->cap_req * sizeof(lnode*));
+        sp->req_game = (int*)realloc(sp->req_game, (size_t)sp->cap_req * sizeof(int));
+    }
     const int side = sp->ply & 1, game = sp->transition_indices[0];
     lagent* ag = side_agents(sp, side)[0];
     const uint32_t tree_global = (uint32_t)((sp->game_offset + game) * 2 + side);
