@@ -795,10 +795,10 @@ constexpr int SIB_MIN = 3;                       // runs shorter than this go to
 constexpr int SIB_WIN = 7, SIB_GW = SIB_WIN + 2; // window side, child grid side (window + halo ring)
 constexpr int SIB_CGRID_ROWS = SIB_GW * SIB_GW + 1;
 constexpr int SIB_CGRID_BYTES = SIB_CGRID_ROWS * GRID_STRIDE * 4; // 11808
-constexpr int SIB_HB_FLOATS = 225 * NM;          // one base h grid in the scratch: [pixel][32]
+constexpr int sib_hb_floats(int n) { return n * n * NM; } // one base h grid in the scratch: [pixel][32]
 constexpr int SIB_PAIR_CUT1 = 289, SIB_PAIR_CUT2 = 578, SIB_PAIR_CUT3 = 801; // shares of a workgroup's children per wave pair, cumulative / 1024 (k_sib_children)
 // difference path: window bins (window origin (wy0, wx0) in 0..8 each), the single rows as bin SIB_BINS, counters, difference rows
-constexpr int SIB_ORG = 15 - SIB_WIN + 1, SIB_BINS = SIB_ORG * SIB_ORG; // 9, 81
+constexpr int SIB_ORG = 15 - SIB_WIN + 1, SIB_BINS = SIB_ORG * SIB_ORG; // 9, 81: bin = wy0 * 9 + wx0 for EVERY board size (N = 9: origins 0..2, 9 bins in use)
 constexpr int SIB_CNT_INTS = 8 + SIB_BINS + 7 + 16;                       // d_gcnt: 8 counters, bin counts (96 ints), [96] full evaluations of runs (base-cache
                                                                           // misses + uncacheable runs), [97] uncacheable runs
 constexpr int SIB_WPX = SIB_WIN * SIB_WIN;                                // 49 window pixels = 98 fc0 super-steps
@@ -806,12 +806,12 @@ constexpr int SIB_DROW_U4 = SIB_WPX * 2 * 12;                             // 117
 constexpr int SIB_DLO_U4 = SIB_WPX * 2 * 8;                               // 784: first residual part
 constexpr int SIBX_DROW_U4 = SIB_WPX * 2 * 16;                            // FC0_F16: 1568 uint4 = 25088 B: [q][w] 128-B f16 parts, [q][w] 128-B f16 residual parts
 
-__device__ inline void sib_window(int action, int& wy0, int& wx0) { // the 7x7 window (clamped to the board) around the pixel the stone's float lands in
+__device__ inline void sib_window(int n, int action, int& wy0, int& wx0) { // the 7x7 window (clamped to the n x n board) around the pixel the stone's float lands in
     const int pc = (2 * action + 1) / 3;
-    wy0 = pc / 15 - SIB_WIN / 2;
-    wx0 = pc % 15 - SIB_WIN / 2;
-    wy0 = wy0 < 0 ? 0 : (wy0 > 15 - SIB_WIN ? 15 - SIB_WIN : wy0);
-    wx0 = wx0 < 0 ? 0 : (wx0 > 15 - SIB_WIN ? 15 - SIB_WIN : wx0);
+    wy0 = pc / n - SIB_WIN / 2;
+    wx0 = pc % n - SIB_WIN / 2;
+    wy0 = wy0 < 0 ? 0 : (wy0 > n - SIB_WIN ? n - SIB_WIN : wy0);
+    wx0 = wx0 < 0 ? 0 : (wx0 > n - SIB_WIN ? n - SIB_WIN : wx0);
 }
 
 // cnt[0] runs, cnt[1] rows outside runs, cnt[2] rows inside runs.  sib_rows[i] = descriptor of a row inside a run: (request row, run
@@ -823,7 +823,7 @@ __device__ inline void sib_window(int action, int& wy0, int& wx0) { // the 7x7 w
 constexpr int GROUP_TREES = 16;
 __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, uint2* __restrict__ groups, int32_t* __restrict__ singles,
                                                              uint4* __restrict__ sib_rows, int32_t* __restrict__ cnt, uint32_t* __restrict__ sib_slot,
-                                                             int32_t* __restrict__ tags, uint2* __restrict__ comp) {
+                                                             int32_t* __restrict__ tags, uint2* __restrict__ comp, int bn) {
     // Difference path (sib_slot != NULL): base slots.  The FIRST run of a tree uses one of the game's two slots (2 g, 2 g + 1), whose content is
     // reused while a tag names the run's parent (a leaf is its tree's expansion target for ~14 rounds); further runs of the tree in the same
     // round (rare) take a slot behind the games' and are always evaluated.  comp[] lists the (first request row, slot) pairs to evaluate.
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
     if (in_run) {
         if (sib_slot) {
             int wy0, wx0;
-            sib_window((int)(ta >> 8), wy0, wx0);
+            sib_window(bn, (int)(ta >> 8), wy0, wx0);
             bin = wy0 * SIB_ORG + wx0;
             rank = atomicAdd(&l_cnt[3 + bin], 1);
         }
@@ -934,7 +934,7 @@ __device__ inline int sib_bin_at(int pos) { // layout position -> bin
 }
 __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, int32_t* __restrict__ bin_start, int32_t* __restrict__ tile_info,
                                                     uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu, int max_fways,
-                                                    int max_wways, int part_w_rows, int facc_single_base, int part_f_rows) {
+                                                    int max_wways, int part_w_rows, int facc_single_base, int part_f_rows, int nsup_full) {
     __shared__ int tile0[SIB_BINS + 2], binc[SIB_BINS + 1];
     const int tid = threadIdx.x;
     const int c = tid < SIB_BINS ? cnt[8 + tid] : (tid == SIB_BINS ? cnt[1] : 0);
@@ -959,13 +959,18 @@ __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, i
         int ways = ntiles > t_split ? n_cu / (ntiles - t_split) : 1;
         if (ways > max_wways) ways = max_wways;
         if (ntiles > t_split && ways > part_w_rows / ((ntiles - t_split) * GT_BS)) ways = part_w_rows / ((ntiles - t_split) * GT_BS); // (partials slab)
+        while (ways > 1 && (ways - 1) * ((2 * SIB_WPX + ways - 1) / ways) >= 2 * SIB_WPX) --ways; // (no empty split of the 98 super-steps)
         if (ways < 2) { ways = 1; t_split = ntiles; }
         cnt[3] = cnt[96] + cnt[1]; // positions evaluated in full this round: runs without a cached base, then the single rows
         const int ftiles = (cnt[3] + GT_BS - 1) / GT_BS;          // fc0 of the full rows: K split so that one round of workgroups covers it;
         int fways = ftiles > 0 ? n_cu / ftiles : 1;              // partials [split][row < ftiles * 128]: as many ways as the slab holds
         const int fcap = (ftiles > 0 ? ftiles : 1) * GT_BS;
         if (fways > part_f_rows / fcap) fways = part_f_rows / fcap;
-        cnt[98] = fways < 1 ? 1 : (fways > max_fways ? max_fways : fways);
+        fways = fways < 1 ? 1 : (fways > max_fways ? max_fways : fways);
+        // no empty split: with ceil(nsup / ways) super-steps each, the last of `ways` splits must still start inside K (N = 9: 162 super-steps
+        // in 30 ways of 6 would leave splits 27..29 empty -- their workgroups would stream weights from beyond the matrix)
+        while (fways > 1 && (fways - 1) * ((nsup_full + fways - 1) / fways) >= nsup_full) --fways;
+        cnt[98] = fways;
         cnt[99] = fcap;
         cnt[4] = ntiles;
         cnt[5] = t_split;
@@ -1039,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_facc_reduce(const float* __restrict__ p
 // DELTA (difference path): a_out holds the FULL rows (one per run, written by k_trunk<BASE | DELTA>); the child's window entries are
 // stored as DIFFERENCES to the base's entries (dequantised: f16 hi + fp6 residual * 2^scale, exactly what fc0 will multiply), in the
 // same entry format, into the child's slot row of d_rows: fc0(child) = fc0(base row) + W[window] * difference row.
-template <bool DELTA, bool TPROF = false, bool F16LO = false> // TPROF (OMOK_SIB_PROF=1, timing only): shader-clock cycles per phase, summed over wave 0's passes, into tprof[]
+template <bool DELTA, bool TPROF = false, bool F16LO = false, int N = 15> // TPROF (OMOK_SIB_PROF=1, timing only): shader-clock cycles per phase, summed over wave 0's passes, into tprof[]
                                                                 // F16LO: operand / difference rows in the FC0_F16 format (f16 residuals)
 __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict__ board, const uint4* __restrict__ wt, const float* __restrict__ side,
                                                       uint4* __restrict__ a_out, size_t row_u4, const uint4* __restrict__ sib_rows,
@@ -1047,9 +1052,10 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
                                                       const uint32_t* __restrict__ sib_slot, const int32_t* __restrict__ bin_start,
                                                       uint4* __restrict__ d_rows, uint2* __restrict__ slot_desc,
                                                       unsigned long long* __restrict__ tprof) {
-    constexpr int N = 15;
     constexpr int BLK_U4 = fmt_blk_u4(F16LO);
     constexpr int DROW_U4 = F16LO ? SIBX_DROW_U4 : SIB_DROW_U4;
+    constexpr int SIB_HB_FLOATS = sib_hb_floats(N);
+    constexpr int SWW = 4; // depthwise strips of the 7-wide window: 4 | 3 pixels
     unsigned long long tp_acc[12] = {}, tp_last = 0;
     auto TP = [&](int phase) { // (phase = what ended here)
         if (TPROF) {
@@ -1332,7 +1338,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
         if (lane < 2 * NW) word = board[(size_t)ent.z * (2 * NW) + lane];
         return word;
     };
-    auto window_of = [&](const uint4& ent, int& wy0, int& wx0) { sib_window((int)((ent.w >> 8) & 0xFFu), wy0, wx0); }; // NodeHdr::action: the child's stone
+    auto window_of = [&](const uint4& ent, int& wy0, int& wx0) { sib_window(N, (int)((ent.w >> 8) & 0xFFu), wy0, wx0); }; // NodeHdr::action: the child's stone
     auto ring_fetch = [&](const float* hb, int blk, int wy0, int wx0, uint4 (&ring)[2]) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1454,23 +1460,23 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
         TP(2);
         if (fetch_next_ring) ring_fetch(hb, blk + 1, wy0, wx0, ring);
         // depthwise over the 7x7 window: (row, strip of 4 | 3 pixels, 4-channel group) = 112 items for the pair's 128 threads
-        f32x4 dout[TG::SW];
+        f32x4 dout[SWW];
         const int item = ptid < 7 * 2 * 8 ? ptid : 0;
         const int cg = item & 7, strip = item >> 3;
-        const int y = strip >> 1, x0 = (strip & 1) * TG::SW;
+        const int y = strip >> 1, x0 = (strip & 1) * SWW;
         {
             const float* gp = cgrid + (y * SIB_GW + x0) * GRID_STRIDE + 4 * cg;
-            f32x4 win[3][TG::SW + 2];
+            f32x4 win[3][SWW + 2];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < TG::SW + 2; ++dx) win[dy][dx] = *(const f32x4*)(gp + (dy * SIB_GW + dx) * GRID_STRIDE);
+                for (int dx = 0; dx < SWW + 2; ++dx) win[dy][dx] = *(const f32x4*)(gp + (dy * SIB_GW + dx) * GRID_STRIDE);
             f32x4 w9[9];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) w9[tap] = *(const f32x4*)(dwt + tap * NM + 4 * cg);
             bar_post(); // B3, first half: this wave's window reads have returned; the arithmetic runs under the mate's
 #pragma unroll
-            for (int p = 0; p < TG::SW; ++p) {
+            for (int p = 0; p < SWW; ++p) {
                 f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
@@ -1485,7 +1491,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
         bar_wait(); // B3, second half: the grid can be overwritten in place
         if (ptid < 7 * 2 * 8) {
 #pragma unroll
-            for (int p = 0; p < TG::SW; ++p)
+            for (int p = 0; p < SWW; ++p)
                 if (x0 + p < SIB_WIN) *(f32x4*)(cgrid + ((y + 1) * SIB_GW + x0 + p + 1) * GRID_STRIDE + 4 * cg) = dout[p];
         }
         lds_barrier(); // B4
@@ -1679,8 +1685,8 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
                                                 const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
                                                 float* __restrict__ out_part, const int32_t* __restrict__ d_count, int max_count,
                                                 const int32_t* __restrict__ tile_info, const uint2* __restrict__ slot_desc,
-                                                const float* __restrict__ facc) {
-    // Static LDS objects, one per weight-ring slot: hipcc orders a ds_read after an LDS-DMA write by object (alias
+                                                const float* __restrict__ facc, int bn) {
+    // (bn: board side, WIN only)  Static LDS objects, one per weight-ring slot: hipcc orders a ds_read after an LDS-DMA write by object (alias
     // scopes of distinct LDS variables), and with one dynamic array it drains ALL outstanding DMA (vmcnt(0)) before
     // the first LDS read of every stage.  With separate objects it waits exactly for the last DMA into the slot read.
     __shared__ uint4 ldsA[2 * MXS_U4];        // [2]{ f16 [128 samples][8 pieces] | fp8 [128 samples][4 pieces] }
@@ -1740,6 +1746,11 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
                 ksup = nsup - ubeg < ksup ? nsup - ubeg : ksup;
             }
         }
+        if (EPI == EPI_PARTIAL) { // an empty split (never chosen on purpose) contributes zeros and must not stream from beyond the matrix
+            const int nsup = full_tiles * 64 + 2 * last_cnt;
+            if (ubeg >= nsup) { ubeg = nsup - 1; ksup = 0; }
+            if (ksup < 0) ksup = 0;
+        }
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // 0..3 = m-tile inside a group
@@ -1758,7 +1769,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
         if (!WIN) return ubeg + ul;
         const int u = ubeg + ul < 2 * SIB_WPX ? ubeg + ul : 2 * SIB_WPX - 1;
         const int w = u >> 1, qq = u & 1, wy = w / SIB_WIN, wx = w - wy * SIB_WIN;
-        const int px = (win_oy + wy) * 15 + win_ox + wx;
+        const int px = (win_oy + wy) * bn + win_ox + wx;
         return px < full_tiles * 32 ? (px >> 5) * 64 + qq * 32 + (px & 31) : full_tiles * 64 + qq * last_cnt + (px - full_tiles * 32);
     };
     // a wave stages exactly the 6 weight fragments it consumes (m-tile `wave` of the stage's group): the weight ring is
@@ -2051,7 +2062,7 @@ __global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, co
                                                 int last_cnt, const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
                                                 float* __restrict__ out_part, const int32_t* __restrict__ d_count, int max_count,
                                                 const int32_t* __restrict__ tile_info, const uint2* __restrict__ slot_desc,
-                                                const float* __restrict__ facc) {
+                                                const float* __restrict__ facc, int bn) {
     __shared__ uint4 ldsA[2 * X3_U4];         // [2]{ hi [128 samples][4 pieces] | lo [128 samples][4 pieces] }
     __shared__ uint4 ldsW0[X3_U4], ldsW1[X3_U4], ldsW2[X3_U4], ldsW3[X3_U4]; // one object per ring slot (see k_fc0_mx)
     auto ring = [&](int slot) -> uint4* { return slot == 0 ? ldsW0 : slot == 1 ? ldsW1 : slot == 2 ? ldsW2 : ldsW3; };
@@ -2104,6 +2115,10 @@ __global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, co
                 ksup = nsup - ubeg < ksup ? nsup - ubeg : ksup;
             }
         }
+        if (EPI == EPI_PARTIAL) { // an empty split contributes zeros and must not stream from beyond the matrix
+            const int nsup = full_tiles * 64 + 2 * last_cnt;
+            if (ubeg >= nsup) { ubeg = nsup - 1; ksup = 0; }
+        }
         if (ksup < 0) ksup = 0;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2137,7 +2152,7 @@ __global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, co
         else {
             const int u = ubeg + ul < 2 * SIB_WPX ? ubeg + ul : 2 * SIB_WPX - 1;
             const int w = u >> 1, qq = u & 1, wy = w / SIB_WIN, wx = w - wy * SIB_WIN;
-            const int px = (win_oy + wy) * 15 + win_ox + wx;
+            const int px = (win_oy + wy) * bn + win_ox + wx;
             us = px < full_tiles * 32 ? (px >> 5) * 64 + qq * 32 + (px & 31) : full_tiles * 64 + qq * last_cnt + (px - full_tiles * 32);
         }
         return us * 2 + mm;
@@ -2680,13 +2695,13 @@ size_t net_alloc(Net& net) {
         ok = ok && A(&net.a_fc0, mb * row_u4 * 16 + 2 * OPX_BLK_U4 * 16); // + slack: the prefetch of the super-step past the last one reads one block beyond the row
         ok = ok && A(&net.h0, mb * 32 * 64 * 2);       // h0 and h1 rows (2 KiB each)
         ok = ok && A((void**)&net.s0, sizeof(float) * mb * heads_mt(net.hw) * 32); // logits
-        if (net.n == 15) { // sibling path of the trunk (k_group / k_trunk_sib): run lists and the per-workgroup base scratch
+        { // sibling path of the trunk (k_group / k_trunk_sib): run lists and the per-workgroup base scratch
             ok = ok && A((void**)&net.d_groups, sizeof(uint2) * (mb / SIB_MIN + 1));
             ok = ok && A((void**)&net.d_singles, sizeof(int32_t) * mb);
             ok = ok && A((void**)&net.d_gcnt, sizeof(int32_t) * SIB_CNT_INTS);
             ok = ok && A((void**)&net.d_sib_rows, sizeof(uint4) * mb);
             net.base_slots = (size_t)2 * net.games + mb / SIB_MIN + 1; // two slots per game + the other runs a round can hold
-            ok = ok && A((void**)&net.sib_h, sizeof(float) * net.base_slots * 3 * SIB_HB_FLOATS);
+            ok = ok && A((void**)&net.sib_h, sizeof(float) * net.base_slots * 3 * (size_t)sib_hb_floats(net.n));
             // difference path: slots (bins padded to whole tiles), their difference rows
             net.d_slots = mb + (size_t)(SIB_BINS + 1) * GT_BS;
             ok = ok && A((void**)&net.d_sib_slot, sizeof(uint32_t) * mb);
@@ -2959,15 +2974,22 @@ __global__ void k_zero_ints(int32_t* __restrict__ p, int n) {
 }
 // delta = false: copy path (the base row is stored into every child row, the children overwrite their windows; fc0 unchanged).
 // delta = true: difference path (full rows for the runs' bases and the single rows, difference rows for the children; fc0 = launch_fc0_delta).
+typedef void (*sib_kernel_t)(const uint64_t*, const uint4*, const float*, uint4*, size_t, const uint4*, const int32_t*, const float*, const uint32_t*, const int32_t*,
+                             uint4*, uint2*, unsigned long long*);
+static sib_kernel_t sib_kernel(bool delta, bool x16, int n) { // k_sib_children<DELTA, false, F16LO, N>
+    if (n == 9) return delta ? (x16 ? k_sib_children<true, false, true, 9> : k_sib_children<true, false, false, 9>)
+                             : (x16 ? k_sib_children<false, false, true, 9> : k_sib_children<false, false, false, 9>);
+    return delta ? (x16 ? k_sib_children<true, false, true, 15> : k_sib_children<true, false, false, 15>)
+                 : (x16 ? k_sib_children<false, false, true, 15> : k_sib_children<false, false, false, 15>);
+}
 static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_count, hipStream_t st, bool delta) {
     constexpr int LDS = TR_WBYTES + 4 * SIB_CGRID_BYTES + TR_SIDE_FLOATS * 4;
     static_assert(LDS + 32 <= 160 * 1024, "k_sib_children LDS (+ the static pair-barrier flags)");
     static bool attr_done[64] = {};
     if (!attr_done[net.device & 63]) {
-        hipFuncSetAttribute((const void*)k_sib_children<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        hipFuncSetAttribute((const void*)k_sib_children<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        hipFuncSetAttribute((const void*)k_sib_children<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        hipFuncSetAttribute((const void*)k_sib_children<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        for (int d = 0; d < 2; ++d)
+            for (int x = 0; x < 2; ++x)
+                for (int n : {9, 15}) hipFuncSetAttribute((const void*)sib_kernel(d != 0, x != 0, n), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done[net.device & 63] = true;
     }
     const bool x16 = net.fc0_fmt == FC0_F16;
@@ -2977,19 +2999,20 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         net.sib_cache_valid = true;
     }
     k_group<<<(S.games + GROUP_TREES - 1) / GROUP_TREES, 64 * GROUP_TREES, 0, st>>>(S, side, (uint2*)net.d_groups, net.d_singles, (uint4*)net.d_sib_rows, net.d_gcnt,
-                                                                                     delta ? net.d_sib_slot : nullptr, net.d_tags, (uint2*)net.d_comp);
+                                                                                     delta ? net.d_sib_slot : nullptr, net.d_tags, (uint2*)net.d_comp, net.n);
     if (!delta) {
         // (the copy path keeps the runs' h grids in sib_h[run index]: the slots the difference path caches bases in -- cached bases are void)
         net.sib_cache_valid = false;
-        launch_trunk_fmt<15, false, 16>(net, S, max_count, st, net.d_singles, net.d_gcnt, nullptr, net.d_gcnt + 1); // base positions of the runs, then the rows outside runs
-        auto kern = x16 ? k_sib_children<false, false, true> : k_sib_children<false>;
-        kern<<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
-                                    (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, nullptr, nullptr, nullptr, nullptr, nullptr);
+        // base positions of the runs, then the rows outside runs
+        if (net.n == 9) launch_trunk_fmt<9, false, 16>(net, S, max_count, st, net.d_singles, net.d_gcnt, nullptr, net.d_gcnt + 1);
+        else launch_trunk_fmt<15, false, 16>(net, S, max_count, st, net.d_singles, net.d_gcnt, nullptr, net.d_gcnt + 1);
+        sib_kernel(false, x16, net.n)<<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_fc0, net.row_u4,
+                                                             (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, nullptr, nullptr, nullptr, nullptr, nullptr);
         return;
     }
     k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu,
                                     sib_max_fways(net, max_count), SIB_MAX_WWAYS, (int)std::min<size_t>(net.part_w_rows * 7, (size_t)1 << 30), (int)net.base_slots,
-                                    (int)std::min<size_t>(net.part_rows, (size_t)1 << 30));
+                                    (int)std::min<size_t>(net.part_rows, (size_t)1 << 30), 2 * net.hw);
     static const bool stats = getenv("OMOK_SIB_STATS") && atoi(getenv("OMOK_SIB_STATS")); // diagnostics only: synchronises every round
     if (stats) {
         static long long acc[8] = {}, launches = 0;
@@ -3007,15 +3030,10 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         }
     }
     // runs without a cached base -> compact rows [0, misses) + their base slots; then the single rows -> compact rows [misses, misses + singles)
-    launch_trunk_fmt<15, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1);
-    if (x16) {
-        k_sib_children<true, false, true><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_base, net.row_u4,
-                                                                  (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, net.d_sib_slot, net.d_bin_start,
-                                                                  (uint4*)net.d_rows, (uint2*)net.d_slot_desc, nullptr);
-        return;
-    }
-    static const bool tprof = getenv("OMOK_SIB_PROF") && atoi(getenv("OMOK_SIB_PROF")); // timing experiments only
-    if (tprof) {
+    if (net.n == 9) launch_trunk_fmt<9, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1);
+    else launch_trunk_fmt<15, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1);
+    static const bool tprof = getenv("OMOK_SIB_PROF") && atoi(getenv("OMOK_SIB_PROF")); // timing experiments only (N = 15, fp6 format)
+    if (tprof && !x16 && net.n == 15) {
         static unsigned long long* d_tp = nullptr;
         static unsigned long long acc[32] = {};
         static int launches = 0;
@@ -3040,9 +3058,9 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         }
         return;
     }
-    k_sib_children<true><<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_base, net.row_u4,
-                                                 (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, net.d_sib_slot, net.d_bin_start,
-                                                 (uint4*)net.d_rows, (uint2*)net.d_slot_desc, nullptr);
+    sib_kernel(true, x16, net.n)<<<256, 512, LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_base, net.row_u4,
+                                                        (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, net.d_sib_slot, net.d_bin_start,
+                                                        (uint4*)net.d_rows, (uint2*)net.d_slot_desc, nullptr);
 }
 
 // fc0 of a sibling round on the difference path: fp32 fc0 rows of the full rows (split-K over blockIdx.y: there are ~16x fewer full rows
@@ -3057,31 +3075,31 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
     if (net.fc0_fmt == FC0_F16) { // the same four launches on f16 residuals (k_fc0_x3)
         const int lc = (hw % 32) ? (hw % 32) : 1;
         k_fc0_x3<EPI_PARTIAL, false><<<dim3(fgrid, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32, lc, bias_fc0, nullptr,
-                                                                     cap_rows, net.part, net.d_gcnt + 3, max_count, net.d_gcnt + 98, nullptr, nullptr);
+                                                                     cap_rows, net.part, net.d_gcnt + 3, max_count, net.d_gcnt + 98, nullptr, nullptr, net.n);
         k_facc_reduce<<<512, 256, 0, st>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 98, net.facc, (const uint2*)net.d_comp, net.d_gcnt + 96, (int)net.base_slots);
         const int wtiles_max = (tiles_max + SIB_BINS + 1 + 7) / 8 * 8 + 8;
         k_fc0_x3<EPI_SPLIT, true><<<dim3(wtiles_max, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.d_rows, 0, (size_t)SIBX_DROW_U4, hw / 32, lc, bias_fc0, h0, 128,
-                                                                       nullptr, net.d_gcnt, max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, net.facc);
+                                                                       nullptr, net.d_gcnt, max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, net.facc, net.n);
         const int stiles = wtiles_max < n_cu + 8 ? wtiles_max : n_cu + 8;
         k_fc0_x3<EPI_PARTIAL, true><<<dim3(n_cu + 8, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.d_rows, 0, (size_t)SIBX_DROW_U4, hw / 32, lc, bias_fc0, nullptr,
-                                                                       net.part_w_rows, net.part_w, net.d_gcnt, max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, nullptr);
+                                                                       net.part_w_rows, net.part_w, net.d_gcnt, max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, nullptr, net.n);
         k_win_finish<<<(unsigned)(((size_t)stiles * GT_BS * 64 + 255) / 256), 256, 0, st>>>(net.part_w, net.part_w_rows, net.d_gcnt, net.d_tile_info,
                                                                                              (const uint2*)net.d_slot_desc, net.facc, bias_fc0, h0, 128);
         return;
     }
     k_fc0_mx<EPI_PARTIAL><<<dim3(fgrid, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32,
                                                                (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, cap_rows, net.part, net.d_gcnt + 3,
-                                                               max_count, net.d_gcnt + 98, nullptr, nullptr);
+                                                               max_count, net.d_gcnt + 98, nullptr, nullptr, net.n);
     k_facc_reduce<<<512, 256, 0, st>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 98, net.facc, (const uint2*)net.d_comp, net.d_gcnt + 96, (int)net.base_slots);
     // window tiles: whole rounds of workgroups at full K, the tiles of the last partial round split over K (k_bin_prefix)
     const int wtiles_max = (tiles_max + SIB_BINS + 1 + 7) / 8 * 8 + 8; // (the XCD-aware tile mapping rounds an eighth of the tiles up)
     k_fc0_mx<EPI_SPLIT, 0, true><<<dim3(wtiles_max, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
                                                                        (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr, net.d_gcnt, max_count,
-                                                                       net.d_tile_info, (const uint2*)net.d_slot_desc, net.facc);
+                                                                       net.d_tile_info, (const uint2*)net.d_slot_desc, net.facc, net.n);
     const int stiles = wtiles_max < n_cu + 8 ? wtiles_max : n_cu + 8;
     k_fc0_mx<EPI_PARTIAL, 0, true><<<dim3(n_cu + 8, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
                                                                      (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, net.part_w_rows, net.part_w, net.d_gcnt,
-                                                                     max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, nullptr);
+                                                                     max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, nullptr, net.n);
     k_win_finish<<<(unsigned)(((size_t)stiles * GT_BS * 64 + 255) / 256), 256, 0, st>>>(net.part_w, net.part_w_rows, net.d_gcnt, net.d_tile_info,
                                                                                          (const uint2*)net.d_slot_desc, net.facc, bias_fc0, h0, 128);
 }
@@ -3089,11 +3107,13 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
 static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1, bool skip_softmax = false) {
     const int hw = net.hw;
     static const int use_sib = getenv("OMOK_TRUNK_SIB") ? atoi(getenv("OMOK_TRUNK_SIB")) : 2; // 0: every row through k_trunk, 1: copy path, 2: difference path
-    const bool sib = net.n == 15 && !from_f32 && sib_side >= 0 && use_sib && net.siblings && net.d_groups;
+    const bool sib = !from_f32 && sib_side >= 0 && use_sib && net.siblings && net.d_groups;
     // Small rounds (the thin tail of an episode) take the copy path: the difference path needs one fc0 tile per non-empty window bin
     // (81 + 1) however few rows there are, the copy path rows / 128 tiles of the full K -- measured break-even between 2048 and 4096 rows.  The choice is a
     // function of the host's bound on the request count (alive games x K) only, so a run is reproducible.
-    static const int delta_min_rows = getenv("OMOK_SIB_DELTA_MIN") ? atoi(getenv("OMOK_SIB_DELTA_MIN")) : 3072;
+    // (N = 9: 9 window bins + the single rows = 10 tiles at least)
+    static const int delta_min_env = getenv("OMOK_SIB_DELTA_MIN") ? atoi(getenv("OMOK_SIB_DELTA_MIN")) : 0;
+    const int delta_min_rows = delta_min_env > 0 ? delta_min_env : (net.n == 15 ? 3072 : 1024);
     const bool delta = sib && use_sib >= 2 && max_count >= delta_min_rows;
     if (prof) prof->begin(PC_TRUNK, st);
     if (sib) launch_trunk_siblings(net, S, sib_side, max_count, st, delta);
@@ -3150,11 +3170,11 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
             const int lc = (hw % 32) ? (hw % 32) : 1;
             if (nsplit == 1)
                 k_fc0_x3<EPI_SPLIT, false><<<dim3(tiles128, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32, lc, bias_fc0, h0, 128,
-                                                                              nullptr, S.d_count, max_count, nullptr, nullptr, nullptr);
+                                                                              nullptr, S.d_count, max_count, nullptr, nullptr, nullptr, net.n);
             else {
                 const size_t cap_rows = (size_t)tiles128 * GT_BS;
                 k_fc0_x3<EPI_PARTIAL, false><<<dim3(tiles128, nsplit), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.a_fc0, (nsup + nsplit - 1) / nsplit, net.row_u4,
-                                                                                     hw / 32, lc, bias_fc0, nullptr, cap_rows, net.part, S.d_count, max_count, nullptr, nullptr, nullptr);
+                                                                                     hw / 32, lc, bias_fc0, nullptr, cap_rows, net.part, S.d_count, max_count, nullptr, nullptr, nullptr, net.n);
                 const size_t threads = (size_t)max_count * 64;
                 k_splitk_finish<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(net.part, nsplit, cap_rows, bias_fc0, h0, 128, S.d_count, max_count);
             }
@@ -3165,13 +3185,13 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
                       : dbg == 4 ? k_fc0_mx<EPI_SPLIT, 4> : dbg == 7 ? k_fc0_mx<EPI_SPLIT, 7> : dbg == 8 ? k_fc0_mx<EPI_SPLIT, 8> : k_fc0_mx<EPI_SPLIT, 0>;
             kern<<<dim3(tiles128, 1), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4,
                                                       hw / 32, (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr,
-                                                      S.d_count, max_count, nullptr, nullptr, nullptr);
+                                                      S.d_count, max_count, nullptr, nullptr, nullptr, net.n);
         } else {
             const size_t cap_rows = (size_t)tiles128 * GT_BS;
             k_fc0_mx<EPI_PARTIAL><<<dim3(tiles128, nsplit), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0,
                                                                             (nsup + nsplit - 1) / nsplit, net.row_u4, hw / 32, (hw % 32) ? (hw % 32) : 1, sc,
                                                                             bias_fc0, nullptr, cap_rows, net.part, S.d_count, max_count, nullptr, nullptr,
-                                                                            nullptr);
+                                                                            nullptr, net.n);
             const size_t threads = (size_t)max_count * 64;
             k_splitk_finish<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(net.part, nsplit, cap_rows, bias_fc0, h0, 128, S.d_count,
                                                                                 max_count);

@@ -181,12 +181,12 @@ def test_evaluate_logits_is_the_same_forward():
 
 
 # ---- self-play: tree arithmetic bit-exact ---------------------------------------------------------
-@pytest.mark.parametrize("games,path", [(40, "copy"), (448, "difference")])
-def test_search_round_outputs_on_the_sibling_path(games, path):
-    """The p / v a SEARCH ROUND produces at N = 15 against the fp32 kernels and against the row-by-row path (evaluate_pv) of the same
-    engine, on the very request rows of the rounds.  Rounds of >= 3072 rows take the difference path (base row + window difference
+@pytest.mark.parametrize("n,k,games,path", [(15, 16, 40, "copy"), (15, 16, 448, "difference"), (9, 8, 40, "copy"), (9, 8, 320, "difference")])
+def test_search_round_outputs_on_the_sibling_path(n, k, games, path):
+    """The p / v a SEARCH ROUND produces against the fp32 kernels and against the row-by-row path (evaluate_pv) of the same
+    engine, on the very request rows of the rounds.  Rounds of >= 3072 rows (N = 15; 1024 at N = 9) take the difference path (base row + window difference
     rows, DESIGN 3.3: different rounding, inside the contract), smaller rounds the copy path (bit-identical to row-by-row)."""
-    n, k, count = 15, 16, 96
+    count = 6 * k
     tensors = oa.weights.init_random(n, seed=3)
     eng = oa.Engine(board_size=n, games=games, max_nodes=512, max_tables=128, max_batch_k=k, seed=11, net_mode=B.NET_F16X3)
     eng.load_weights(tensors)
