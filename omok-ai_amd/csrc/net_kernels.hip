@@ -935,23 +935,24 @@ __device__ inline int sib_bin_at(int pos) { // layout position -> bin
 __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, int32_t* __restrict__ bin_start, int32_t* __restrict__ tile_info,
                                                     uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu, int max_fways,
                                                     int max_wways, int part_w_rows, int facc_single_base, int part_f_rows, int nsup_full) {
-    __shared__ int tile0[SIB_BINS + 2], binc[SIB_BINS + 1];
+    __shared__ int tile0[SIB_BINS + 2], binc[SIB_BINS + 1], order[SIB_BINS + 1], start_at[SIB_BINS + 2];
     const int tid = threadIdx.x;
     const int c = tid < SIB_BINS ? cnt[8 + tid] : (tid == SIB_BINS ? cnt[1] : 0);
-    if (tid <= SIB_BINS) binc[tid] = c;
-    __syncthreads();
+    if (tid <= SIB_BINS) { binc[tid] = (c + GT_BS - 1) / GT_BS; order[tid] = sib_bin_at(tid); } // (tiles per bin and the layout order in parallel:
+    __syncthreads();                                                                                    //  the serial part below only adds)
     if (tid == 0) {
         int t = 0;
         for (int pos = 0; pos <= SIB_BINS; ++pos) { // (counts from LDS: 82 serial global loads were most of this kernel's 16 us)
-            const int b = sib_bin_at(pos);
+            const int b = order[pos];
             tile0[b] = t;
-            t += (binc[b] + GT_BS - 1) / GT_BS;
+            start_at[pos] = t;
+            t += binc[b];
         }
         const int ntiles = t;
         int t_split = ntiles - (ntiles < n_cu ? ntiles : ntiles % n_cu); // first tile of the partial round ...
         int first = ntiles;
         for (int pos = SIB_BINS; pos >= 0; --pos) {                     // ... moved down to the start of its bin
-            const int b0 = tile0[sib_bin_at(pos)];
+            const int b0 = start_at[pos];
             if (b0 < first) first = b0;
             if (b0 <= t_split) break;
         }

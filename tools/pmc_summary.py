@@ -28,7 +28,7 @@ if a.json:
     out = {"board": a.board, "rows": a.rows, "sims": a.sims, "unit": "bytes", "source": a.root,
            "method": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE [KiB] x 1024; raw (x1) fetch kept beside it"}
     for name, pre in (("k_trunk", ["k_trunk", "k_sib_children", "k_group", "k_bin_prefix"]),
-                      ("k_fc0_mx", ["k_fc0_mx", "k_splitk_finish", "k_facc_reduce", "k_win_finish"]),
+                      ("k_fc0_mx", ["k_fc0_mx", "k_fc0_x3", "k_splitk_finish", "k_facc_reduce", "k_win_finish"]),
                       ("tree", ["k_round", "k_scan", "k_fill", "k_scatter", "k_softmax_scatter", "k_add_evals"])):
         f, w = tot(pre, "FETCH_SIZE") * 1024.0, tot(pre, "WRITE_SIZE") * 1024.0
         # unit utilisation of the group over the profiled launches: MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x shader-engine-clock cycles);
