@@ -368,13 +368,13 @@ def main():
         # N = 15 (difference path): trunk = the child's 49-pixel difference row written (18816 B) + the base's 49 entries read
         # + per run of ~15 siblings whose base is not cached (22 % of the runs over a configs[1] episode, OMOK_SIB_STATS) a full row written twice
         # (fc0's compact copy, the base slot) and the base's three h grids; fc0 = the difference row + that share of a full row.
-        if n == 15:
-            miss = 0.22
-            alg_row = {"k_trunk": 2 * 18816.0 + miss * (2 * 384.0 * hw + 3 * hw * 128.0) / 15.0, "k_fc0_mx": 18816.0 + miss * 384.0 * hw / 15.0 + 2048}[kernel]
-        else:
-            alg_row = {"k_trunk": 2 * 8 * ((hw + 63) // 64) + 16 + 384.0 * hw, "k_fc0_mx": 384.0 * hw + 2048}[kernel]
-        members = {"k_trunk": "k_sib_children + k_trunk<BASE> + k_trunk<rows> + k_group + k_bin_prefix (N = 15 search rounds); k_trunk otherwise",
-                   "k_fc0_mx": "k_fc0_mx<full rows, split-K> + k_facc_reduce + k_fc0_mx<window tiles> + k_win_finish (N = 15 search rounds); k_fc0_mx (+ k_splitk_finish) otherwise"}[kernel]
+        # (bytes per pixel of an operand row: 2 x 192 in the fp6 format, 2 x 256 in the f16 format; a difference row = 49 pixels)
+        ppx = 512.0 if int(st.get("fc0_format", 0)) == 1 else 384.0
+        drow = 49.0 * ppx
+        miss, run = (0.22, 15.0) if n == 15 else (0.25, 7.5)  # share of the runs whose base is evaluated in full, siblings per run
+        alg_row = {"k_trunk": 2 * drow + miss * (2 * ppx * hw + 3 * hw * 128.0) / run, "k_fc0_mx": drow + miss * ppx * hw / run + 2048}[kernel]
+        members = {"k_trunk": "k_sib_children + k_trunk<BASE> + k_trunk<rows> + k_group + k_bin_prefix (search rounds); k_trunk otherwise",
+                   "k_fc0_mx": "k_fc0_mx | k_fc0_x3 <full rows, split-K> + k_facc_reduce + <window tiles> + k_win_finish (search rounds on the difference path); dense k_fc0_mx | k_fc0_x3 (+ k_splitk_finish) otherwise"}[kernel]
         return {"bound": "mfma", "kernel": kernel, "kernel_members": members, "achieved": ach, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / F16_DENSE_PEAK_TFLOPS, "traffic": per_row * rows / launches if per_row else None,
                 "traffic_uncalibrated_x2": per_row_x2 * rows / launches if per_row_x2 else None,
@@ -390,15 +390,18 @@ def main():
 
     note_trunk = ("`kernel` = the trunk GROUP of a forward: conv_in + 3 bottleneck blocks (k_group + k_bin_prefix + k_trunk<BASE> + k_sib_children + k_trunk on the "
                   "rows outside sibling runs); avg_launch_ms = the group per forward, averaged over ALL rounds of the timed region (thin ones included; "
-                  "`--max-plies 4` gives the full-round figure that profiles/r02_rocprofv3_kernel_stats_c2_first4plies.csv sums to).  "
+                  "`--max-plies 4` gives the full-round figure that profiles/r03_rocprofv3_kernel_stats_c2_first4plies.csv sums to).  "
                   "ALGORITHMIC flops 2*MAC of a full evaluation (13.0 MFLOP/eval at N = 15) / HIP-event time on the engine's stream.  Every product "
                   "runs as 3 f16 MFMAs (split operands), and at N = 15 sibling requests share a base pass and recompute only a 7x7 window each, so "
                   "the EXECUTED matrix work is ~0.3x the algorithmic figure: `achieved` counts useful work; the kernels' own utilisation (MFMA busy "
                   "26 %, VALU 52 %) is in profiles/")
-    note_fc0 = ("ALGORITHMIC flops 2*128*HW*512 per eval / HIP-event time of all fc0 launches.  Per K = 64 the kernels issue 4 f16 + 2 block-scaled "
-                "fp6 MFMAs (split operands) = 1.5x the pipe time of a plain-f16 product (frac <= 0.67 for a dense fc0).  At N = 15 a search round "
-                "runs the dense fc0 only on one full row per run of siblings and 98 of the 450 K-steps (the 7x7 window) on each child's difference "
-                "row, i.e. ~0.28x of the algorithmic work is EXECUTED: `achieved` counts useful work and can exceed what a dense kernel could reach")
+    mix = ("Per K = 64 the kernel (k_fc0_mx) issues 4 f16 + 2 block-scaled fp6 MFMAs (split operands) = 1.5x the pipe time of a plain-f16 product (frac <= 0.67 for a dense fc0)"
+           if int(st.get("fc0_format", 0)) == 0 else
+           "f16 operand format (k_fc0_x3): 3 f16 MFMAs per product = 3x the pipe time of a plain-f16 product (frac <= 0.33 for a dense fc0)")
+    note_fc0 = ("ALGORITHMIC flops 2*128*HW*512 per eval / HIP-event time of all fc0 launches.  " + mix + ".  A search round "
+                "runs the dense fc0 only on one full row per run of siblings whose base is not cached and 98 of the 2*HW K-steps (the 7x7 window) on each "
+                "child's difference row, i.e. ~0.28x (N = 15) / ~0.65x (N = 9) of the algorithmic work is EXECUTED: `achieved` counts useful work and can exceed "
+                "what a dense kernel could reach")
     fc0_fmt = {0: "block-scaled fp6 (e2m3)", 1: "f16"}.get(int(st.get("fc0_format", 0)), "f32")
     net_s = (st["ms_trunk"] + st["ms_fc0"] + st["ms_tail"]) * 1e-3
     tree_s = st["ms_tree"] * 1e-3
