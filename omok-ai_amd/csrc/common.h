@@ -111,7 +111,10 @@ void launch_harvest(int n, const Store& S, uint8_t* mask_dev /*[G]*/, long long*
                     uint8_t* dst_dev, long long cap_records, hipStream_t st);
 void launch_refill(int n, const Store& S, const float* root_policy_dev, int32_t* next_gid_dev, int total_games, int32_t* new_gid_dev /*[G]*/, hipStream_t st);
 void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st);
-void launch_scan(int n, const Store& S, int side, int K, hipStream_t st, unsigned long long* evals_dev = nullptr); // evals_dev[0] += the round's requests
+// evals_dev[0] += the round's requests; zero_ptr[0 .. zero_n) = 0 (counters the round's forward expects zeroed); fill = false: the dense
+// (tree, node) list is written by the net's grouping kernel instead (run-loop rounds on the sibling path: k_group visits every request anyway)
+void launch_scan(int n, const Store& S, int side, int K, hipStream_t st, unsigned long long* evals_dev = nullptr, int32_t* zero_ptr = nullptr, int zero_n = 0,
+                 bool fill = true);
 // one tree searched by `waves` waves (MCTSExecutor::run): sh_req [waves][KMAX] u16, sh_cnt [2 * KMAX] u32 (counts | bases)
 // rec_order / rec_pos non-NULL: RECORDED mode -- every simulation (round kernel) / every backup (scatter kernel) runs under the tree lock and
 // appends its wave's index to rec_order[(*rec_pos)++]: an exactly replayable interleaving (omok_execute_shared_recorded)

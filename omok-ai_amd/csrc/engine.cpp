@@ -596,7 +596,13 @@ static void enqueue_round(omok_engine* e, int round, int K, float eps, float alp
     launch_round(e->n, e->S, a, e->st);
     e->prof.end(e->st);
     e->prof.begin(PC_TREE_OTHER, e->st);
-    launch_scan(e->n, e->S, side, K, e->st, e->d_evals);
+    // run-loop rounds whose forward groups the requests by parent: k_scan zeroes the grouping counters, k_group writes the dense request list
+    // (two launches less per round); the step-wise API keeps the separate kernels (its callers read the request list before the forward)
+    int max_req = alive * K;
+    if (max_req > e->net.max_b) max_req = e->net.max_b;
+    const bool sib_round = eval_and_scatter && net_round_takes_sibling_path(e->net, max_req);
+    launch_scan(e->n, e->S, side, K, e->st, e->d_evals, sib_round ? e->net.d_gcnt : nullptr, NET_GCNT_INTS, !sib_round);
+    e->net.gcnt_zeroed = e->net.fill_in_group = sib_round;
     e->prof.end(e->st);
     if (eval_and_scatter) {
         // the split-precision net hands over its logits: softmax / tanh run inside the policy scatter (no [requests][ROWP] round trip of p)

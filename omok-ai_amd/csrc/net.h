@@ -64,6 +64,8 @@ struct Net {
     float* facc = nullptr;           // [base_slots + max_b][512] fp32 fc0 rows: base slots, then the round's single rows
     int32_t* d_tags = nullptr;       // [games][2] (leaf node | slot << 16) of the bases in the game's two slots, most recently used first; -1 = none
     void* d_comp = nullptr;          // the round's positions to evaluate in full: (request row of the first child, base slot)
+    bool gcnt_zeroed = false;        // the engine's k_scan of this round has zeroed d_gcnt (launch_trunk_siblings then skips k_zero_ints)
+    bool fill_in_group = false;      // ... and left the dense request list to k_group (launch_scan(fill = false))
     bool base_cache = true;          // false (omok_debug_set_base_cache): every run's base is evaluated in full every round (A-B check: same p / v bit for bit)
     bool sib_cache_valid = false;    // false: the trees changed outside the search rounds (reset, advance, refill): tags are cleared first
     float* part_w = nullptr;         // fp32 partials of the K-split window tiles: [7][part_w_rows][512]
@@ -112,6 +114,10 @@ inline int64_t net_tensor_size(int n, int idx) {
 // sibling requests take the incremental trunk path.  -1: plain rows (mirror evaluations, shared-tree rounds).
 // true if a forward of max_count rows leaves ALL its logits in net_logits() (split-precision modes, not chunked): skip_softmax may be used
 bool net_logits_cover_batch(const Net& net, int max_count);
+// true if net_forward_requests(net, S, max_count, ..., sibling_side >= 0) will group the requests by parent (k_group): the caller may then hand
+// the zeroing of net.d_gcnt and the request-list fill to it (Net::gcnt_zeroed, Net::fill_in_group)
+bool net_round_takes_sibling_path(const Net& net, int max_count);
+constexpr int NET_GCNT_INTS = 8 + 81 + 7 + 16; // ints of Net::d_gcnt
 // skip_softmax (split-precision modes only): stop behind the heads; the caller turns net_logits() into p / v itself (launch_softmax_scatter).
 void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, struct Prof* prof, int sibling_side = -1, bool skip_softmax = false);
 // Forward of explicit f32 inputs already in net.in_f32 ([count][3HW]); count is a host value

@@ -799,7 +799,7 @@ constexpr int sib_hb_floats(int n) { return n * n * NM; } // one base h grid in 
 constexpr int SIB_PAIR_CUT1 = 289, SIB_PAIR_CUT2 = 578, SIB_PAIR_CUT3 = 801; // shares of a workgroup's children per wave pair, cumulative / 1024 (k_sib_children)
 // difference path: window bins (window origin (wy0, wx0) in 0..8 each), the single rows as bin SIB_BINS, counters, difference rows
 constexpr int SIB_ORG = 15 - SIB_WIN + 1, SIB_BINS = SIB_ORG * SIB_ORG; // 9, 81: bin = wy0 * 9 + wx0 for EVERY board size (N = 9: origins 0..2, 9 bins in use)
-constexpr int SIB_CNT_INTS = 8 + SIB_BINS + 7 + 16;                       // d_gcnt: 8 counters, bin counts (96 ints), [96] full evaluations of runs (base-cache
+constexpr int SIB_CNT_INTS = NET_GCNT_INTS;                                // d_gcnt: 8 counters, bin counts (96 ints), [96] full evaluations of runs (base-cache
                                                                           // misses + uncacheable runs), [97] uncacheable runs
 constexpr int SIB_WPX = SIB_WIN * SIB_WIN;                                // 49 window pixels = 98 fc0 super-steps
 constexpr int SIB_DROW_U4 = SIB_WPX * 2 * 12;                             // 1176 uint4 = 18816 B: [q][w] 128-B f16 parts, [q][w] 64-B residual parts
@@ -823,7 +823,7 @@ __device__ inline void sib_window(int n, int action, int& wy0, int& wx0) { // th
 constexpr int GROUP_TREES = 16;
 __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, uint2* __restrict__ groups, int32_t* __restrict__ singles,
                                                              uint4* __restrict__ sib_rows, int32_t* __restrict__ cnt, uint32_t* __restrict__ sib_slot,
-                                                             int32_t* __restrict__ tags, uint2* __restrict__ comp, int bn) {
+                                                             int32_t* __restrict__ tags, uint2* __restrict__ comp, int bn, int do_fill) {
     // Difference path (sib_slot != NULL): base slots.  The FIRST run of a tree uses one of the game's two slots (2 g, 2 g + 1), whose content is
     // reused while a tag names the run's parent (a leaf is its tree's expansion target for ~14 rounds); further runs of the tree in the same
     // round (rare) take a slot behind the games' and are always evaluated.  comp[] lists the (first request row, slot) pairs to evaluate.
@@ -842,7 +842,12 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
     int parent = -1 - lane; // distinct for the lanes beyond the list
     uint32_t tn = 0, ta = 0;
     if (lane < n) {
-        tn = (uint32_t)t * (uint32_t)S.cap_nodes + S.req_node[(size_t)t * KMAX + lane];
+        const uint32_t node = S.req_node[(size_t)t * KMAX + lane];
+        tn = (uint32_t)t * (uint32_t)S.cap_nodes + node;
+        if (do_fill) { // k_fill's work (tree_kernels.hip): the dense (tree, node) list in tree order, then simulation order
+            S.req_ref[ts.req_base + (uint32_t)lane] = ((uint32_t)t << 16) | node;
+            S.req_aux[ts.req_base + (uint32_t)lane] = 0xFFFFFFFFu;
+        }
         const NodeHdr hd = S.hdr[tn];
         parent = hd.parent;
         ta = (uint32_t)hd.turn | ((uint32_t)hd.action << 8);
@@ -2994,13 +2999,15 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         attr_done[net.device & 63] = true;
     }
     const bool x16 = net.fc0_fmt == FC0_F16;
-    k_zero_ints<<<1, 128, 0, st>>>(net.d_gcnt, SIB_CNT_INTS); // (a hipMemsetAsync of these 448 bytes is a 13-us fill kernel)
+    if (!net.gcnt_zeroed) k_zero_ints<<<1, 128, 0, st>>>(net.d_gcnt, SIB_CNT_INTS); // (a hipMemsetAsync of these 448 bytes is a 13-us fill kernel)
+    const int do_fill = net.fill_in_group ? 1 : 0;
+    net.gcnt_zeroed = net.fill_in_group = false; // (one round's worth: the engine sets them per round)
     if (delta && (!net.sib_cache_valid || !net.base_cache)) { // the trees changed since the last search round: no cached base is valid
         hipMemsetAsync(net.d_tags, 0xFF, sizeof(int32_t) * (size_t)net.games * 2, st);
         net.sib_cache_valid = true;
     }
     k_group<<<(S.games + GROUP_TREES - 1) / GROUP_TREES, 64 * GROUP_TREES, 0, st>>>(S, side, (uint2*)net.d_groups, net.d_singles, (uint4*)net.d_sib_rows, net.d_gcnt,
-                                                                                     delta ? net.d_sib_slot : nullptr, net.d_tags, (uint2*)net.d_comp, net.n);
+                                                                                     delta ? net.d_sib_slot : nullptr, net.d_tags, (uint2*)net.d_comp, net.n, do_fill);
     if (!delta) {
         // (the copy path keeps the runs' h grids in sib_h[run index]: the slots the difference path caches bases in -- cached bases are void)
         net.sib_cache_valid = false;
@@ -3105,9 +3112,22 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
                                                                                          (const uint2*)net.d_slot_desc, net.facc, bias_fc0, h0, 128);
 }
 
+static int sib_env() { // OMOK_TRUNK_SIB: 0: every row through k_trunk, 1: copy path, 2: difference path
+    static const int use_sib = getenv("OMOK_TRUNK_SIB") ? atoi(getenv("OMOK_TRUNK_SIB")) : 2;
+    return use_sib;
+}
+static int chunk_env() {
+    static const int chunk_max = getenv("OMOK_NET_CHUNK") ? atoi(getenv("OMOK_NET_CHUNK")) : NET_CHUNK_DEFAULT;
+    return chunk_max;
+}
+bool net_round_takes_sibling_path(const Net& net, int max_count) { // (what forward_chunked + forward_f16x3 decide for a round's requests)
+    if (net.mode == OMOK_NET_F32 || max_count <= 0) return false;
+    if (chunk_env() > 0 && max_count > chunk_env()) return false;
+    return sib_env() && net.siblings && net.d_groups;
+}
 static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1, bool skip_softmax = false) {
     const int hw = net.hw;
-    static const int use_sib = getenv("OMOK_TRUNK_SIB") ? atoi(getenv("OMOK_TRUNK_SIB")) : 2; // 0: every row through k_trunk, 1: copy path, 2: difference path
+    const int use_sib = sib_env();
     const bool sib = !from_f32 && sib_side >= 0 && use_sib && net.siblings && net.d_groups;
     // Small rounds (the thin tail of an episode) take the copy path: the difference path needs one fc0 tile per non-empty window bin
     // (81 + 1) however few rows there are, the copy path rows / 128 tiles of the full K -- measured break-even between 2048 and 4096 rows.  The choice is a
@@ -3240,7 +3260,7 @@ __global__ void k_chunk_counts(const int32_t* __restrict__ d_count, int max_coun
 }
 
 static void forward_chunked(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1, bool skip_softmax = false) {
-    static const int chunk_max = getenv("OMOK_NET_CHUNK") ? atoi(getenv("OMOK_NET_CHUNK")) : NET_CHUNK_DEFAULT;
+    const int chunk_max = chunk_env();
     if (chunk_max <= 0 || max_count <= chunk_max) {
         forward_f16x3(net, S, max_count, from_f32, st, prof, sib_side, skip_softmax);
         return;
@@ -3348,7 +3368,7 @@ static int net_probe(Net& net, const Store& S, hipStream_t st) {
 }
 
 bool net_logits_cover_batch(const Net& net, int max_count) {
-    static const int chunk_max = getenv("OMOK_NET_CHUNK") ? atoi(getenv("OMOK_NET_CHUNK")) : NET_CHUNK_DEFAULT;
+    const int chunk_max = chunk_env();
     return net.mode != OMOK_NET_F32 && max_count <= net.max_b && (chunk_max <= 0 || max_count <= chunk_max);
 }
 

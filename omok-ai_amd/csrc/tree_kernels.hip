@@ -828,7 +828,9 @@ __global__ __launch_bounds__(1024) void k_scatter_shared(Store S, int side, cons
 // ---------------------------------------------------------------------------------------------
 // k_scan: dense, order-preserving request list over the live trees of one side
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan(Store S, int side, unsigned long long* __restrict__ evals) {
+__global__ __launch_bounds__(1024) void k_scan(Store S, int side, unsigned long long* __restrict__ evals, int32_t* __restrict__ zero_ptr, int zero_n) {
+    // (zero_ptr: the counters of the net's sibling grouping, which the round's forward expects zeroed: one launch less per round)
+    for (int i = threadIdx.x; i < zero_n; i += 1024) zero_ptr[i] = 0;
     // exclusive scan of the per-tree request counts in game order: each thread owns a contiguous chunk of
     // games, chunk sums are scanned with wave shuffles (64 lanes) and a 16-entry LDS table
     __shared__ uint32_t s_wave[16];
@@ -1897,9 +1899,9 @@ void launch_scatter_shared(int n, const Store& S, int side, const float* p, cons
     DISPATCH_N(n, (k_scatter_shared<9><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt, rec_order, rec_pos)),
                (k_scatter_shared<15><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt, rec_order, rec_pos)));
 }
-void launch_scan(int n, const Store& S, int side, int K, hipStream_t st, unsigned long long* evals) {
-    k_scan<<<1, 1024, 0, st>>>(S, side, evals);
-    k_fill<<<(S.games * K + 255) / 256, 256, 0, st>>>(S, side, K);
+void launch_scan(int n, const Store& S, int side, int K, hipStream_t st, unsigned long long* evals, int32_t* zero_ptr, int zero_n, bool fill) {
+    k_scan<<<1, 1024, 0, st>>>(S, side, evals, zero_ptr, zero_ptr ? zero_n : 0);
+    if (fill) k_fill<<<(S.games * K + 255) / 256, 256, 0, st>>>(S, side, K);
 }
 void launch_scatter(int n, const Store& S, int side, const float* p, const float* v, int max_count, hipStream_t st, bool backups) {
     const int grid = max_count < 8192 ? (max_count > 0 ? max_count : 1) : 8192;

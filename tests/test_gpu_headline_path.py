@@ -89,11 +89,11 @@ def _packed_run(n, games, count, k, plies, seed, tensors, cache=True):
     return got, data, dumps
 
 
-def test_selfplay_run_on_the_difference_path_is_reproducible_and_cache_independent():
-    """(b) + (d): two runs of omok_selfplay_run at N = 15 with 4096-row rounds (>= 3072: difference path, k_group hands out slots with
-    atomics) give the same packed replay bytes and trees; a third run with the base cache switched off gives them too (a cached base
-    evaluation == its recomputation, bit for bit)."""
-    n, games, count, k, plies = 15, 256, 96, 16, 4
+@pytest.mark.parametrize("n,games,count,k,plies", [(15, 256, 96, 16, 4), (9, 256, 48, 8, 5)])
+def test_selfplay_run_on_the_difference_path_is_reproducible_and_cache_independent(n, games, count, k, plies):
+    """(b) + (d): two runs of omok_selfplay_run with rounds on the difference path (N = 15: 4096 rows >= 3072; N = 9: 2048 rows >= 1024;
+    k_group hands out slots with atomics) give the same packed replay bytes and trees; a third run with the base cache switched off
+    gives them too (a cached base evaluation == its recomputation, bit for bit)."""
     tensors = oa.weights.init_random(n, seed=0)
     a = _packed_run(n, games, count, k, plies, 3, tensors)
     b = _packed_run(n, games, count, k, plies, 3, tensors)
@@ -105,11 +105,11 @@ def test_selfplay_run_on_the_difference_path_is_reproducible_and_cache_independe
     _same_dumps(a[2], c[2], "cache on vs off")
 
 
+@pytest.mark.parametrize("n,games,k", [(15, 224, 16), (9, 160, 8)])  # 3584 rows per round >= 3072; 1280 >= 1024
 @pytest.mark.parametrize("weights", ["random-init", "trained"])
-def test_difference_path_outputs_against_the_oracle(weights):
+def test_difference_path_outputs_against_the_oracle(weights, n, games, k):
     """(c) the p / v that rounds on the difference path deliver, against the oracle's fp32 forward of the same request rows (>= 256
     rows per weight set, taken across the rounds of two plies), in the default mode with its committed operand format."""
-    n, games, k = 15, 224, 16  # 3584 rows per round >= 3072
     tensors = oa.weights.init_random(n, seed=2) if weights == "random-init" else trained_tensors(n, 1)[0]
     eng = oa.Engine(board_size=n, games=games, max_nodes=512, max_tables=128, max_batch_k=k, seed=21)
     eng.load_weights(tensors)
