@@ -436,6 +436,11 @@ def main():
                           "algorithmic_bytes_per_sim": st["tree_bytes"] / max(st["sims"], 1.0),
                           "traffic": tree_traffic * st["sims"] / max(st["round_launches"], 1.0) if tree_traffic else None,
                           "hbm_gbs_pmc": tree_traffic * st["sims"] / tree_s / 1e9 if tree_traffic and tree_s > 0 else None,
+                          "hbm_bytes_per_sim_pmc": tree_traffic,
+                          "on_chip_fraction": (max(0.0, 1.0 - tree_traffic / (st["tree_bytes"] / max(st["sims"], 1.0))) if tree_traffic and st["tree_bytes"] > 0 else None),
+                          "on_chip_note": "SURVEY 8d asks for the LDS-resident fraction of the tree: this design stages NO tree array in LDS -- what a round reuses is one leaf per tree, "
+                                          "kept in registers (DESIGN 3, 'Where the tree lives') -- so the figure reported is the share of the kernel-counted algorithmic bytes that never "
+                                          "reach HBM by the PMC counters (registers + L2): 1 - hbm_bytes_per_sim_pmc / algorithmic_bytes_per_sim, 0 if the counters see more than the algorithm needs",
                           "traffic_unit": "HBM bytes per round (k_round + k_scan + k_fill + k_scatter*): PMC bytes per simulation (profiles/) x simulations per round"},
         "rank0_kernel_ms": {kk: st[kk] for kk in ("ms_round", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply")},
         "rank0_kernel_ms_method": f"HIP events on the engine's stream around every kernel category of 1 search round in {max(1, args.profile_every)} "
