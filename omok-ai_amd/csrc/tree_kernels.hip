@@ -544,8 +544,11 @@ __device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>&
     }
 }
 
+#ifndef KROUND_WPS
+#define KROUND_WPS 4 // minimum waves per SIMD the register allocation of k_round must allow (A-B builds: -DKROUND_WPS=...)
+#endif
 template <int N>
-__global__ __launch_bounds__(64) void k_round(Store S, RoundArgs A) {
+__global__ __launch_bounds__(64, KROUND_WPS) void k_round(Store S, RoundArgs A) {
     using G = Geo<N>;
     __shared__ float s_row[G::ROWP];
     const int g = blockIdx.x;
@@ -835,12 +838,20 @@ __global__ __launch_bounds__(1024) void k_scan(Store S, int side, unsigned long 
     // games, chunk sums are scanned with wave shuffles (64 lanes) and a 16-entry LDS table
     __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = (S.games + 1023) / 1024;
+    const int chunk = (S.games + 1023) / 1024; // <= 32 (games <= 32767)
     const int g0 = tid * chunk;
     uint32_t local = 0;
-    for (int i = 0; i < chunk; ++i) {
+    // (both loads of every game issued unconditionally and kept: `alive` then `n_req` as two dependent round trips per game and a second
+    //  pass over the same pairs cost 60 us at 16384 games)
+    uint32_t cnt[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
         const int g = g0 + i;
-        if (g < S.games && S.gs[g].alive) local += S.ts[side * S.games + g].n_req;
+        const bool in = i < chunk && g < S.games;
+        const uint32_t alive = in ? (uint32_t)S.gs[in ? g : 0].alive : 0u;
+        const uint32_t nreq = in ? S.ts[side * S.games + (in ? g : 0)].n_req : 0u;
+        cnt[i] = alive ? nreq : 0xFFFFFFFFu; // (0xFFFFFFFF: no live game here)
+        local += alive ? nreq : 0u;
     }
     uint32_t incl = local;
 #pragma unroll
@@ -858,12 +869,11 @@ __global__ __launch_bounds__(1024) void k_scan(Store S, int side, unsigned long 
         total += v;
     }
     uint32_t run = wbase + incl - local;
-    for (int i = 0; i < chunk; ++i) {
-        const int g = g0 + i;
-        if (g < S.games && S.gs[g].alive) {
-            const int t = side * S.games + g;
-            S.ts[t].req_base = run;
-            run += S.ts[t].n_req;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (cnt[i] != 0xFFFFFFFFu) {
+            S.ts[side * S.games + g0 + i].req_base = run;
+            run += cnt[i];
         }
     }
     if (tid == 0) {
