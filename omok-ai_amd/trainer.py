@@ -75,6 +75,7 @@ class Trainer:
         for _ in range(iteration_count):
             self.selfplay.set_episode(self.iteration)  # RNG stream of this iteration (key = seed + iteration * golden ratio)
             self.iteration += 1
+            self.engine.reset_stats()  # (per-iteration counters in the log line)
             self.selfplay.reset()  # fresh agents; the engine's replay buffer is cleared with them (:77-93)
             stats = self.selfplay.run(p.evaluate_count, p.evaluate_batch_size, p.epsilon, p.alpha, p.temperature,
                                       p.temperature_threshold, 0)
