@@ -228,6 +228,16 @@ constexpr bool MX6 = true;   // fc0 correction terms on fp6 (e2m3) operands with
 constexpr bool LO_SCALE_FROM_BOUND = false; // true: -16 VALU per block in the trunk epilogue (trunk -2 %), N = 9 max|dv| 3.6e-4 -> 5.9e-4
 constexpr int MX_SA = 2;        // fp8 copies of the fc0 operand are x * 2^MX_SA (|x| <= 112 representable; clamped beyond)
 
+// V2 children kernel (k_sib_children2, difference path): a base slot holds, PIXEL-major (a lane = (pixel, half h) of the MFMA accumulators reads its own
+// pixel's bytes, and the two halves' four 16-B pieces together use every byte of the pixel's lines: planes by piece -- adjacent pixels adjacent -- fetched
+// 2.5x the bytes through the L1 and were 20 % slower), uint4 units:
+//   grids  [(blk * 2 + kind) * HW + pixel][8 pieces]: kind 0 = h (depthwise input), 1 = d (depthwise output) of block blk; piece 2 g + h = channels 8 g + 4 h .. + 3
+//   x2     48 HW + [pixel][32 pieces]: the residual stream in front of block 2; piece 8 m + 2 g + h = channels 32 m + 8 g + 4 h .. + 3
+constexpr int SIB2_U4_PER_PX = 80;
+__host__ __device__ constexpr size_t sib2_slot_u4(int n) { return (size_t)n * n * SIB2_U4_PER_PX; }
+__host__ __device__ constexpr size_t sib2_grid(int hw, int blk, int kind, int px, int g, int h) { return ((size_t)(blk * 2 + kind) * hw + px) * 8 + 2 * g + h; }
+__host__ __device__ constexpr size_t sib2_x2(int hw, int px, int m, int g, int h) { return (size_t)48 * hw + (size_t)px * 32 + 8 * m + 2 * g + h; }
+
 template <int N>
 struct TrunkGeo {
     static constexpr int HW = N * N;
@@ -263,7 +273,9 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                                                                     const int32_t* __restrict__ row_list, const int32_t* __restrict__ d_nrows,
                                                                     const uint2* __restrict__ groups, float* __restrict__ hscr,
                                                                     const int32_t* __restrict__ d_out_base, uint4* __restrict__ a_base,
-                                                                    const int32_t* __restrict__ d_nrows2) {
+                                                                    const int32_t* __restrict__ d_nrows2, uint4* __restrict__ sib2) {
+    // sib2 != NULL (BASE | DELTA only): the base's h and d grids and its residual stream in front of block 2 go to the base slot in the layout
+    // k_sib_children2 reads (sib2_grid, sib2_x2) instead of the h grids to hscr.
     // row_list != NULL: the kernel evaluates the request rows row_list[0 .. d_nrows[0]) (the rows outside the sibling runs).
     // BASE: sample i is the BASE position of sibling run groups[i] -- the parent's board with the children's side to move; the
     // depthwise inputs of its three blocks go to hscr[i][blk][pixel][32] and its operand row into every child row of the run
@@ -474,6 +486,16 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
             const half8* W = ldsW + (size_t)blk * TR_FRAGS_PER_BLOCK * 64;
             const float* sd = lside + blk * TR_SIDE_PER_BLOCK;
             const float *dwt = sd, *b0 = sd + 9 * NM, *b1 = b0 + NM, *b2 = b1 + NM;
+            const bool to_sib2 = BASE && DELTA && sib2 != nullptr && active && !single(bi) && valid;
+            uint4* sb2 = nullptr;
+            if (BASE && DELTA) sb2 = sib2 + (size_t)(to_sib2 ? groups[bi].y : 0u) * sib2_slot_u4(N);
+            if (to_sib2 && blk == 2) { // the residual stream in front of block 2: what the children's outer ring continues from
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        sb2[sib2_x2(HW, px, m, g, h)] = __builtin_bit_cast(uint4, (f32x4){x[m][4 * g], x[m][4 * g + 1], x[m][4 * g + 2], x[m][4 * g + 3]});
+            }
             // L0: 1x1 128 -> 32, bias as the initial accumulator
             f32x16 acc;
 #pragma unroll
@@ -507,10 +529,11 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                     const f32x2 r0 = lrelu2(acc[4 * g], acc[4 * g + 1]), r1 = lrelu2(acc[4 * g + 2], acc[4 * g + 3]);
                     o[0] = r0[0]; o[1] = r0[1]; o[2] = r1[0]; o[3] = r1[1];
                     *(f32x4*)(grid + gi * GRID_STRIDE + 8 * g + 4 * h) = o;
+                    if (to_sib2) sb2[sib2_grid(HW, blk, 0, px, g, h)] = __builtin_bit_cast(uint4, o);
                 }
             }
             lds_barrier(); // B2: h of the whole sample is in the halo grid
-            if (BASE && active && !single(bi)) { // the base's depthwise input of this block -> scratch: the children's halo rings read it (225 pixels x 8 pieces of 16 B)
+            if (BASE && active && !single(bi) && !(DELTA && sib2)) { // the base's depthwise input of this block -> scratch: the children's halo rings read it (225 pixels x 8 pieces of 16 B)
                 for (int i = stid; i < HW * 8; i += TG::THREADS) {
                     const int p = i >> 3, piece = i & 7;
                     *(uint4*)(hscr + ((size_t)(DELTA ? (int)groups[bi].y : b) * 3 + blk) * (HW * NM) + p * NM + piece * 4) =
@@ -565,6 +588,7 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
                 const f32x4 dv = *(const f32x4*)(grid + gi * GRID_STRIDE + 8 * g + 4 * h);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) d[4 * g + i] = dv[i];
+                if (to_sib2) sb2[sib2_grid(HW, blk, 1, px, g, h)] = __builtin_bit_cast(uint4, dv);
             }
             }
             // L1: pointwise 32 -> 32 + bias + lrelu
@@ -1595,6 +1619,603 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
     }
 }
 
+// ===============================================================================================
+// k_sib_children2: the children of the difference path, ONE WAVE PER CHILD, windows that grow with the blocks
+// ===============================================================================================
+// A child differs from its base position in one input pixel P0, so its trunk activations differ from the base's only inside P0's
+// 3x3 / 5x5 / 7x7 neighbourhood after block 0 / 1 / 2.  k_sib_children evaluates the whole 7x7 window (two 32-pixel tiles = a wave pair)
+// through every block; here ONE 32-lane tile holds the 5x5 window (clamped to the board, nested in the 7x7 one) through conv_in, blocks 0
+// and 1 and the first layer of block 2, and only block 2's last two layers run on both the 5x5 tile and the 24 pixels of the outer ring:
+// 200 MFMAs per child instead of 340, no pair barriers (everything in LDS is the wave's own), two children per SIMD.  The depthwise uses
+// its linearity: d_child = d_base + dw(h_child - h_base), where the difference is non-zero only inside the 5x5 tile -- so the tile's LDS
+// grid is 25 cells without a halo, and the base pass stores its h AND d grids and its residual stream in front of block 2 (for the ring)
+// pixel-major in the piece order of the accumulators (sib2_grid, sib2_x2).  Results are within rounding of k_sib_children's (a different summation order in the
+// depthwise), not bit-identical: the difference path is tolerance-checked; the copy path (bit-identical rows) keeps k_sib_children.
+constexpr int V2_TW = 5, V2_TPX = V2_TW * V2_TW;          // tile window side, pixels
+constexpr int V2_RING = SIB_WPX - V2_TPX;                 // 24
+constexpr int V2_ZERO_CELL = 32, V2_WORD_CELL = 33;       // cells 0..31: tile grid / staging rows
+constexpr int V2_CELLS = 34;
+constexpr int V2_WAVE_FLOATS = V2_CELLS * GRID_STRIDE;
+constexpr int V2_LDS = TR_WBYTES + TR_SIDE_FLOATS * 4 + 8 * V2_WAVE_FLOATS * 4;
+static_assert(V2_LDS <= 160 * 1024, "k_sib_children2 LDS");
+#define OL() ({ int lq_ = lane; asm volatile("" : "+v"(lq_)); lq_; })
+#define TILE_A(LQ) (((LQ) & 31) < V2_TPX ? ((LQ) & 31) : V2_TPX - 1)
+#define RING_B(LQ) (((LQ) & 31) < V2_RING ? ((LQ) & 31) : V2_RING - 1)
+template <bool F16LO, int N, bool TPROF = false> // TPROF (OMOK_SIB_PROF=2, timing only): shader-clock cycles per phase of waves 0 and 5, summed over their passes, into tprof[]
+__global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restrict__ board, const uint4* __restrict__ wt, const float* __restrict__ side,
+                                                       uint4* __restrict__ a_out, size_t row_u4, const uint4* __restrict__ sib_rows,
+                                                       const int32_t* __restrict__ d_cnt, const uint4* __restrict__ sib2,
+                                                       const uint32_t* __restrict__ sib_slot, const int32_t* __restrict__ bin_start,
+                                                       uint4* __restrict__ d_rows, uint2* __restrict__ slot_desc, unsigned long long* __restrict__ tprof) {
+    unsigned long long tp_acc[12] = {}, tp_last = 0;
+    auto TP = [&](int phase) { // (phase = what ended here)
+        if (TPROF) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            tp_acc[phase] += now - tp_last;
+            tp_last = now;
+        }
+    };
+    constexpr int BLK_U4 = fmt_blk_u4(F16LO);
+    constexpr int DROW_U4 = F16LO ? SIBX_DROW_U4 : SIB_DROW_U4;
+    constexpr int HW = N * N, NW = Geo<N>::NW;
+    constexpr size_t SLOT_U4 = sib2_slot_u4(N);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const half8* ldsW = (const half8*)smem;
+    const float* lside = (const float*)(smem + TR_WBYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* wgrid = (float*)(smem + TR_WBYTES + TR_SIDE_FLOATS * 4) + wv * V2_WAVE_FLOATS; // this wave's cells
+    const int h = lane >> 5, l31 = lane & 31;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+    for (int i = tid; i < TR_WBYTES / 16; i += blockDim.x) ((uint4*)smem)[i] = wt[i];
+    for (int i = tid; i < TR_SIDE_FLOATS; i += blockDim.x) ((float*)lside)[i] = side[i];
+    for (int i = tid; i < 8 * V2_WAVE_FLOATS; i += blockDim.x) ((float*)(smem + TR_WBYTES + TR_SIDE_FLOATS * 4))[i] = 0.0f;
+    __syncthreads(); // (the only workgroup barrier: from here on a wave touches read-only LDS and its own cells)
+    for (int i = 0; i < (wv >> 2); ++i) __builtin_amdgcn_s_sleep(120); // the two waves of a SIMD (w, w + 4) start about half a pass apart
+    const int nsib = d_cnt[2];
+    const half8* convW = (const half8*)(wt + TR_WBYTES / 16);
+    half8 cwh[4], cwl[4]; // conv_in fragments: fetched again at the end of every pass (see k_sib_children)
+    auto load_conv_w = [&]() {
+        typedef const __attribute__((address_space(1))) half8* gptr_t;
+        unsigned long long cpv = (unsigned long long)convW;
+        asm volatile("" : "+s"(cpv));
+        gptr_t cp = (gptr_t)cpv;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            cwh[m] = cp[m * 64 + lane];
+            cwl[m] = cp[(4 + m) * 64 + lane];
+        }
+    };
+    load_conv_w();
+
+    // ---- the per-tile arithmetic of k_sib_children / k_trunk ----
+    auto L0_tile = [&](const f32x16 (&x)[4], int blk, f32x16& acc) {
+        const half8* W = ldsW + (size_t)blk * TR_FRAGS_PER_BLOCK * 64;
+        const float* b0 = lside + blk * TR_SIDE_PER_BLOCK + 9 * NM;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *(const f32x4*)(b0 + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[4 * g + i] = bv[i];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = x[ks >> 1][8 * (ks & 1) + j];
+            half8 bh, bl;
+            split8(v, bh, bl);
+            const half8 ah = W[(0 + ks) * 64 + lane], al = W[(8 + ks) * 64 + lane];
+            MFMA3(ah, al, bh, bl, acc);
+        }
+    };
+    auto L1L2_tile = [&](f32x16 (&x)[4], int blk, const float* d) {
+        const half8* W = ldsW + (size_t)blk * TR_FRAGS_PER_BLOCK * 64;
+        const float* sd = lside + blk * TR_SIDE_PER_BLOCK;
+        const float *b1 = sd + 10 * NM, *b2 = b1 + NM;
+        f32x16 accg;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *(const f32x4*)(b1 + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accg[4 * g + i] = bv[i];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 bh, bl;
+            split8(d + 8 * ks, bh, bl);
+            const half8 ah = W[(16 + ks) * 64 + lane], al = W[(18 + ks) * 64 + lane];
+            MFMA3(ah, al, bh, bl, accg);
+        }
+        float gv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gv[i] = accg[i];
+        LRELU16(gv);
+        half8 gh[2], gl[2];
+        split8(gv, gh[0], gl[0]);
+        split8(gv + 8, gh[1], gl[1]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4*)(b2 + 32 * m + 8 * g + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[m][4 * g + i] += bv[i];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const half8 ah = W[(20 + m * 2 + ks) * 64 + lane], al = W[(28 + m * 2 + ks) * 64 + lane];
+                MFMA3(ah, al, gh[ks], gl[ks], x[m]);
+            }
+            LRELU16(x[m]);
+        }
+    };
+    auto conv_in_tile = [&](f32x16 (&x)[4], uint32_t b0, uint32_t b1, uint32_t b2) {
+        union { uint32_t u[4]; half8 v; } Bq;
+        Bq.u[0] = h == 0 ? (b0 * 0x3C00u) | (b1 * 0x3C000000u) : 0u;
+        Bq.u[1] = h == 0 ? (b2 * 0x3C00u) | 0x3C000000u : 0u;
+        Bq.u[2] = 0u;
+        Bq.u[3] = 0u;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[m][i] = 0.0f;
+            x[m] = MFMA16(cwh[m], Bq.v, x[m]);
+            x[m] = MFMA16(cwl[m], Bq.v, x[m]);
+            LRELU16(x[m]);
+        }
+    };
+    auto input_bits = [&](const uint64_t* wsrc, int turn, int px, uint32_t (&bits)[3]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int m = 3 * px + c;
+            if (m >= 2 * HW) { bits[c] = turn == 0 ? 1u : 0u; continue; }
+            const int cell = m >> 1;
+            const bool want_black = ((m & 1) == 0) == (turn == 0);
+            const uint64_t w = wsrc[(want_black ? 0 : NW) + (cell >> 6)];
+            bits[c] = (uint32_t)((w >> (cell & 63)) & 1ULL);
+        }
+    };
+    // difference-row entries of a tile's pixels: k_sib_children's store_rows<DELTA> (staging rows = this wave's cells 0..31)
+    auto store_rows = [&](const f32x16 (&x)[4], uint4* row, bool lane_valid, const int (&rd_px)[4], const bool (&rd_ok)[4]) {
+        const int lq = OL();
+        uint4* stage_w = (uint4*)(wgrid + (lq & 31) * GRID_STRIDE);
+        int rd_gi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rd_gi[i] = 8 * i + (lq >> 3);
+        if constexpr (F16LO) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                half8 hi8[4], lo8[4];
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = x[2 * q + mm][8 * sx + j];
+                        split8(v, hi8[mm * 2 + sx], lo8[mm * 2 + sx]);
+                    }
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    if (lane_valid) {
+#pragma unroll
+                        for (int p4 = 0; p4 < 4; ++p4) stage_w[p4 * 2 + h] = __builtin_bit_cast(uint4, part ? lo8[p4] : hi8[p4]);
+                    }
+                    WAVE_LDS_FENCE();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint4 v = *(const uint4*)(wgrid + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
+                        if (i == 3) WAVE_LDS_FENCE();
+                        if (rd_ok[i]) nt_store(v, &row[part * SIB_DLO_U4 + (q * SIB_WPX + rd_px[i]) * 8 + (lane & 7)]);
+                    }
+                }
+            }
+            return;
+        }
+        u32x6 lo6[2];
+        uint32_t esc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float res[32], amax_v = 0.0f, amax_l = 0.0f;
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    union { uint32_t u[4]; uint4 v; } H;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float v0 = x[2 * q + mm][8 * sx + 2 * jj], v1 = x[2 * q + mm][8 * sx + 2 * jj + 1];
+                        const uint32_t ph = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v0, v1}, half2v));
+                        H.u[jj] = ph;
+                        float l0, l1;
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(ph), "v"(v0));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(ph), "v"(v1));
+                        const int slot = 16 * mm + 8 * sx + 2 * jj;
+                        res[slot] = l0; res[slot + 1] = l1;
+                        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax_v) : "v"(v0), "v"(v1));
+                        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax_l) : "v"(l0), "v"(l1));
+                    }
+                    if (lane_valid) stage_w[(mm * 2 + sx) * 2 + h] = H.v;
+                }
+            WAVE_LDS_FENCE();
+            int eh = (int)((__float_as_uint(amax_v) >> 23) & 0xFFu) - 2, el = (int)((__float_as_uint(amax_l) >> 23) & 0xFFu) - 2;
+            eh = eh < 1 ? 1 : eh;
+            el = el < 1 ? 1 : el;
+            esc[q] = (uint32_t)eh | ((uint32_t)el << 8);
+            f32x16v ev, od;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ev[i] = res[2 * i]; od[i] = res[2 * i + 1]; }
+            lo6[q] = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, __uint_as_float((uint32_t)el << 23));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 v = *(const uint4*)(wgrid + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
+                if (rd_ok[i]) nt_store(v, &row[(q * SIB_WPX + rd_px[i]) * 8 + (lane & 7)]);
+            }
+            WAVE_LDS_FENCE();
+        }
+        if (lane_valid) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                stage_w[q * 4 + h] = make_uint4(lo6[q][0], lo6[q][1], lo6[q][2], lo6[q][3]);
+                ((uint2*)(stage_w + q * 4 + 2))[h] = make_uint2(lo6[q][4], lo6[q][5]);
+                ((uint16_t*)(stage_w + q * 4 + 3))[h] = (uint16_t)esc[q];
+            }
+        }
+        WAVE_LDS_FENCE();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = *(const uint4*)(wgrid + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
+            const int q = (lane >> 2) & 1;
+            if (rd_ok[i]) nt_store(v, &row[SIB_DLO_U4 + (q * SIB_WPX + rd_px[i]) * 4 + (lane & 3)]);
+        }
+        WAVE_LDS_FENCE();
+    };
+    // the base's operand entries of this lane's pixel, and their subtraction: k_sib_children's
+    uint4 bs_hi[2][4], bs_lo[2];
+    uint2 bs_lt[2];
+    uint32_t bs_sc[2];
+    auto base_fetch = [&](const uint4* frow, int px) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint4* bp = frow + (size_t)((px >> 5) * 2 + q) * BLK_U4;
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) bs_hi[q][p4] = bp[(px & 31) * 8 + p4 * 2 + h];
+            if (F16LO) continue;
+            const uint4* lp = bp + OP_LO_U4 + (px & 31) * 4;
+            bs_lo[q] = lp[h];
+            bs_lt[q] = ((const uint2*)(lp + 2))[h];
+            bs_sc[q] = ((const uint16_t*)(lp + 3))[h];
+        }
+    };
+    auto sub_pieces = [&](f32x16 (&x)[4], int q, const uint4 (&pc)[4]) {
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                const uint4 hq = pc[mm * 2 + sx];
+                const uint32_t hu[4] = {hq.x, hq.y, hq.z, hq.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float v0 = x[2 * q + mm][8 * sx + 2 * jj], v1 = x[2 * q + mm][8 * sx + 2 * jj + 1];
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(v0) : "v"(hu[jj]));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v1) : "v"(hu[jj]));
+                    x[2 * q + mm][8 * sx + 2 * jj] = v0;
+                    x[2 * q + mm][8 * sx + 2 * jj + 1] = v1;
+                }
+            }
+    };
+    auto base_sub_f16lo = [&](f32x16 (&x)[4], const uint4* frow, int px) {
+        uint4 lo[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint4* bp = frow + (size_t)((px >> 5) * 2 + q) * BLK_U4 + OP_LO_U4;
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) lo[q][p4] = bp[(px & 31) * 8 + p4 * 2 + h];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) sub_pieces(x, q, bs_hi[q]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) sub_pieces(x, q, lo[q]);
+    };
+    auto base_subtract = [&](f32x16 (&x)[4]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const u32x6 r = {bs_lo[q].x, bs_lo[q].y, bs_lo[q].z, bs_lo[q].w, bs_lt[q].x, bs_lt[q].y};
+            union { half32 v; uint32_t u[16]; } L;
+            L.v = __builtin_amdgcn_cvt_scalef32_pk32_f16_fp6(r, __uint_as_float((bs_sc[q] >> 8) << 23));
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    const uint4 hq = bs_hi[q][mm * 2 + sx];
+                    const uint32_t hu[4] = {hq.x, hq.y, hq.z, hq.w};
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        float v0 = x[2 * q + mm][8 * sx + 2 * jj], v1 = x[2 * q + mm][8 * sx + 2 * jj + 1];
+                        const uint32_t ph = hu[jj], pl = L.u[8 * mm + 4 * sx + jj];
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(v0) : "v"(ph));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v1) : "v"(ph));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(v0) : "v"(pl));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v1) : "v"(pl));
+                        x[2 * q + mm][8 * sx + 2 * jj] = v0;
+                        x[2 * q + mm][8 * sx + 2 * jj + 1] = v1;
+                    }
+                }
+        }
+    };
+
+    f32x16 x[4];
+    // every wave walks its own contiguous eighth of the workgroup's contiguous range (a run's children are adjacent: its base comes
+    // from HBM once and from this XCD's L2 afterwards)
+    const int per_wg = (nsib + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int wg_begin = (int)blockIdx.x * per_wg < nsib ? (int)blockIdx.x * per_wg : nsib, wg_end = wg_begin + per_wg < nsib ? wg_begin + per_wg : nsib;
+    const int e_begin = wg_begin + (int)(((long long)(wg_end - wg_begin) * wv) >> 3), e_end = wg_begin + (int)(((long long)(wg_end - wg_begin) * (wv + 1)) >> 3);
+    auto entry_of = [&](int e0) { return e0 < e_end ? e0 : (e_begin < nsib ? e_begin : 0); };
+    auto fetch_word = [&](const uint4& ent) {
+        uint64_t word = 0ULL;
+        if (lane < 2 * NW) word = board[(size_t)ent.z * (2 * NW) + lane];
+        return word;
+    };
+    uint4 ent_c = sib_rows[entry_of(e_begin)], ent_n = sib_rows[entry_of(e_begin + 1)];
+    uint32_t slot_c = sib_slot[entry_of(e_begin)], slot_n = sib_slot[entry_of(e_begin + 1)];
+    uint64_t word_c = fetch_word(ent_c);
+    for (int e0 = e_begin; e0 < e_end; ++e0) {
+        if (TPROF) tp_last = __builtin_readcyclecounter();
+        // lane "constants" (tile pixel (ty, tx) of the 5x5 window, ring index, depthwise strip item) are derived again in every phase from an opaque
+        // copy of the lane index (OL): hoisted out of the loop or to the top of the pass, they and the addresses built on them were spilled to scratch
+        const uint4 ent = ent_c;
+        const int crow = (int)ent.x;
+        const int turn = (int)(ent.w & 0xFFu);
+        // windows: 7x7 around P0 clamped to the board (the difference row's), the 5x5 tile clamped likewise (nested in it)
+        const int pc = (2 * (int)((ent.w >> 8) & 0xFFu) + 1) / 3, py = pc / N, pxx = pc % N;
+        int wy0, wx0;
+        sib_window(N, (int)((ent.w >> 8) & 0xFFu), wy0, wx0);
+        int vy0 = py - V2_TW / 2, vx0 = pxx - V2_TW / 2;
+        vy0 = vy0 < 0 ? 0 : (vy0 > N - V2_TW ? N - V2_TW : vy0);
+        vx0 = vx0 < 0 ? 0 : (vx0 > N - V2_TW ? N - V2_TW : vx0);
+        const int oy = vy0 - wy0, ox = vx0 - wx0; // 0..2: where the tile sits in the 7x7 window
+        int bpxA; // this lane's board pixel in the tile
+        {
+            const int tA = TILE_A(OL());
+            bpxA = (vy0 + tA / V2_TW) * N + vx0 + tA % V2_TW;
+        }
+        // ring pixel `r` of the 7x7 window (those outside the tile): oy rows above, 2 - oy below, then per tile row ox pixels left, 2 - ox right
+        auto ring_at = [&](int r, int& wy, int& wx) {
+            if (r < 2 * SIB_WIN) {
+                const int fr = r >= SIB_WIN ? 1 : 0;
+                wx = r - SIB_WIN * fr;
+                wy = fr < oy ? fr : fr + V2_TW;
+            } else {
+                const int r2 = r - 2 * SIB_WIN, s = r2 & 1;
+                wy = oy + (r2 >> 1);
+                wx = s < ox ? s : s + V2_TW;
+            }
+        };
+        int bpxB; // ... and on the ring
+        {
+            int wyB, wxB;
+            ring_at(RING_B(OL()), wyB, wxB);
+            bpxB = (wy0 + wyB) * N + wx0 + wxB;
+        }
+
+        const int slot = bin_start[slot_c >> 24] + (int)(slot_c & 0xFFFFFFu);
+        uint4* crow_p = d_rows + (size_t)slot * DROW_U4;
+        const uint4* sb = sib2 + (size_t)ent.y * SLOT_U4;
+        const uint4* frow = a_out + (size_t)ent.y * row_u4;
+        uint64_t* cw = (uint64_t*)(wgrid + V2_WORD_CELL * GRID_STRIDE);
+        if (lane < 2 * NW) cw[lane] = word_c;
+        const uint64_t word_n = fetch_word(ent_n);
+        const uint4 ent_nn = sib_rows[entry_of(e0 + 2)];
+        const uint32_t slot_nn = sib_slot[entry_of(e0 + 2)];
+        WAVE_LDS_FENCE();
+        uint32_t bits[3];
+        input_bits(cw, turn, bpxA, bits);
+        conv_in_tile(x, bits[0], bits[1], bits[2]);
+        TP(0);
+        // h_child - h_base of the tile -> the wave's cells; `hb` / `db`: the base's h and d pieces of this lane's pixel
+        auto grid_write = [&](const f32x16& acc, const uint4 (&hb)[4]) {
+            const int lq = OL(), tA = TILE_A(lq);
+            if ((lq & 31) < V2_TPX) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b = __builtin_bit_cast(f32x4, hb[g]);
+                    const f32x2 r0 = lrelu2(acc[4 * g], acc[4 * g + 1]), r1 = lrelu2(acc[4 * g + 2], acc[4 * g + 3]);
+                    f32x4 o;
+                    o[0] = r0[0] - b[0]; o[1] = r0[1] - b[1]; o[2] = r1[0] - b[2]; o[3] = r1[1] - b[3];
+                    *(f32x4*)(wgrid + tA * GRID_STRIDE + 8 * g + 4 * h) = o;
+                }
+            }
+            WAVE_LDS_FENCE();
+        };
+        float d[16];
+        // depthwise of the difference over the 5x5 tile (zero outside it) + the base's depthwise output: item = (tile row, 4-channel group), one 3x5 window of
+        // b128 reads serves the row's 5 pixels; rows outside the tile get zero weights; outputs in place, then every lane takes its pixel's 16 channels
+        auto strip_dw = [&](const float* dwt, const uint4 (&db)[4]) {
+            {
+                const int lq = OL();
+                const int sy = (lq >> 3) < V2_TW ? (lq >> 3) : V2_TW - 1, scg = lq & 7; // lanes >= 40 run along
+                const bool s_act = (lq >> 3) < V2_TW;
+                f32x4 dout[V2_TW];
+#pragma unroll
+                for (int p = 0; p < V2_TW; ++p) dout[p] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) { // one window row at a time (registers)
+                    const int yr = sy + dy - 1;
+                    const int yy = yr < 0 ? 0 : (yr > V2_TW - 1 ? V2_TW - 1 : yr);
+                    const float rowok = (yr >= 0 && yr <= V2_TW - 1) ? 1.0f : 0.0f;
+                    f32x4 win[V2_TW], w3[3];
+#pragma unroll
+                    for (int xx = 0; xx < V2_TW; ++xx) win[xx] = *(const f32x4*)(wgrid + (yy * V2_TW + xx) * GRID_STRIDE + 4 * scg);
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) w3[dx] = *(const f32x4*)(dwt + (dy * 3 + dx) * NM + 4 * scg) * rowok;
+#pragma unroll
+                    for (int p = 0; p < V2_TW; ++p)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int xx = p + dx - 1;
+                            if (xx < 0 || xx > V2_TW - 1) continue;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) dout[p][c] += win[xx][c] * w3[dx][c];
+                        }
+                }
+                WAVE_LDS_FENCE(); // (every lane's window is in registers: the cells can be overwritten in place)
+                if (s_act) {
+#pragma unroll
+                    for (int p = 0; p < V2_TW; ++p) *(f32x4*)(wgrid + (sy * V2_TW + p) * GRID_STRIDE + 4 * scg) = dout[p];
+                }
+                WAVE_LDS_FENCE();
+            }
+            const int tA = TILE_A(OL());
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 dv = *(const f32x4*)(wgrid + tA * GRID_STRIDE + 8 * g + 4 * h);
+                const f32x4 b = __builtin_bit_cast(f32x4, db[g]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[4 * g + i] = b[i] + dv[i];
+            }
+            WAVE_LDS_FENCE();
+        };
+#pragma unroll 1
+        for (int blk = 0; blk < 2; ++blk) {
+            uint4 hb[4], db[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                hb[g] = sb[sib2_grid(HW, blk, 0, bpxA, g, h)];
+                db[g] = sb[sib2_grid(HW, blk, 1, bpxA, g, h)];
+            }
+            f32x16 acc;
+            L0_tile(x, blk, acc);
+            TP(1);
+            grid_write(acc, hb);
+            strip_dw(lside + blk * TR_SIDE_PER_BLOCK, db);
+            TP(2);
+            L1L2_tile(x, blk, d);
+            TP(3);
+        }
+        // ---- block 2: L0 on the tile; depthwise outputs on the tile AND the ring ----
+        float dBk[16];
+        int blk2 = 2;
+        asm volatile("" : "+s"(blk2)); // (opaque: as a constant, every LDS address of the block's weights and side table became a register of its own, hoisted and spilled)
+        {
+            uint4 hb[4], db[4], dbB[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                hb[g] = sb[sib2_grid(HW, 2, 0, bpxA, g, h)];
+                dbB[g] = sb[sib2_grid(HW, 2, 1, bpxB, g, h)];
+                db[g] = sb[sib2_grid(HW, 2, 1, bpxA, g, h)];
+            }
+            f32x16 acc;
+            L0_tile(x, blk2, acc);
+            TP(1);
+            grid_write(acc, hb);
+            const float* dwt = lside + blk2 * TR_SIDE_PER_BLOCK;
+            // ring first (it reads the difference cells the tile's depthwise then overwrites in place): a pixel outside the tile has at most 3 taps inside it.
+            // Its depthwise outputs (dBk) wait in registers while the tile goes through the last two layers and its stores
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = __builtin_bit_cast(f32x4, dbB[g]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dBk[4 * g + i] = b[i];
+            }
+            {
+                const int lq = OL();
+                const bool validB = (lq & 31) < V2_RING;
+                int wyB, wxB;
+                ring_at(RING_B(lq), wyB, wxB);
+                const int ry = wyB - oy, rx = wxB - ox; // relative to the tile: -2..6
+                const int ylo = ry - 1 < 0 ? 0 : ry - 1, yhi = ry + 1 > V2_TW - 1 ? V2_TW - 1 : ry + 1;
+                const int xlo = rx - 1 < 0 ? 0 : rx - 1, xhi = rx + 1 > V2_TW - 1 ? V2_TW - 1 : rx + 1;
+                const int cy = yhi - ylo + 1 > 0 ? yhi - ylo + 1 : 0, cx = xhi - xlo + 1 > 0 ? xhi - xlo + 1 : 0;
+                const int cnt = validB ? cy * cx : 0; // <= 3
+#pragma unroll 1
+                for (int k = 0; k < 3; ++k) { // (rolled: unrolled, the scheduler issues every tap's reads first and the registers spill)
+                    const int iy = cx > 0 ? (cx == 1 ? k : (cx == 2 ? k >> 1 : k / 3)) : 0, ix = k - iy * cx;
+                    const bool ok = k < cnt;
+                    const int ny = ylo + iy, nx = xlo + ix;
+                    const int cell = ok ? ny * V2_TW + nx : V2_ZERO_CELL;
+                    const int tap = ok ? (ny - ry + 1) * 3 + (nx - rx + 1) : 0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 hv = *(const f32x4*)(wgrid + cell * GRID_STRIDE + 8 * g + 4 * h);
+                        const f32x4 wv4 = *(const f32x4*)(dwt + tap * NM + 8 * g + 4 * h);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dBk[4 * g + i] += hv[i] * wv4[i];
+                    }
+                }
+            }
+            WAVE_LDS_FENCE();
+            strip_dw(dwt, db);
+        }
+        TP(4);
+        base_fetch(frow, bpxA);
+        L1L2_tile(x, blk2, d);
+        TP(5);
+        {
+            int rd_px[4];
+            bool rd_ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int t = 8 * i + (lane >> 3);
+                asm volatile("" : "+v"(t));
+                const int tc = t < V2_TPX ? t : V2_TPX - 1;
+                rd_px[i] = (oy + tc / V2_TW) * SIB_WIN + ox + tc % V2_TW;
+                rd_ok[i] = t < V2_TPX;
+            }
+            if constexpr (F16LO) base_sub_f16lo(x, frow, bpxA);
+            else base_subtract(x);
+            if (lane == 0) slot_desc[slot] = make_uint2((uint32_t)crow, ent.y);
+            TP(6);
+            store_rows(x, crow_p, (OL() & 31) < V2_TPX, rd_px, rd_ok);
+            TP(7);
+        }
+        // ---- the ring: residual stream of the BASE in front of block 2 + this child's depthwise outputs ----
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = __builtin_bit_cast(f32x4, sb[sib2_x2(HW, bpxB, m, g, h)]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[m][4 * g + i] = v[i];
+            }
+        base_fetch(frow, bpxB);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = dBk[i];
+        TP(8);
+        L1L2_tile(x, blk2, d);
+        TP(9);
+        {
+            int rd_px[4];
+            bool rd_ok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int t = 8 * i + (lane >> 3);
+                asm volatile("" : "+v"(t));
+                int wy, wx;
+                ring_at(t < V2_RING ? t : V2_RING - 1, wy, wx);
+                rd_px[i] = wy * SIB_WIN + wx;
+                rd_ok[i] = t < V2_RING;
+            }
+            if constexpr (F16LO) base_sub_f16lo(x, frow, bpxB);
+            else base_subtract(x);
+            TP(10);
+            store_rows(x, crow_p, (OL() & 31) < V2_RING, rd_px, rd_ok);
+        }
+        load_conv_w();
+        ent_c = ent_n;
+        ent_n = ent_nn;
+        slot_c = slot_n;
+        slot_n = slot_nn;
+        word_c = word_n;
+        TP(11);
+    }
+    if (TPROF && lane == 0 && (wv == 0 || wv == 5))
+        for (int i = 0; i < 12; ++i) atomicAdd(&tprof[(wv ? 16 : 0) + i], tp_acc[i]);
+}
+
+#undef OL
+#undef TILE_A
+#undef RING_B
 // ===============================================================================================
 // OMOK_NET_F16X3: fc0 with block-scaled fp6 (or fp8) correction terms
 // ===============================================================================================
@@ -2707,7 +3328,11 @@ size_t net_alloc(Net& net) {
             ok = ok && A((void**)&net.d_gcnt, sizeof(int32_t) * SIB_CNT_INTS);
             ok = ok && A((void**)&net.d_sib_rows, sizeof(uint4) * mb);
             net.base_slots = (size_t)2 * net.games + mb / SIB_MIN + 1; // two slots per game + the other runs a round can hold
-            ok = ok && A((void**)&net.sib_h, sizeof(float) * net.base_slots * 3 * (size_t)sib_hb_floats(net.n));
+            { // V2 children (default; OMOK_SIB_V2=0: k_sib_children on the difference path too): a base slot holds 80 planes instead of 3 h grids
+                const char* e = getenv("OMOK_SIB_V2");
+                net.sib_v2 = !(e && atoi(e) == 0);
+            }
+            ok = ok && A((void**)&net.sib_h, net.base_slots * std::max<size_t>(sizeof(float) * 3 * (size_t)sib_hb_floats(net.n), net.sib_v2 ? sib2_slot_u4(net.n) * 16 : 0));
             // difference path: slots (bins padded to whole tiles), their difference rows
             net.d_slots = mb + (size_t)(SIB_BINS + 1) * GT_BS;
             ok = ok && A((void**)&net.d_sib_slot, sizeof(uint32_t) * mb);
@@ -2931,7 +3556,7 @@ static int net_pack(Net& net, hipStream_t st) {
 
 template <int N, bool FROM_F32, int ABL = 0>
 static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st, const int32_t* row_list = nullptr, const int32_t* d_nrows = nullptr,
-                         const int32_t* d_out_base = nullptr, const int32_t* d_nrows2 = nullptr) {
+                         const int32_t* d_out_base = nullptr, const int32_t* d_nrows2 = nullptr, bool v2 = false) {
     using TG = TrunkGeo<N>;
     static bool attr_done[64] = {}; // per device: the attribute belongs to the device's copy of the code object
     auto kern = k_trunk<N, FROM_F32, ABL>;
@@ -2944,15 +3569,15 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
     kern<<<grid, TG::WG_THREADS, TG::LDS_BYTES, st>>>(S.req_ref, S.req_aux, S.board, S.hdr, S.d_count, S.cap_nodes, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first,
                                                        (uint4*)net.a_fc0, net.row_u4, max_count, row_list, d_nrows,
                                                        (ABL & 48) == 48 ? (const uint2*)net.d_comp : (const uint2*)net.d_groups, net.sib_h, d_out_base, (uint4*)net.a_base,
-                                                       d_nrows2);
+                                                       d_nrows2, v2 ? (uint4*)net.sib_h : nullptr);
 }
 
 // the same in the engine's current operand format (ABL bit 64 = FC0_F16 rows)
 template <int N, bool FROM_F32, int ABL = 0>
 static void launch_trunk_fmt(Net& net, const Store& S, int max_count, hipStream_t st, const int32_t* row_list = nullptr, const int32_t* d_nrows = nullptr,
-                             const int32_t* d_out_base = nullptr, const int32_t* d_nrows2 = nullptr) {
-    if (net.fc0_fmt == FC0_F16) launch_trunk<N, FROM_F32, ABL | 64>(net, S, max_count, st, row_list, d_nrows, d_out_base, d_nrows2);
-    else launch_trunk<N, FROM_F32, ABL>(net, S, max_count, st, row_list, d_nrows, d_out_base, d_nrows2);
+                             const int32_t* d_out_base = nullptr, const int32_t* d_nrows2 = nullptr, bool v2 = false) {
+    if (net.fc0_fmt == FC0_F16) launch_trunk<N, FROM_F32, ABL | 64>(net, S, max_count, st, row_list, d_nrows, d_out_base, d_nrows2, v2);
+    else launch_trunk<N, FROM_F32, ABL>(net, S, max_count, st, row_list, d_nrows, d_out_base, d_nrows2, v2);
 }
 
 template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
@@ -2988,6 +3613,12 @@ static sib_kernel_t sib_kernel(bool delta, bool x16, int n) { // k_sib_children<
     return delta ? (x16 ? k_sib_children<true, false, true, 15> : k_sib_children<true, false, false, 15>)
                  : (x16 ? k_sib_children<false, false, true, 15> : k_sib_children<false, false, false, 15>);
 }
+typedef void (*sib2_kernel_t)(const uint64_t*, const uint4*, const float*, uint4*, size_t, const uint4*, const int32_t*, const uint4*, const uint32_t*, const int32_t*,
+                              uint4*, uint2*, unsigned long long*);
+static sib2_kernel_t sib2_kernel(bool x16, int n) { // k_sib_children2<F16LO, N>
+    if (n == 9) return x16 ? k_sib_children2<true, 9> : k_sib_children2<false, 9>;
+    return x16 ? k_sib_children2<true, 15> : k_sib_children2<false, 15>;
+}
 static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_count, hipStream_t st, bool delta) {
     constexpr int LDS = TR_WBYTES + 4 * SIB_CGRID_BYTES + TR_SIDE_FLOATS * 4;
     static_assert(LDS + 32 <= 160 * 1024, "k_sib_children LDS (+ the static pair-barrier flags)");
@@ -2996,6 +3627,8 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         for (int d = 0; d < 2; ++d)
             for (int x = 0; x < 2; ++x)
                 for (int n : {9, 15}) hipFuncSetAttribute((const void*)sib_kernel(d != 0, x != 0, n), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        for (int x = 0; x < 2; ++x)
+            for (int n : {9, 15}) hipFuncSetAttribute((const void*)sib2_kernel(x != 0, n), hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS);
         attr_done[net.device & 63] = true;
     }
     const bool x16 = net.fc0_fmt == FC0_F16;
@@ -3038,9 +3671,39 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         }
     }
     // runs without a cached base -> compact rows [0, misses) + their base slots; then the single rows -> compact rows [misses, misses + singles)
-    if (net.n == 9) launch_trunk_fmt<9, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1);
-    else launch_trunk_fmt<15, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1);
-    static const bool tprof = getenv("OMOK_SIB_PROF") && atoi(getenv("OMOK_SIB_PROF")); // timing experiments only (N = 15, fp6 format)
+    static const int tprof_mode = getenv("OMOK_SIB_PROF") ? atoi(getenv("OMOK_SIB_PROF")) : 0; // timing experiments only (N = 15, fp6 format): 1 = k_sib_children, 2 = k_sib_children2
+    const bool tprof = tprof_mode == 1;
+    const bool v2 = net.sib_v2 && !tprof;
+    if (net.n == 9) launch_trunk_fmt<9, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1, v2);
+    else launch_trunk_fmt<15, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1, v2);
+    if (v2 && tprof_mode == 2 && !x16 && net.n == 15) {
+        static unsigned long long* d_tp = nullptr;
+        static unsigned long long acc[32] = {};
+        static int launches = 0;
+        if (!d_tp) { hipMalloc(&d_tp, 256); hipMemset(d_tp, 0, 256); hipFuncSetAttribute((const void*)k_sib_children2<false, 15, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS); }
+        k_sib_children2<false, 15, true><<<256, 512, V2_LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_base, net.row_u4, (const uint4*)net.d_sib_rows,
+                                                                   net.d_gcnt, (const uint4*)net.sib_h, net.d_sib_slot, net.d_bin_start, (uint4*)net.d_rows, (uint2*)net.d_slot_desc,
+                                                                   d_tp);
+        if (++launches % 100 == 0) {
+            hipStreamSynchronize(st);
+            hipMemcpy(acc, d_tp, 256, hipMemcpyDeviceToHost);
+            static const char* names[12] = {"inputs+conv_in", "L0 x3", "grid+strip dw+read d (blocks 0,1)", "L1L2 (blocks 0,1)", "block 2: grid + ring + tile dw", "L1L2 tile",
+                                            "base subtract tile", "stores tile", "x2 + base fetch ring", "L1L2 ring", "base subtract ring", "stores ring + conv w"};
+            for (int w = 0; w < 2; ++w) {
+                double tot = 0;
+                for (int i = 0; i < 12; ++i) tot += (double)acc[16 * w + i];
+                fprintf(stderr, "[sib2 prof] wave %d, %d launches x 256 workgroups: ", w ? 5 : 0, launches);
+                for (int i = 0; i < 12; ++i) fprintf(stderr, "%s %.1f%%  ", names[i], 100.0 * (double)acc[16 * w + i] / tot);
+                fprintf(stderr, " | %.0f cycles per workgroup and launch\n", tot / 256.0 / launches);
+            }
+        }
+        return;
+    }
+    if (v2) {
+        sib2_kernel(x16, net.n)<<<256, 512, V2_LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_base, net.row_u4, (const uint4*)net.d_sib_rows,
+                                                          net.d_gcnt, (const uint4*)net.sib_h, net.d_sib_slot, net.d_bin_start, (uint4*)net.d_rows, (uint2*)net.d_slot_desc, nullptr);
+        return;
+    }
     if (tprof && !x16 && net.n == 15) {
         static unsigned long long* d_tp = nullptr;
         static unsigned long long acc[32] = {};
