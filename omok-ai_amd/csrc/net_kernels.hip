@@ -1946,10 +1946,12 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
     };
 
     f32x16 x[4];
-    // every wave walks its own contiguous eighth of the workgroup's contiguous range (a run's children are adjacent: its base comes
+    // every wave walks its own contiguous part of the workgroup's contiguous range (a run's children are adjacent: its base comes
     // from HBM once and from this XCD's L2 afterwards)
     const int per_wg = (nsib + (int)gridDim.x - 1) / (int)gridDim.x;
     const int wg_begin = (int)blockIdx.x * per_wg < nsib ? (int)blockIdx.x * per_wg : nsib, wg_end = wg_begin + per_wg < nsib ? wg_begin + per_wg : nsib;
+    // (equal shares: the in-kernel counters show waves 4..7 18 % slower per child than the four launched first, but shares of 134 .. 146 / 1024 for waves 0..3
+    //  measured the same as 128: A-B builds, 144.7 - 148.8 ms of trunk kernels per three plies with no order in them)
     const int e_begin = wg_begin + (int)(((long long)(wg_end - wg_begin) * wv) >> 3), e_end = wg_begin + (int)(((long long)(wg_end - wg_begin) * (wv + 1)) >> 3);
     auto entry_of = [&](int e0) { return e0 < e_end ? e0 : (e_begin < nsib ? e_begin : 0); };
     auto fetch_word = [&](const uint4& ent) {
@@ -2076,21 +2078,66 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
             }
             WAVE_LDS_FENCE();
         };
-#pragma unroll 1
-        for (int blk = 0; blk < 2; ++blk) {
+        { // ---- block 0: h differs from the base's in ONE pixel (P0): its difference goes to one cell, and every tile pixel next to P0 adds one tap of it ----
+            int blk0 = 0;
+            asm volatile("" : "+s"(blk0));
+            const int tP = (py - vy0) * V2_TW + (pxx - vx0); // P0's pixel index in the tile (wave-uniform)
+            const int lq = OL(), tA = TILE_A(lq);
+            const bool at_p0 = (lq & 31) == tP;
             uint4 hb[4], db[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                hb[g] = sb[sib2_grid(HW, blk, 0, bpxA, g, h)];
-                db[g] = sb[sib2_grid(HW, blk, 1, bpxA, g, h)];
+                hb[g] = make_uint4(0u, 0u, 0u, 0u);
+                if (at_p0) hb[g] = sb[sib2_grid(HW, 0, 0, bpxA, g, h)];
+                db[g] = sb[sib2_grid(HW, 0, 1, bpxA, g, h)];
             }
             f32x16 acc;
-            L0_tile(x, blk, acc);
+            L0_tile(x, blk0, acc);
+            TP(1);
+            if (at_p0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b = __builtin_bit_cast(f32x4, hb[g]);
+                    const f32x2 r0 = lrelu2(acc[4 * g], acc[4 * g + 1]), r1 = lrelu2(acc[4 * g + 2], acc[4 * g + 3]);
+                    f32x4 o;
+                    o[0] = r0[0] - b[0]; o[1] = r0[1] - b[1]; o[2] = r1[0] - b[2]; o[3] = r1[1] - b[3];
+                    *(f32x4*)(wgrid + 8 * g + 4 * h) = o; // cell 0
+                }
+            }
+            WAVE_LDS_FENCE();
+            const int ey = py - vy0 - tA / V2_TW + 1, ex = pxx - vx0 - tA % V2_TW + 1; // P0 as a tap of this lane's pixel: (ey, ex) in 0..2 if adjacent
+            const bool adj = ey >= 0 && ey <= 2 && ex >= 0 && ex <= 2;
+            const float* wt0 = lside + blk0 * TR_SIDE_PER_BLOCK + (adj ? ey * 3 + ex : 0) * NM;
+            const float adjf = adj ? 1.0f : 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 dv = *(const f32x4*)(wgrid + 8 * g + 4 * h);
+                const f32x4 wv4 = *(const f32x4*)(wt0 + 8 * g + 4 * h) * adjf;
+                const f32x4 b = __builtin_bit_cast(f32x4, db[g]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[4 * g + i] = b[i] + dv[i] * wv4[i];
+            }
+            WAVE_LDS_FENCE();
+            TP(2);
+            L1L2_tile(x, blk0, d);
+            TP(3);
+        }
+        { // ---- block 1: differences in the 3x3 around P0 ----
+            int blk1 = 1;
+            asm volatile("" : "+s"(blk1));
+            uint4 hb[4], db[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                hb[g] = sb[sib2_grid(HW, 1, 0, bpxA, g, h)];
+                db[g] = sb[sib2_grid(HW, 1, 1, bpxA, g, h)];
+            }
+            f32x16 acc;
+            L0_tile(x, blk1, acc);
             TP(1);
             grid_write(acc, hb);
-            strip_dw(lside + blk * TR_SIDE_PER_BLOCK, db);
+            strip_dw(lside + blk1 * TR_SIDE_PER_BLOCK, db);
             TP(2);
-            L1L2_tile(x, blk, d);
+            L1L2_tile(x, blk1, d);
             TP(3);
         }
         // ---- block 2: L0 on the tile; depthwise outputs on the tile AND the ring ----
