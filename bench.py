@@ -372,8 +372,11 @@ def main():
         ppx = 512.0 if int(st.get("fc0_format", 0)) == 1 else 384.0
         drow = 49.0 * ppx
         miss, run = (0.22, 15.0) if n == 15 else (0.25, 7.5)  # share of the runs whose base is evaluated in full, siblings per run
-        alg_row = {"k_trunk": 2 * drow + miss * (2 * ppx * hw + 3 * hw * 128.0) / run, "k_fc0_mx": drow + miss * ppx * hw / run + 2048}[kernel]
-        members = {"k_trunk": "k_sib_children + k_trunk<BASE> + k_trunk<rows> + k_group + k_bin_prefix (search rounds); k_trunk otherwise",
+        # (k_sib_children2, the default: a base slot also holds the base's d grids and its residual stream in front of block 2 -- 1280 B per pixel instead of
+        #  384 -- written with the base and read once per run by its children; OMOK_SIB_V2=0: k_sib_children, 3 h grids)
+        slot_px = 1280.0 if os.environ.get("OMOK_SIB_V2", "1") != "0" else 384.0
+        alg_row = {"k_trunk": 2 * drow + (miss * (2 * ppx * hw + slot_px * hw) + slot_px * hw) / run, "k_fc0_mx": drow + miss * ppx * hw / run + 2048}[kernel]
+        members = {"k_trunk": "k_sib_children2 (k_sib_children on the copy path) + k_trunk<BASE> + k_trunk<rows> + k_group + k_bin_prefix (search rounds); k_trunk otherwise",
                    "k_fc0_mx": "k_fc0_mx | k_fc0_x3 <full rows, split-K> + k_facc_reduce + <window tiles> + k_win_finish (search rounds on the difference path); dense k_fc0_mx | k_fc0_x3 (+ k_splitk_finish) otherwise"}[kernel]
         return {"bound": "mfma", "kernel": kernel, "kernel_members": members, "achieved": ach, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / F16_DENSE_PEAK_TFLOPS, "traffic": per_row * rows / launches if per_row else None,
@@ -388,12 +391,12 @@ def main():
                                  "over GRBM_GUI_ACTIVE",
                 "note": note}
 
-    note_trunk = ("`kernel` = the trunk GROUP of a forward: conv_in + 3 bottleneck blocks (k_group + k_bin_prefix + k_trunk<BASE> + k_sib_children + k_trunk on the "
+    note_trunk = ("`kernel` = the trunk GROUP of a forward: conv_in + 3 bottleneck blocks (k_group + k_bin_prefix + k_trunk<BASE> + k_sib_children2 + k_trunk on the "
                   "rows outside sibling runs); avg_launch_ms = the group per forward, averaged over ALL rounds of the timed region (thin ones included; "
                   "`--max-plies 4` gives the full-round figure that profiles/r03_rocprofv3_kernel_stats_c2_first4plies.csv sums to).  "
                   "ALGORITHMIC flops 2*MAC of a full evaluation (13.0 MFLOP/eval at N = 15) / HIP-event time on the engine's stream.  Every product "
-                  "runs as 3 f16 MFMAs (split operands), and at N = 15 sibling requests share a base pass and recompute only a 7x7 window each, so "
-                  "the EXECUTED matrix work is ~0.3x the algorithmic figure: `achieved` counts useful work; the kernels' own utilisation (MFMA busy "
+                  "runs as 3 f16 MFMAs (split operands), and at N = 15 sibling requests share a base pass and recompute only a 5x5 / 7x7 window each, so "
+                  "the EXECUTED matrix work is ~0.2x the algorithmic figure: `achieved` counts useful work; the kernels' own utilisation (MFMA busy "
                   "26 %, VALU 52 %) is in profiles/")
     mix = ("Per K = 64 the kernel (k_fc0_mx) issues 4 f16 + 2 block-scaled fp6 MFMAs (split operands) = 1.5x the pipe time of a plain-f16 product (frac <= 0.67 for a dense fc0)"
            if int(st.get("fc0_format", 0)) == 0 else

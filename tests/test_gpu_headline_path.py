@@ -174,3 +174,41 @@ def test_rounds_of_different_sizes_in_one_ply_never_read_a_stale_base(mode):
         sp.sample_actions(1.0, 30)
         sp.advance()
     eng.close()
+
+
+@pytest.mark.parametrize("n,games,k", [(15, 224, 16), (9, 160, 8)])
+def test_both_children_kernels_of_the_difference_path_agree(n, games, k, monkeypatch):
+    """The difference path evaluates a run's children with k_sib_children2 (one wave per child, windows that grow with the blocks, the base's depthwise
+    outputs + the depthwise of the difference); OMOK_SIB_V2=0 (read when an engine is created) keeps k_sib_children (wave pair per child, the whole 7x7 window
+    through every block, halo ring from the base).  Same requests -> p / v within 2e-4 of each other and each within 1e-3 of the oracle; different bits
+    (both kernels really ran)."""
+    tensors = oa.weights.init_random(n, seed=4)
+    net = O.Net(n, tensors)
+    outs = []
+    for v2 in ("1", "0"):
+        monkeypatch.setenv("OMOK_SIB_V2", v2)
+        eng = oa.Engine(board_size=n, games=games, max_nodes=512, max_tables=128, max_batch_k=k, seed=13)
+        eng.load_weights(tensors)
+        sp = oa.SelfPlay(eng)
+        sp.reset()
+        per = []
+        for rnd in range(4):
+            nreq = sp.round_generate(rnd, k, 0.25, 0.03)
+            x = sp.round_inputs().copy()
+            p, v = sp.round_eval()
+            per.append((x, np.array(p).reshape(nreq, -1).copy(), np.array(v).reshape(-1).copy()))
+            sp.round_scatter()
+        outs.append(per)
+        eng.close()
+    rng = np.random.default_rng(1)
+    differing = 0
+    for rnd in range(1, 4):
+        (xa, pa, va), (xb, pb, vb) = outs[0][rnd], outs[1][rnd]
+        assert np.array_equal(xa, xb)
+        assert np.abs(pa - pb).max() < 2e-4 and np.abs(va - vb).max() < 2e-4, (rnd, float(np.abs(pa - pb).max()), float(np.abs(va - vb).max()))
+        differing += int((pa.view(np.uint32) != pb.view(np.uint32)).any(axis=1).sum())
+        pick = rng.choice(len(xa), size=32, replace=False)
+        pc, vc = net.forward(xa[pick], threads=8)
+        for p, v in ((pa, va), (pb, vb)):
+            assert np.abs(p[pick] - pc).max() < TOL and np.abs(v[pick] - vc).max() < TOL
+    assert differing > 0
