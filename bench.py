@@ -374,7 +374,7 @@ def main():
         miss, run = (0.22, 15.0) if n == 15 else (0.25, 7.5)  # share of the runs whose base is evaluated in full, siblings per run
         # (k_sib_children2, the default: a base slot also holds the base's d grids and its residual stream in front of block 2 -- 1280 B per pixel instead of
         #  384 -- written with the base and read once per run by its children; OMOK_SIB_V2=0: k_sib_children, 3 h grids)
-        slot_px = 1280.0 if os.environ.get("OMOK_SIB_V2", "1") != "0" else 384.0
+        slot_px = 1280.0 if st.get("children2_launches", 0.0) > 0 else 384.0
         alg_row = {"k_trunk": 2 * drow + (miss * (2 * ppx * hw + slot_px * hw) + slot_px * hw) / run, "k_fc0_mx": drow + miss * ppx * hw / run + 2048}[kernel]
         members = {"k_trunk": "k_sib_children2 (k_sib_children on the copy path) + k_trunk<BASE> + k_trunk<rows> + k_group + k_bin_prefix (search rounds); k_trunk otherwise",
                    "k_fc0_mx": "k_fc0_mx | k_fc0_x3 <full rows, split-K> + k_facc_reduce + <window tiles> + k_win_finish (search rounds on the difference path); dense k_fc0_mx | k_fc0_x3 (+ k_splitk_finish) otherwise"}[kernel]
@@ -420,6 +420,9 @@ def main():
                        "probe_logit_abs_max": st.get("probe_logit_max"),
                        "rule": "fp6 correction terms are kept while the probe's worst |dp| and |dv| against the fp32 kernels are <= probe_limit (half the 1e-3 "
                                "contract); otherwise f16 correction terms (DESIGN 3.4)"} if args.net_mode == "f16x3" else None,
+        "children_kernel_launches": {"k_sib_children2": st.get("children2_launches"), "k_sib_children": st.get("children1_launches"),
+                                     "note": "sibling rounds of the timed region by the kernel that evaluated the runs' children: k_sib_children2 on the difference path "
+                                             "(rounds of >= 3072 rows at N = 15, >= 1024 at N = 9), k_sib_children on the copy path (smaller rounds)"},
         "data": "synthetic (games from the empty board, random-init net seed 0, one RNG stream per step)",
         "config": {"workload": f"{games} concurrent {n}x{n} games per GPU, {args.sims} sims/move, K={k}, two trees per game"
                                + ("" if complete else f", first {args.max_plies} plies only (games/s extrapolated)"),

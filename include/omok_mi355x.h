@@ -246,6 +246,11 @@ int omok_debug_operand_rows(omok_engine* e, int32_t first_row, int32_t rows, voi
  * then evaluated in full in every round instead of being kept while its leaf stays the tree's expansion target).  Results must not
  * change by a bit (tests). */
 int omok_debug_set_base_cache(omok_engine* e, int32_t enabled);
+/* Debugging aid / A-B switch: which kernel evaluates the children of a sibling run on the difference path: 2 = k_sib_children2 (default: one wave
+ * per child, windows that grow with the blocks), 1 = k_sib_children (a wave pair per child, the 7x7 window through every block; always used on the copy path).
+ * Outputs agree within 2e-4 (tests); cached base positions are dropped (the kernels read different base-slot layouts).  The environment variable
+ * OMOK_SIB_V2=0 at omok_create selects 1 as the engine's default. */
+int omok_debug_set_children_kernel(omok_engine* e, int32_t which);
 
 #define OMOK_STAT_SIMS 0        /* simulations run (incl. terminal hits / no-action sims) */
 #define OMOK_STAT_EVALS 1       /* net evaluations (search requests + mirror evals + root) */
@@ -271,7 +276,9 @@ int omok_debug_set_base_cache(omok_engine* e, int32_t enabled);
 #define OMOK_STAT_PROBE_DV_F16 21
 #define OMOK_STAT_PROBE_LIMIT 22  /* fp6 is kept while both of its figures are <= this (5e-4) */
 #define OMOK_STAT_PROBE_LOGIT_MAX 23 /* largest |policy logit| of the probe rows (fp32 kernels) */
-#define OMOK_STAT_COUNT 24
+#define OMOK_STAT_CHILDREN2_LAUNCHES 24 /* sibling rounds whose children ran on k_sib_children2 (difference path, default) ... */
+#define OMOK_STAT_CHILDREN1_LAUNCHES 25 /* ... on k_sib_children (copy path; difference path after omok_debug_set_children_kernel(1)) */
+#define OMOK_STAT_COUNT 26
 int omok_get_stats(omok_engine* e, double* stats /* [OMOK_STAT_COUNT] */);
 int omok_reset_stats(omok_engine* e);
 /* Per-category HIP-event timing of the kernels on the engine's stream (off by default).  enabled = 1: every launch; enabled = N > 1:

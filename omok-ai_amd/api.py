@@ -137,6 +137,10 @@ class Engine:
     def set_base_cache(self, on=True):
         self._chk(B.lib().omok_debug_set_base_cache(self.h, int(bool(on))))
 
+    def set_children_kernel(self, which=2):
+        """2: k_sib_children2 (default), 1: k_sib_children on the difference path of sibling rounds (A-B / tests)."""
+        self._chk(B.lib().omok_debug_set_children_kernel(self.h, int(which)))
+
     def set_profiling(self, on=True):
         """True / 1: time every launch; N > 1: time one search round in N (stats are scaled); False: off."""
         self._chk(B.lib().omok_set_profiling(self.h, int(on)))

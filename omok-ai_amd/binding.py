@@ -16,7 +16,8 @@ FC0_FORMATS = {-1: "f32", 0: "fp6", 1: "f16"}
 MODE_PLAYER, MODE_OPPONENT = 0, 1
 STAT_NAMES = ["sims", "evals", "ply_games", "finished", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply",
               "fc0_launches", "fc0_rows", "tree_bytes", "round_launches", "ms_round", "peak_nodes", "peak_tables",
-              "fc0_format", "probe_rows", "probe_dp_fp6", "probe_dv_fp6", "probe_dp_f16", "probe_dv_f16", "probe_limit", "probe_logit_max"]
+              "fc0_format", "probe_rows", "probe_dp_fp6", "probe_dv_fp6", "probe_dp_f16", "probe_dv_f16", "probe_limit", "probe_logit_max",
+              "children2_launches", "children1_launches"]
 
 # every symbol include/omok_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -27,7 +28,7 @@ SYMBOLS = [
     "omok_round_eval", "omok_round_outputs", "omok_round_inject", "omok_round_scatter", "omok_mirror_generate",
     "omok_mirror_inputs", "omok_mirror_eval", "omok_mirror_outputs", "omok_mirror_inject", "omok_mirror_apply",
     "omok_alive_count", "omok_current_ply", "omok_game_info", "omok_tree_dump", "omok_tree_root", "omok_replay_game",
-    "omok_operand_row_bytes", "omok_debug_operand_rows", "omok_debug_set_base_cache",
+    "omok_operand_row_bytes", "omok_debug_operand_rows", "omok_debug_set_base_cache", "omok_debug_set_children_kernel",
     "omok_replay_pack_dev", "omok_replay_record_bytes", "omok_replay_augment_dev", "omok_replay_augmented_game", "omok_get_stats", "omok_reset_stats", "omok_set_profiling",
 ]
 
@@ -83,6 +84,7 @@ def lib():
     L.omok_operand_row_bytes.restype = C.c_int64
     L.omok_debug_operand_rows.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
     L.omok_debug_set_base_cache.argtypes = [H, C.c_int32]
+    L.omok_debug_set_children_kernel.argtypes = [H, C.c_int32]
     L.omok_set_episode.argtypes = [H, C.c_uint64]
     L.omok_env_place_stone.argtypes = [H, u8p, u8p, C.POINTER(C.c_uint16), ip, C.c_int32, ip]
     L.omok_compute_policy.argtypes = [H, fp, u8p]

@@ -1352,6 +1352,14 @@ extern "C" int omok_debug_set_base_cache(omok_engine* e, int32_t enabled) {
     return OMOK_OK;
 }
 
+extern "C" int omok_debug_set_children_kernel(omok_engine* e, int32_t which) {
+    if (!e) return OMOK_ERR_INVALID;
+    if (which != 1 && which != 2) return fail(e, OMOK_ERR_INVALID, "children kernel %d (1 = k_sib_children, 2 = k_sib_children2)", which);
+    e->net.sib_v2 = which == 2;
+    net_invalidate_sibling_cache(e->net); // (the two kernels read different base-slot layouts)
+    return OMOK_OK;
+}
+
 extern "C" int omok_get_stats(omok_engine* e, double* stats) {
     if (!e || !stats) return OMOK_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->cfg.device));
@@ -1385,6 +1393,8 @@ extern "C" int omok_get_stats(omok_engine* e, double* stats) {
     stats[OMOK_STAT_PROBE_DV_F16] = e->net.probe[4];
     stats[OMOK_STAT_PROBE_LIMIT] = NET_PROBE_LIMIT;
     stats[OMOK_STAT_PROBE_LOGIT_MAX] = e->net.probe[5];
+    stats[OMOK_STAT_CHILDREN2_LAUNCHES] = e->net.children_launches[0];
+    stats[OMOK_STAT_CHILDREN1_LAUNCHES] = e->net.children_launches[1];
     return OMOK_OK;
 }
 
@@ -1396,6 +1406,7 @@ extern "C" int omok_reset_stats(omok_engine* e) {
     e->prof.rounds_seen = e->prof.rounds_timed = 0;
     e->sims = e->evals = e->ply_games = e->finished = 0;
     e->peak_nodes = e->peak_tables = 0;
+    e->net.children_launches[0] = e->net.children_launches[1] = 0.0;
     hipMemset(e->d_evals, 0, 16);
     hipMemset(e->S.d_bytes, 0, 16);
     return OMOK_OK;

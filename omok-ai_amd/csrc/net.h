@@ -66,6 +66,7 @@ struct Net {
     void* d_comp = nullptr;          // the round's positions to evaluate in full: (request row of the first child, base slot)
     bool gcnt_zeroed = false;        // the engine's k_scan of this round has zeroed d_gcnt (launch_trunk_siblings then skips k_zero_ints)
     bool fill_in_group = false;      // ... and left the dense request list to k_group (launch_scan(fill = false))
+    double children_launches[2] = {0.0, 0.0}; // sibling rounds by children kernel: [0] k_sib_children2, [1] k_sib_children
     bool sib_v2 = true;              // difference path: k_sib_children2 (one wave per child, growing windows) and the base-slot layout it reads
     bool base_cache = true;          // false (omok_debug_set_base_cache): every run's base is evaluated in full every round (A-B check: same p / v bit for bit)
     bool sib_cache_valid = false;    // false: the trees changed outside the search rounds (reset, advance, refill): tags are cleared first
