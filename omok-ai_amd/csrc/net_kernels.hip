@@ -1671,7 +1671,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* wgrid = (float*)(smem + TR_WBYTES + TR_SIDE_FLOATS * 4) + wv * V2_WAVE_FLOATS; // this wave's cells
-    const int h = lane >> 5, l31 = lane & 31;
+    const int h = lane >> 5;
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
     for (int i = tid; i < TR_WBYTES / 16; i += blockDim.x) ((uint4*)smem)[i] = wt[i];
     for (int i = tid; i < TR_SIDE_FLOATS; i += blockDim.x) ((float*)lside)[i] = side[i];
