@@ -2402,8 +2402,8 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
         ubeg = split_y * per;
         ksup = nsup - ubeg < per ? nsup - ubeg : per;
         if (ksup < 0) ksup = 0;
-        win_oy = bin / SIB_ORG;
-        win_ox = bin % SIB_ORG;
+        win_oy = bin < SIB_BINS ? bin / SIB_ORG : 0; // (the single rows' bin has no window: its tiles run no super-step, and their prologue's prefetches
+        win_ox = bin < SIB_BINS ? bin % SIB_ORG : 0; //  must stay inside the matrix)
     } else {
         count = d_count[0];
         if (count > max_count) count = max_count;
@@ -2773,8 +2773,8 @@ __global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, co
         ubeg = split_y * per;
         ksup = nsup - ubeg < per ? nsup - ubeg : per;
         if (ksup < 0) ksup = 0;
-        win_oy = bin / SIB_ORG;
-        win_ox = bin % SIB_ORG;
+        win_oy = bin < SIB_BINS ? bin / SIB_ORG : 0; // (the single rows' bin has no window: its tiles run no super-step, and their prologue's prefetches
+        win_ox = bin < SIB_BINS ? bin % SIB_ORG : 0; //  must stay inside the matrix)
     } else {
         count = d_count[0];
         if (count > max_count) count = max_count;
