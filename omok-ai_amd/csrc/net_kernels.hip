@@ -1636,7 +1636,8 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
 // its linearity: d_child = d_base + dw(h_child - h_base), where the difference is non-zero only inside the 5x5 tile -- so the tile's LDS
 // grid is 25 cells without a halo, and the base pass stores its h AND d grids and its residual stream in front of block 2 (for the ring)
 // pixel-major in the piece order of the accumulators (sib2_grid, sib2_x2).  Results are within rounding of k_sib_children's (a different summation order in the
-// depthwise), not bit-identical: the difference path is tolerance-checked; the copy path (bit-identical rows) keeps k_sib_children.
+// depthwise) and need not be bit-identical -- on the rows the tests compare they are, every layer boundary re-quantising to ~22 bits -- so the difference path
+// is tolerance-checked; the copy path (rows bit-identical to a full evaluation by construction) keeps k_sib_children.
 constexpr int V2_TW = 5, V2_TPX = V2_TW * V2_TW;          // tile window side, pixels
 constexpr int V2_RING = SIB_WPX - V2_TPX;                 // 24
 constexpr int V2_ZERO_CELL = 32, V2_WORD_CELL = 33;       // cells 0..31: tile grid / staging rows
