@@ -54,7 +54,10 @@ def parse(argv=None):
     ap.add_argument("--max-plies", type=int, default=0, help="debug: stop every episode after this many plies")
     ap.add_argument("--max-nodes", type=int, default=0)
     ap.add_argument("--max-tables", type=int, default=0)
-    ap.add_argument("--net-mode", default="f16x3", choices=["f16x3", "f32"])
+    ap.add_argument("--net-mode", default="f16x3", choices=["f16x3", "fp6", "f16", "f32"],
+                    help="f16x3: split-operand MFMA, fc0's correction terms in the format omok_net_commit's probe keeps (the headline); fp6 / f16: that format forced "
+                         "(f16 meets north_star's 1e-3 on the LOGITS too); f32: the fp32 VALU kernels")
+    ap.add_argument("--f16-leg", type=int, default=1, help="extra leg: one more whole episode with fc0 forced into the f16 operand format -> value_f16_format (0 = skip)")
     ap.add_argument("--gather", action="store_true", help="RCCL all-gather-v of replay tuples at episode end")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=20, help="training steps timed after the episode (0 = skip; batch 128)")
@@ -122,6 +125,8 @@ def cpu_baseline(args, mean_plies, budget_s):
             p, v = net(torch.from_numpy(np.ascontiguousarray(x)).reshape(-1, n, n, 3))
         return p.numpy().reshape(len(x), hw), v.numpy().reshape(-1)
 
+    seen_rows = []  # request rows of the legs' real search rounds (for the oracle-vs-GPU check of the net outputs below)
+
     def leg(games, sims, threads, seconds, max_plies):
         torch.set_num_threads(threads)
         root_p, _ = forward(O.Environment(n).encode_nn_input(0)[None])
@@ -138,6 +143,8 @@ def cpu_baseline(args, mean_plies, budget_s):
                 inp = sp.round_generate(rnd, k, 0.25, 0.03)
                 n_sims += k * sp.alive_count
                 if len(inp):
+                    if games > 1 and sum(len(r) for r in seen_rows) < 16384:
+                        seen_rows.append(np.array(inp[:: max(1, len(inp) // 32)], dtype=np.float32))  # (a spread of every round's rows)
                     t1 = time.perf_counter()
                     p, v = forward(inp)
                     t_net += time.perf_counter() - t1
@@ -188,7 +195,22 @@ def cpu_baseline(args, mean_plies, budget_s):
     except OSError:
         pass
     rounds_up = (args.sims + k - 1) // k * k
-    return {"value": best["sims_per_s"] / (rounds_up * mean_plies), "unit": "games/s", "cores": best_t, "host_threads": cores, "kind": "port",
+    # The oracle's own net forward (oracle/net.c, fp32, the checker of the -m gpu parity tests) on 256 request rows of the rounds above: timed as a
+    # sample of the CPU path's net part, and its outputs handed back so that main() can state the GPU's |dp|, |dv| and |dlogit| against the ORACLE
+    net_check = None
+    if seen_rows:
+        allr = np.concatenate(seen_rows)
+        xr = np.ascontiguousarray(allr[:: max(1, len(allr) // 256)][:256])
+        onet = O.Net(n, tensors)
+        t1 = time.perf_counter()
+        po, vo, lgo, vpo = onet.forward_logits(xr, threads=best_t)
+        dt_o = time.perf_counter() - t1
+        net_check = {"x": xr, "p": po, "v": vo, "logits": lgo, "vpre": vpo, "seconds": dt_o, "threads": best_t}
+    return {"_net_check": net_check,
+            "oracle_net_forward": ({"rows": int(len(net_check["x"])), "seconds": net_check["seconds"], "rows_per_s": len(net_check["x"]) / net_check["seconds"],
+                                    "threads": best_t, "what": "oracle/net.c fp32 forward (plain loops, OpenMP over blocks of 8 rows) on request rows of the legs' search rounds"}
+                                   if net_check else None),
+            "value": best["sims_per_s"] / (rounds_up * mean_plies), "unit": "games/s", "cores": best_t, "host_threads": cores, "kind": "port",
             "thread_calibration_sims_per_s": {str(t): v for t, v in calib.items()},
             "sample": f"C2' = {g2} games x {rounds_up} sims/move x up to 5 plies (bounded to {share:.0f} s; {best['plies_completed']} plies completed) on {best_t} of {cores} threads (fastest of {cand}): oracle C tree "
                       f"code + torch-CPU fp32 forward (BLAS); {best['sims_per_s']:.0f} sims/s, converted with {mean_plies:.1f} plies/game "
@@ -282,7 +304,7 @@ def main():
     max_nodes = args.max_nodes or min(16384, 4 * args.sims + 1024)
     max_tables = args.max_tables or max(256, max_nodes // 4)
     eng = oa.Engine(board_size=n, games=games, max_nodes=max_nodes, max_tables=max_tables, max_batch_k=k,
-                    device=gpu, net_mode=B.NET_F16X3 if args.net_mode == "f16x3" else B.NET_F32,
+                    device=gpu, net_mode={"f16x3": B.NET_F16X3, "fp6": B.NET_F16X3_FP6, "f16": B.NET_F16X3_F16, "f32": B.NET_F32}[args.net_mode],
                     seed=args.seed, game_offset=oa.dist.game_offset(rank, games))
     eng.load_random_weights(0)
     sp = oa.SelfPlay(eng)
@@ -375,15 +397,34 @@ def main():
         # (k_sib_children2, the default: a base slot also holds the base's d grids and its residual stream in front of block 2 -- 1280 B per pixel instead of
         #  384 -- written with the base and read once per run by its children; OMOK_SIB_V2=0: k_sib_children, 3 h grids)
         slot_px = 1280.0 if st.get("children2_launches", 0.0) > 0 else 384.0
-        alg_row = {"k_trunk": 2 * drow + (miss * (2 * ppx * hw + slot_px * hw) + slot_px * hw) / run, "k_fc0_mx": drow + miss * ppx * hw / run + 2048}[kernel]
+        # Trunk group, per request row: the child's difference row written (drow); of its base it reads the 49 operand entries of its window (drow again), the h / d
+        # grids of blocks 1 and 2 and the d grid of block 0 on its 25-pixel tile (640 B per pixel), the d grid of block 2 and the residual stream in front of block 2 on the
+        # 24 ring pixels (640 B per pixel): 2 drow + 49 x 640 B = 69.0 KB in the fp6 format -- what the kernel moves when nothing is shared between siblings (`design`).
+        # A run's ~15 siblings have windows all over the board, so the least a run can read is its base slot once (1280 B per pixel + the operand row): that / run + drow
+        # = 43.8 KB per row (`alg_row`, the figure the roofline uses).  Both + the share of base passes (runs whose base is not cached).
+        base_pass = miss * (2 * ppx * hw + slot_px * hw) / run
+        design_row = {"k_trunk": 2 * drow + 49.0 * 640.0 + base_pass if slot_px > 384.0 else 2 * drow + 49.0 * 384.0 + base_pass, "k_fc0_mx": None}[kernel]
+        alg_row = {"k_trunk": drow + (slot_px * hw + ppx * hw) / run + base_pass, "k_fc0_mx": drow + miss * ppx * hw / run + 2048}[kernel]
+        if n != 15:  # (N = 9 rounds below the difference path's threshold and the f32 mode write / read whole operand rows)
+            design_row = None
         members = {"k_trunk": "k_sib_children2 (k_sib_children on the copy path) + k_trunk<BASE> + k_trunk<rows> + k_group + k_bin_prefix (search rounds); k_trunk otherwise",
                    "k_fc0_mx": "k_fc0_mx | k_fc0_x3 <full rows, split-K> + k_facc_reduce + <window tiles> + k_win_finish (search rounds on the difference path); dense k_fc0_mx | k_fc0_x3 (+ k_splitk_finish) otherwise"}[kernel]
-        return {"bound": "mfma", "kernel": kernel, "kernel_members": members, "achieved": ach, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / F16_DENSE_PEAK_TFLOPS, "traffic": per_row * rows / launches if per_row else None,
+        # which roof is lower for this kernel group: time per row at the MFMA peak vs time per row at the HBM peak for the bytes it has to move
+        alg_launch = alg_row * rows / launches + ({"k_trunk": 110e3, "k_fc0_mx": 128.0 * hw * 512 * 3}[kernel])
+        t_mfma, t_hbm = flop_row / (F16_DENSE_PEAK_TFLOPS * 1e12), alg_row / (HBM_PEAK_GBS * 1e9)
+        hbm_ach = alg_launch * launches / sec / 1e9 if sec > 0 else 0.0
+        sides = {"mfma": {"achieved": ach, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F16_DENSE_PEAK_TFLOPS, "ns_per_row_at_peak": 1e9 * t_mfma},
+                 "hbm": {"achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS, "ns_per_row_at_peak": 1e9 * t_hbm}}
+        bound = "hbm" if t_hbm > t_mfma else "mfma"
+        return {"bound": bound, "kernel": kernel, "kernel_members": members, "achieved": sides[bound]["achieved"], "peak": sides[bound]["peak"], "unit": sides[bound]["unit"],
+                "frac": sides[bound]["frac"], "both_roofs": sides,
+                "bound_rule": "the lower roof: algorithmic flops per row / 2500 TFLOP/s against algorithmic bytes per row / 8 TB/s; `achieved` = that quantity per launch / avg_launch_ms",
+                "design_bytes_per_launch": design_row * rows / launches if design_row else None,
+                "traffic": per_row * rows / launches if per_row else None,
                 "traffic_uncalibrated_x2": per_row_x2 * rows / launches if per_row_x2 else None,
                 "traffic_unit": "HBM bytes per (average) launch: per-row bytes of the committed rocprofv3 --pmc pass (profiles/pmc_bytes.json: "
                                 "FETCH_SIZE x 2 + WRITE_SIZE; fc0 calibrated for its 64-B residual requests, the flat x2 figure beside it) x rows per launch",
-                "algorithmic_bytes_per_launch": alg_row * rows / launches + ({"k_trunk": 110e3, "k_fc0_mx": 128.0 * hw * 512 * 3}[kernel]),
+                "algorithmic_bytes_per_launch": alg_launch,
                 "avg_launch_ms": k_ms[kernel] / launches, "rows_per_launch": rows / launches, "share_of_kernel_time": k_ms[kernel] / max(sum(k_ms.values()), 1e-9),
                 "mfma_busy_pmc": pmc.get(kernel + "_mfma_busy"), "valu_busy_pmc": pmc.get(kernel + "_valu_busy"), "lds_busy_pmc": pmc.get(kernel + "_lds_busy"),
                 "busy_pmc_unit": "fraction of the kernel group's cycles its SIMDs' matrix pipes / vector ALUs / the CUs' LDS were busy, from the committed "
@@ -396,8 +437,10 @@ def main():
                   "`--max-plies 4` gives the full-round figure that profiles/r03_rocprofv3_kernel_stats_c2_first4plies.csv sums to).  "
                   "ALGORITHMIC flops 2*MAC of a full evaluation (13.0 MFLOP/eval at N = 15) / HIP-event time on the engine's stream.  Every product "
                   "runs as 3 f16 MFMAs (split operands), and at N = 15 sibling requests share a base pass and recompute only a 5x5 / 7x7 window each, so "
-                  "the EXECUTED matrix work is ~0.2x the algorithmic figure: `achieved` counts useful work; the kernels' own utilisation (MFMA busy "
-                  "26 %, VALU 52 %) is in profiles/")
+                  "the EXECUTED matrix work is ~0.2x the algorithmic figure: the mfma side of `both_roofs` counts useful work; the group's own unit utilisation is in "
+                  "mfma_busy_pmc / valu_busy_pmc / lds_busy_pmc.  By arithmetic intensity (13.0 MFLOP over ~50 KB per row = 260 FLOP/B, under the 312 FLOP/B ridge) the HBM "
+                  "roof is the lower one; measured (profiles/r04_children_traffic_experiments.txt): with every base read an L2 hit the group is 13 % faster, with no stores 17 % -- "
+                  "the rest is the dependent instruction chain of two waves per SIMD")
     mix = ("Per K = 64 the kernel (k_fc0_mx) issues 4 f16 + 2 block-scaled fp6 MFMAs (split operands) = 1.5x the pipe time of a plain-f16 product (frac <= 0.67 for a dense fc0)"
            if int(st.get("fc0_format", 0)) == 0 else
            "f16 operand format (k_fc0_x3): 3 f16 MFMAs per product = 3x the pipe time of a plain-f16 product (frac <= 0.33 for a dense fc0)")
@@ -414,12 +457,12 @@ def main():
         "value": games_per_s, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": (f"f16 (split hi+lo MFMA operands: f16 main term + two correction terms, fp32 accumulate; fc0's correction terms in {fc0_fmt}, "
-                  "chosen by omok_net_commit's probe)") if args.net_mode == "f16x3" else "f32",
+                  + ("chosen by omok_net_commit's probe)" if args.net_mode == "f16x3" else "forced by --net-mode)")) if args.net_mode != "f32" else "f32",
         "fc0_format": {"in_use": fc0_fmt, "probe_rows": st.get("probe_rows"), "probe_limit": st.get("probe_limit"),
                        "fp6_max_dp_dv": [st.get("probe_dp_fp6"), st.get("probe_dv_fp6")], "f16_max_dp_dv": [st.get("probe_dp_f16"), st.get("probe_dv_f16")],
                        "probe_logit_abs_max": st.get("probe_logit_max"),
-                       "rule": "fp6 correction terms are kept while the probe's worst |dp| and |dv| against the fp32 kernels are <= probe_limit (half the 1e-3 "
-                               "contract); otherwise f16 correction terms (DESIGN 3.4)"} if args.net_mode == "f16x3" else None,
+                       "rule": "fp6 correction terms are kept while the probe's worst |dp| and |dv| against the fp32 kernels are <= probe_limit (0.3 of the 1e-3 "
+                               "contract); otherwise f16 correction terms (DESIGN 3.4)"} if args.net_mode != "f32" else None,
         "children_kernel_launches": {"k_sib_children2": st.get("children2_launches"), "k_sib_children": st.get("children1_launches"),
                                      "note": "sibling rounds of the timed region by the kernel that evaluated the runs' children: k_sib_children2 on the difference path "
                                              "(rounds of >= 3072 rows at N = 15, >= 1024 at N = 9), k_sib_children on the copy path (smaller rounds)"},
@@ -473,6 +516,37 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if use_cuda and world == 1 and complete and args.f16_leg and args.net_mode == "f16x3" and room(30 + 1.6 * dt / max(args.steps, 1)):
+        # north_star's sentence as written asks for LOGITS within 1e-3: the f16 operand format meets that too (`precision.vs_oracle` below), the format the
+        # probe keeps for this net (fp6) meets it on p and v.  One more whole episode of the same workload with fc0 forced into the f16 format:
+        try:
+            eng2 = oa.Engine(board_size=n, games=games, max_nodes=max_nodes, max_tables=max_tables, max_batch_k=k, device=gpu, net_mode=B.NET_F16X3_F16,
+                             seed=args.seed, game_offset=oa.dist.game_offset(rank, games))
+            eng2.load_random_weights(0)
+            sp2 = oa.SelfPlay(eng2)
+            sp2.reset()
+            sp2.run(args.sims, k, 0.25, 0.03, 1.0, 30, args.warmup_plies or 4)  # warm-up: an episode cut after a few plies
+            sp2.set_episode(1)
+            eng2.reset_stats()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sp2.reset()
+            sp2.run(args.sims, k, 0.25, 0.03, 1.0, 30, 0)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            st2 = eng2.stats()
+            out["value_f16_format"] = st2["finished"] / dt2
+            out["f16_format_leg"] = {"games_per_s": st2["finished"] / dt2, "seconds": dt2, "episodes": 1, "games_finished": st2["finished"],
+                                     "mcts_sims_per_s": st2["sims"] / dt2, "fc0_format": B.FC0_FORMATS[int(st2["fc0_format"])],
+                                     "ratio_to_value": st2["finished"] / dt2 / max(games_per_s, 1e-9),
+                                     "note": "extra leg outside the timed region: the same workload (one whole episode after a cut warm-up episode, its own engine) with "
+                                             "net mode OMOK_NET_F16X3_F16: fc0's correction terms on f16 operands (three f16 MFMAs per product), the mode that meets "
+                                             "north_star's 1e-3 on the pre-softmax logits as well as on p and v"}
+            eng2.close()
+            del sp2, eng2
+        except Exception as ex:
+            out["f16_format_leg"] = {"error": repr(ex)}
+        extras = True
     if use_cuda and world == 1 and complete:
         if args.precision_rows > 0 and room(25):
             try:
@@ -561,6 +635,28 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args, max(mean_plies, 1.0), share)
             except Exception as ex:  # (the GPU measurement above stands on its own)
                 out["cpu_baseline"] = {"error": repr(ex)}
+            chk = out["cpu_baseline"].pop("_net_check", None)
+            if chk is not None and use_cuda:
+                # the GPU's outputs against the ORACLE (not the GPU's own fp32 kernels) on those rows: the headline's net mode and the f16 format
+                try:
+                    vs = {"rows": int(len(chk["x"])), "reference": "oracle/net.c (fp32 restatement of network.rs, the checker of the -m gpu tests), rows of real search rounds"}
+                    for tag, mode in (("headline_mode", {"f16x3": B.NET_F16X3, "fp6": B.NET_F16X3_FP6, "f16": B.NET_F16X3_F16, "f32": B.NET_F32}[args.net_mode]),
+                                      ("f16_format", B.NET_F16X3_F16)):
+                        e3 = oa.Engine(board_size=n, games=64, max_nodes=8, max_tables=4, max_batch_k=k, device=gpu, net_mode=mode)
+                        e3.load_random_weights(0)
+                        pg, vg = e3.evaluate_pv(chk["x"])
+                        lg, vpg = e3.evaluate_logits(chk["x"])
+                        fmt3 = B.FC0_FORMATS[int(e3.stats()["fc0_format"])]
+                        e3.close()
+                        vs[tag] = {"fc0_format": fmt3, "max_dp": float(np.abs(pg.reshape(len(chk["x"]), -1) - chk["p"]).max()),
+                                   "max_dv": float(np.abs(vg.reshape(-1) - chk["v"]).max()),
+                                   "max_dlogit": float(np.abs(lg.reshape(len(chk["x"]), -1)[:, :hw] - chk["logits"]).max()),
+                                   "max_dvpre": float(np.abs(vpg.reshape(-1) - chk["vpre"]).max())}
+                    vs["logit_abs_max"] = float(np.abs(chk["logits"]).max())
+                    vs["north_star_logits_1e-3"] = {tag: bool(vs[tag]["max_dlogit"] < 1e-3 and vs[tag]["max_dvpre"] < 1e-3) for tag in ("headline_mode", "f16_format")}
+                    out.setdefault("precision", {})["vs_oracle"] = vs
+                except Exception as ex:
+                    out.setdefault("precision", {})["vs_oracle"] = {"error": repr(ex)}
         else:
             out["cpu_baseline"] = {"skipped": f"no room in the {args.budget_seconds:.0f} s budget ({elapsed():.0f} s used)"}
         extras = True

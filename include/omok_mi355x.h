@@ -40,7 +40,7 @@ extern "C" {
 #define OMOK_NET_F16X3 0 /* split-operand MFMA (x = hi + lo, hi = f16(x): f16 main term + two correction terms, fp32 accumulate).  The
                             correction terms of trunk, fc1 and heads are f16; those of fc0 (68 % of the flops) are block-scaled fp6 (products good to
                             ~2^-15) or f16 (~2^-22, ~2x the fc0 time): omok_net_commit evaluates a fixed probe set of 2048 positions in both
-                            formats and with the fp32 kernels and keeps fp6 only while its worst |dp|, |dv| stay within 5e-4 = half the
+                            formats and with the fp32 kernels and keeps fp6 only while its worst |dp|, |dv| stay within 3e-4 = 0.3 of the
                             1e-3 contract on AgentModel::evaluate_pv's outputs (OMOK_STAT_FC0_FORMAT / OMOK_STAT_PROBE_*) */
 #define OMOK_NET_F32 1   /* plain fp32 VALU kernels (debug / A-B reference on the GPU) */
 #define OMOK_NET_F16X3_ROWS 2 /* OMOK_NET_F16X3 with every request row evaluated on its own: at board_size 15 the search rounds of
@@ -274,7 +274,7 @@ int omok_debug_set_children_kernel(omok_engine* e, int32_t which);
 #define OMOK_STAT_PROBE_DV_FP6 19
 #define OMOK_STAT_PROBE_DP_F16 20 /* ... f16 correction terms */
 #define OMOK_STAT_PROBE_DV_F16 21
-#define OMOK_STAT_PROBE_LIMIT 22  /* fp6 is kept while both of its figures are <= this (5e-4) */
+#define OMOK_STAT_PROBE_LIMIT 22  /* fp6 is kept while both of its figures are <= this (3e-4) */
 #define OMOK_STAT_PROBE_LOGIT_MAX 23 /* largest |policy logit| of the probe rows (fp32 kernels) */
 #define OMOK_STAT_CHILDREN2_LAUNCHES 24 /* sibling rounds whose children ran on k_sib_children2 (difference path, default) ... */
 #define OMOK_STAT_CHILDREN1_LAUNCHES 25 /* ... on k_sib_children (copy path; difference path after omok_debug_set_children_kernel(1)) */

@@ -44,7 +44,10 @@ class Engine:
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:  # (at interpreter shutdown the module globals may already be gone: the process is ending, the driver frees the device memory)
+            self.close()
+        except Exception:
+            pass
 
     def _chk(self, rc):
         if rc < 0:

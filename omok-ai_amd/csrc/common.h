@@ -123,6 +123,8 @@ void launch_round_shared(int n, const Store& S, const RoundArgs& a, int rounds_t
 void launch_scatter_shared(int n, const Store& S, int side, const float* p_dev, const float* v_dev, int max_count, int waves, const uint16_t* sh_req,
                            const uint32_t* sh_cnt, hipStream_t st, uint8_t* rec_order = nullptr, uint32_t* rec_pos = nullptr);
 constexpr int MAX_TREE_WAVES = 16; // one workgroup of 1024 threads
+constexpr int MAX_GAMES = 32767;         // games per engine (omok_create)
+constexpr int SCAN_GAMES_PER_THREAD = 32; // k_scan: one workgroup of 1024 threads, each owning this many consecutive games
 // backups = false: the policies only; the backups (k_scatter) are deferred to launch_backups or into the next round's kernel (RoundArgs::scatter_v)
 void launch_scatter(int n, const Store& S, int side, const float* p_dev, const float* v_dev, int max_count, hipStream_t st, bool backups = true);
 void launch_backups(int n, const Store& S, int side, const float* v_dev, hipStream_t st);

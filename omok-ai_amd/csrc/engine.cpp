@@ -195,7 +195,7 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     *out = nullptr;
     if (cfg->board_size != 9 && cfg->board_size != 15)
         return fail(nullptr, OMOK_ERR_INVALID, "board_size must be 9 or 15 (got %d)", cfg->board_size);
-    if (cfg->games < 1 || cfg->games > 32767) return fail(nullptr, OMOK_ERR_INVALID, "games must be in [1, 32767]");
+    if (cfg->games < 1 || cfg->games > MAX_GAMES) return fail(nullptr, OMOK_ERR_INVALID, "games must be in [1, %d]", MAX_GAMES);
     if (cfg->max_nodes < 2 || cfg->max_nodes > OMOK_MAX_ARENA || cfg->max_tables < 1 || cfg->max_tables > OMOK_MAX_ARENA)
         return fail(nullptr, OMOK_ERR_INVALID, "max_nodes must be in [2, %d] and max_tables in [1, %d]", OMOK_MAX_ARENA, OMOK_MAX_ARENA);
     if (cfg->max_batch_k < 1 || cfg->max_batch_k > KMAX) return fail(nullptr, OMOK_ERR_INVALID, "max_batch_k must be in [1, 64]");
@@ -662,8 +662,9 @@ extern "C" int omok_execute_shared(omok_engine* e, int32_t count, int32_t batch_
     if (need_net(e) || need_reset(e)) return OMOK_ERR_STATE;
     if (check_exec_args(e, count, batch_size, epsilon, alpha)) return OMOK_ERR_INVALID;
     if (e->cfg.games != 1) return fail(e, OMOK_ERR_INVALID, "omok_execute_shared searches ONE tree: create the engine with games = 1 (got %d)", e->cfg.games);
-    if (waves < 1 || waves > MAX_TREE_WAVES || waves * batch_size > e->net.max_b)
-        return fail(e, OMOK_ERR_INVALID, "waves must be in [1, max_tree_waves = %d] (and waves * batch_size <= %d)", e->cfg.max_tree_waves, e->net.max_b);
+    if (waves < 1 || waves > MAX_TREE_WAVES || waves * batch_size > e->net.max_b) // (cfg.max_tree_waves sizes the net batch: it binds through max_b)
+        return fail(e, OMOK_ERR_INVALID, "waves must be in [1, %d] and waves * batch_size <= %d (the net batch, sized by max(games, max_tree_waves = %d) * max_batch_k)",
+                    MAX_TREE_WAVES, e->net.max_b, e->cfg.max_tree_waves);
     HIPCHK(e, hipSetDevice(e->cfg.device));
     uint32_t bits = 0, alive = 0;
     if (read_status(e, &bits, &alive)) return OMOK_ERR_HIP;
@@ -700,8 +701,9 @@ extern "C" int omok_execute_shared_recorded(omok_engine* e, int32_t count, int32
     if (need_net(e) || need_reset(e)) return OMOK_ERR_STATE;
     if (check_exec_args(e, count, batch_size, epsilon, alpha)) return OMOK_ERR_INVALID;
     if (e->cfg.games != 1) return fail(e, OMOK_ERR_INVALID, "omok_execute_shared_recorded searches ONE tree: create the engine with games = 1 (got %d)", e->cfg.games);
-    if (waves < 1 || waves > MAX_TREE_WAVES || waves * batch_size > e->net.max_b)
-        return fail(e, OMOK_ERR_INVALID, "waves must be in [1, max_tree_waves = %d] (and waves * batch_size <= %d)", e->cfg.max_tree_waves, e->net.max_b);
+    if (waves < 1 || waves > MAX_TREE_WAVES || waves * batch_size > e->net.max_b) // (cfg.max_tree_waves sizes the net batch: it binds through max_b)
+        return fail(e, OMOK_ERR_INVALID, "waves must be in [1, %d] and waves * batch_size <= %d (the net batch, sized by max(games, max_tree_waves = %d) * max_batch_k)",
+                    MAX_TREE_WAVES, e->net.max_b, e->cfg.max_tree_waves);
     ENTER(e);
     const size_t per = (size_t)waves * batch_size;
     uint8_t* d_rec = nullptr;   // [2][per] wave ids: simulations, backups

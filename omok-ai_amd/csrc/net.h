@@ -10,7 +10,9 @@ constexpr int NC = 128; // RESIDUAL_CHANNELS (alpha-zero/src/network.rs:24)
 constexpr int NM = 32;  // RESIDUAL_MIDDLE_CHANNELS (:25)
 constexpr int NF = 512; // FC_0_SIZE / FC_1_SIZE (:29-30)
 enum { FC0_AUTO = -1, FC0_FP6 = 0, FC0_F16 = 1 };
-constexpr float NET_PROBE_LIMIT = 5e-4f; // fp6 correction terms are kept only while the probe's worst |dp|, |dv| stay below this (2x margin to the 1e-3 contract)
+// fp6 correction terms are kept only while the probe's worst |dp|, |dv| stay below this.  Round 4: 3e-4 (was 5e-4): held-out positions exceeded the probe's figure by up to 1.7x
+// (profiles/r03_precision_sweep.log) and the difference path of the search rounds adds up to 3e-4 against row-by-row evaluation, so 3e-4 x 1.7 + 3e-4 stays inside the 1e-3 contract
+constexpr float NET_PROBE_LIMIT = 3e-4f;
 constexpr int NET_PROBE_ROWS = 2048;
 
 struct Net {
@@ -78,7 +80,7 @@ struct Net {
     // fc0 operand format: the correction terms hi*lo + lo*hi of fc0 run either on block-scaled fp6 operands (FC0_FP6: 4
     // significant bits, products good to ~2^-15) or on f16 operands (FC0_F16: three f16 MFMAs per product, ~2^-22).  net_commit packs the
     // weights for both and, with fc0_policy = FC0_AUTO, measures both against the fp32 kernels on a fixed probe set and keeps the
-    // faster one (fp6) only if its worst |dp|, |dv| stay within NET_PROBE_LIMIT (half the 1e-3 contract).
+    // faster one (fp6) only if its worst |dp|, |dv| stay within NET_PROBE_LIMIT (3e-4 against the 1e-3 contract).
     int fc0_policy = FC0_AUTO; // FC0_AUTO / FC0_FP6 / FC0_F16 (forced)
     int fc0_fmt = 0;          // format in use: FC0_FP6 or FC0_F16
     void* wt_fc0x = nullptr;  // fc0 weights for FC0_F16: [half-step][stage g][m-tile i][hi s0, hi s1, lo s0, lo s1][lane][8] f16

@@ -1638,6 +1638,14 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
 // pixel-major in the piece order of the accumulators (sib2_grid, sib2_x2).  Results are within rounding of k_sib_children's (a different summation order in the
 // depthwise) and need not be bit-identical -- on the rows the tests compare they are, every layer boundary re-quantising to ~22 bits -- so the difference path
 // is tolerance-checked; the copy path (rows bit-identical to a full evaluation by construction) keeps k_sib_children.
+#ifndef SIB2_EXP
+#define SIB2_EXP 0 // A-B builds (tools/build_variant.sh): 1 = every child reads base slot 0 (timing only), 3 = a workgroup barrier per pass, 6 = per 4 passes, 4 = plain stores, 7 = no stores (timing only), 8 = contiguous shares per wave (round 3)
+#endif
+#if SIB2_EXP == 4
+#define ROW_STORE(V, P) (*(P) = (V))
+#else
+#define ROW_STORE(V, P) nt_store((V), (P))
+#endif
 constexpr int V2_TW = 5, V2_TPX = V2_TW * V2_TW;          // tile window side, pixels
 constexpr int V2_RING = SIB_WPX - V2_TPX;                 // 24
 constexpr int V2_ZERO_CELL = 32, V2_WORD_CELL = 33;       // cells 0..31: tile grid / staging rows
@@ -1680,6 +1688,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
     __syncthreads(); // (the only workgroup barrier: from here on a wave touches read-only LDS and its own cells)
     for (int i = 0; i < (wv >> 2); ++i) __builtin_amdgcn_s_sleep(120); // the two waves of a SIMD (w, w + 4) start about half a pass apart
     const int nsib = d_cnt[2];
+    const bool st_on = SIB2_EXP != 7 || nsib < 0; // (timing experiment 7: no difference-row stores; a run-time condition, so that nothing is dead code)
     const half8* convW = (const half8*)(wt + TR_WBYTES / 16);
     half8 cwh[4], cwl[4]; // conv_in fragments: fetched again at the end of every pass (see k_sib_children)
     auto load_conv_w = [&]() {
@@ -1814,7 +1823,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
                     for (int i = 0; i < 4; ++i) {
                         const uint4 v = *(const uint4*)(wgrid + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
                         if (i == 3) WAVE_LDS_FENCE();
-                        if (rd_ok[i]) nt_store(v, &row[part * SIB_DLO_U4 + (q * SIB_WPX + rd_px[i]) * 8 + (lane & 7)]);
+                        if (rd_ok[i] && st_on) ROW_STORE(v, &row[part * SIB_DLO_U4 + (q * SIB_WPX + rd_px[i]) * 8 + (lane & 7)]);
                     }
                 }
             }
@@ -1857,7 +1866,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint4 v = *(const uint4*)(wgrid + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
-                if (rd_ok[i]) nt_store(v, &row[(q * SIB_WPX + rd_px[i]) * 8 + (lane & 7)]);
+                if (rd_ok[i] && st_on) ROW_STORE(v, &row[(q * SIB_WPX + rd_px[i]) * 8 + (lane & 7)]);
             }
             WAVE_LDS_FENCE();
         }
@@ -1874,7 +1883,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
         for (int i = 0; i < 4; ++i) {
             const uint4 v = *(const uint4*)(wgrid + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
             const int q = (lane >> 2) & 1;
-            if (rd_ok[i]) nt_store(v, &row[SIB_DLO_U4 + (q * SIB_WPX + rd_px[i]) * 4 + (lane & 3)]);
+            if (rd_ok[i] && st_on) ROW_STORE(v, &row[SIB_DLO_U4 + (q * SIB_WPX + rd_px[i]) * 4 + (lane & 3)]);
         }
         WAVE_LDS_FENCE();
     };
@@ -1959,17 +1968,29 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
     const int wg_begin = (int)blockIdx.x * per_wg < nsib ? (int)blockIdx.x * per_wg : nsib, wg_end = wg_begin + per_wg < nsib ? wg_begin + per_wg : nsib;
     // (equal shares: the in-kernel counters show waves 4..7 18 % slower per child than the four launched first, but shares of 134 .. 146 / 1024 for waves 0..3
     //  measured the same as 128: A-B builds, 144.7 - 148.8 ms of trunk kernels per three plies with no order in them)
+#if SIB2_EXP != 8
+    // the 8 waves take consecutive entries: a run's ~15 siblings are in flight together on ONE CU, and what one wave pulled into this XCD's L2 the others find there
+    // (FETCH_SIZE per launch -30 % against contiguous shares per wave, same time: profiles/r04_children_traffic_experiments.txt)
+    constexpr int ESTR = 8;
+    const int e_begin = wg_begin + wv, e_end = wg_end;
+#else
+    constexpr int ESTR = 1;
     const int e_begin = wg_begin + (int)(((long long)(wg_end - wg_begin) * wv) >> 3), e_end = wg_begin + (int)(((long long)(wg_end - wg_begin) * (wv + 1)) >> 3);
-    auto entry_of = [&](int e0) { return e0 < e_end ? e0 : (e_begin < nsib ? e_begin : 0); };
+#endif
+    auto entry_of = [&](int e0) { return e0 < e_end ? e0 : (e_begin < e_end ? e_begin : 0); };
     auto fetch_word = [&](const uint4& ent) {
         uint64_t word = 0ULL;
         if (lane < 2 * NW) word = board[(size_t)ent.z * (2 * NW) + lane];
         return word;
     };
-    uint4 ent_c = sib_rows[entry_of(e_begin)], ent_n = sib_rows[entry_of(e_begin + 1)];
-    uint32_t slot_c = sib_slot[entry_of(e_begin)], slot_n = sib_slot[entry_of(e_begin + 1)];
+    uint4 ent_c = sib_rows[entry_of(e_begin)], ent_n = sib_rows[entry_of(e_begin + ESTR)];
+    uint32_t slot_c = sib_slot[entry_of(e_begin)], slot_n = sib_slot[entry_of(e_begin + ESTR)];
     uint64_t word_c = fetch_word(ent_c);
-    for (int e0 = e_begin; e0 < e_end; ++e0) {
+    for (int e0 = e_begin; e0 < e_end; e0 += ESTR) {
+#if SIB2_EXP == 3 || SIB2_EXP == 6
+        // (experiment: the waves of the workgroup stay on the same entries by a barrier per pass / per 4 passes; a wave that has left the loop has ended and no longer counts)
+        if (SIB2_EXP == 3 || (((e0 - e_begin) >> 3) & 3) == 0) __builtin_amdgcn_s_barrier();
+#endif
         if (TPROF) tp_last = __builtin_readcyclecounter();
         // lane "constants" (tile pixel (ty, tx) of the 5x5 window, ring index, depthwise strip item) are derived again in every phase from an opaque
         // copy of the lane index (OL): hoisted out of the loop or to the top of the pass, they and the addresses built on them were spilled to scratch
@@ -2010,13 +2031,13 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
 
         const int slot = bin_start[slot_c >> 24] + (int)(slot_c & 0xFFFFFFu);
         uint4* crow_p = d_rows + (size_t)slot * DROW_U4;
-        const uint4* sb = sib2 + (size_t)ent.y * SLOT_U4;
-        const uint4* frow = a_out + (size_t)ent.y * row_u4;
+        const uint4* sb = sib2 + (size_t)(SIB2_EXP == 1 ? 0u : ent.y) * SLOT_U4; // (timing experiment 1: every child reads base slot 0 -- all hits)
+        const uint4* frow = a_out + (size_t)(SIB2_EXP == 1 ? 0u : ent.y) * row_u4;
         uint64_t* cw = (uint64_t*)(wgrid + V2_WORD_CELL * GRID_STRIDE);
         if (lane < 2 * NW) cw[lane] = word_c;
         const uint64_t word_n = fetch_word(ent_n);
-        const uint4 ent_nn = sib_rows[entry_of(e0 + 2)];
-        const uint32_t slot_nn = sib_slot[entry_of(e0 + 2)];
+        const uint4 ent_nn = sib_rows[entry_of(e0 + 2 * ESTR)];
+        const uint32_t slot_nn = sib_slot[entry_of(e0 + 2 * ESTR)];
         WAVE_LDS_FENCE();
         uint32_t bits[3];
         input_bits(cw, turn, bpxA, bits);
@@ -2268,6 +2289,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
 }
 
 #undef OL
+#undef ROW_STORE
 #undef TILE_A
 #undef RING_B
 // ===============================================================================================
@@ -3839,15 +3861,27 @@ static int chunk_env() {
     static const int chunk_max = getenv("OMOK_NET_CHUNK") ? atoi(getenv("OMOK_NET_CHUNK")) : NET_CHUNK_DEFAULT;
     return chunk_max;
 }
-bool net_round_takes_sibling_path(const Net& net, int max_count) { // (what forward_chunked + forward_f16x3 decide for a round's requests)
+// THE decision whether a forward of request rows groups them by parent (launch_trunk_siblings): forward_f16x3 takes it from here, and so does the engine's
+// prediction of it (net_round_takes_sibling_path), on which it hands the request-list fill and the zeroing of d_gcnt to that path
+static bool sibling_path(const Net& net, bool from_f32, int sib_side) { return !from_f32 && sib_side >= 0 && sib_env() && net.siblings && net.d_groups; }
+bool net_round_takes_sibling_path(const Net& net, int max_count) { // (forward_chunked: a chunked forward passes no sibling side)
     if (net.mode == OMOK_NET_F32 || max_count <= 0) return false;
     if (chunk_env() > 0 && max_count > chunk_env()) return false;
-    return sib_env() && net.siblings && net.d_groups;
+    return sibling_path(net, false, 0);
+}
+// The engine skipped k_fill / the zeroing of d_gcnt for this round (Net::fill_in_group, Net::gcnt_zeroed) because it expected the sibling path: a forward that
+// does not take it would read a request list nobody wrote.  Never silently: this is a programming error between engine.cpp and this file.
+static void require_no_handed_over_fill(const Net& net, const char* where) {
+    if (net.fill_in_group) {
+        fprintf(stderr, "omok_mi355x: internal error: the round's request-list fill was handed to the sibling path, but the forward (%s) does not take it\n", where);
+        abort();
+    }
 }
 static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32, hipStream_t st, Prof* prof, int sib_side = -1, bool skip_softmax = false) {
     const int hw = net.hw;
     const int use_sib = sib_env();
-    const bool sib = !from_f32 && sib_side >= 0 && use_sib && net.siblings && net.d_groups;
+    const bool sib = sibling_path(net, from_f32, sib_side);
+    if (!sib) require_no_handed_over_fill(net, "forward_f16x3 on plain rows");
     // Small rounds (the thin tail of an episode) take the copy path: the difference path needs one fc0 tile per non-empty window bin
     // (81 + 1) however few rows there are, the copy path rows / 128 tiles of the full K -- measured break-even between 2048 and 4096 rows.  The choice is a
     // function of the host's bound on the request count (alive games x K) only, so a run is reproducible.
@@ -4095,6 +4129,7 @@ void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t s
     if (max_count <= 0) return;
     if (max_count > net.max_b) max_count = net.max_b;
     if (net.mode == OMOK_NET_F32) {
+        require_no_handed_over_fill(net, "fp32 kernels");
         launch_encode_requests(net.n, S, net.in_f32, max_count, st);
         forward_f32(net, S, max_count, st, prof);
     } else {

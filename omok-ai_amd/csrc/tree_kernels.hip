@@ -838,14 +838,15 @@ __global__ __launch_bounds__(1024) void k_scan(Store S, int side, unsigned long 
     // games, chunk sums are scanned with wave shuffles (64 lanes) and a 16-entry LDS table
     __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = (S.games + 1023) / 1024; // <= 32 (games <= 32767)
+    static_assert(MAX_GAMES <= SCAN_GAMES_PER_THREAD * 1024, "k_scan covers 1024 threads x SCAN_GAMES_PER_THREAD games");
+    const int chunk = (S.games + 1023) / 1024; // <= SCAN_GAMES_PER_THREAD (omok_create: games <= MAX_GAMES)
     const int g0 = tid * chunk;
     uint32_t local = 0;
     // (both loads of every game issued unconditionally and kept: `alive` then `n_req` as two dependent round trips per game and a second
     //  pass over the same pairs cost 60 us at 16384 games)
-    uint32_t cnt[32];
+    uint32_t cnt[SCAN_GAMES_PER_THREAD];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
+    for (int i = 0; i < SCAN_GAMES_PER_THREAD; ++i) {
         const int g = g0 + i;
         const bool in = i < chunk && g < S.games;
         const uint32_t alive = in ? (uint32_t)S.gs[in ? g : 0].alive : 0u;
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(1024) void k_scan(Store S, int side, unsigned long 
     }
     uint32_t run = wbase + incl - local;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
+    for (int i = 0; i < SCAN_GAMES_PER_THREAD; ++i) {
         if (cnt[i] != 0xFFFFFFFFu) {
             S.ts[side * S.games + g0 + i].req_base = run;
             run += cnt[i];

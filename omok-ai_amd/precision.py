@@ -2,10 +2,12 @@
 given set of weights and input rows.  The contract (BASELINE.json north_star) is 1e-3 on the outputs of AgentModel::evaluate_pv
 (alpha-zero/src/agent_model.rs:116-134): p after softmax, v after tanh.
 
-The engine keeps the contract BY ITSELF: `omok_net_commit` measures fc0's fast operand format (block-scaled fp6 correction terms,
-products good to ~2^-15) on a fixed probe set against the fp32 kernels and falls back to f16 correction terms (~2^-22, ~1.5x the fc0
-time) when its worst |dp| or |dv| exceeds 5e-4 (`Engine.stats()`: fc0_format, probe_*).  The functions below are the
-independent check of that choice on rows of the caller's choosing: tests, bench.py and `Trainer` use them.
+`omok_net_commit` measures fc0's fast operand format (block-scaled fp6 correction terms, products good to ~2^-15) on a fixed probe
+set against the fp32 kernels and falls back to f16 correction terms (~2^-22, ~1.5x the fc0 time) when its worst |dp| or |dv| exceeds
+3e-4 (`Engine.stats()`: fc0_format, probe_*).  The probe is a measurement on 2048 synthetic positions through the plain-row
+path, not a proof: held-out positions have exceeded its figure by up to 1.7x and the search rounds' difference path adds up to 3e-4
+(which is what the 3e-4 limit is sized for).  The functions below are the independent check on rows of the caller's choosing: tests,
+bench.py and `Trainer` (on by default) use them.
 
 At board_size 15 the SEARCH ROUNDS take a different path through the first two stages of the net (sibling requests = one base row
 + 7x7-window difference rows) than `omok_evaluate_pv`; `measure_search_rounds` checks that path on the request rows of

@@ -34,13 +34,14 @@ class Parameters:  # src/config.rs:83-110
 
 
 class Trainer:
-    def __init__(self, params=None, board_size=15, seed=0, save_dir="saves", max_nodes=None, max_tables=None, precision_rows=0):
+    def __init__(self, params=None, board_size=15, seed=0, save_dir="saves", max_nodes=None, max_tables=None, precision_rows=256, precision_search_rounds=True):
         self.p = params or Parameters()
         self.n = board_size
         self.rank, self.local_rank, self.world = dist.shard_info()
         self.device = f"cuda:{self.local_rank}"
         self.save_dir = save_dir
-        self.precision_rows = precision_rows
+        self.precision_rows = precision_rows  # independent check of the net outputs after every weight update (0 = off)
+        self.precision_search_rounds = precision_search_rounds  # ... and of the search rounds' own path (sibling base + difference rows)
         self.last_precision = None
         sims = -(-self.p.evaluate_count // self.p.evaluate_batch_size) * self.p.evaluate_batch_size
         max_nodes = max_nodes or min(16384, 4 * sims + 1024)
@@ -89,12 +90,12 @@ class Trainer:
             v_loss, p_loss, loss = self.phase.run(records, p.parameter_update_count, p.parameter_update_batch_size,
                                                   seed=self.iteration * 7919 + self.rank)
             self.phase.push_to(self.engine)
-            # new weights -> omok_net_commit -> the engine re-measured fc0's operand format on its probe set: the 1e-3
-            # contract holds by construction; the probe's figures are kept for the log
+            # new weights -> omok_net_commit -> the engine re-measured fc0's operand format on its probe set; the probe's
+            # figures are kept for the log, and the outputs are checked independently below (a probe is a measurement, not a proof)
             st = self.engine.stats()
             self.last_precision = {"fc0_format": api.B.FC0_FORMATS[int(st["fc0_format"])], "probe_rows": int(st["probe_rows"]),
                                    "probe_fp6": (st["probe_dp_fp6"], st["probe_dv_fp6"]), "probe_f16": (st["probe_dp_f16"], st["probe_dv_f16"])}
-            if self.precision_rows > 0:  # optional independent check on rows of this iteration's replay buffer (spread over the buffer)
+            if self.precision_rows > 0:  # independent check on rows of this iteration's replay buffer (spread over the buffer); on by default
                 from . import precision
                 idx = torch.linspace(0, records.shape[0] - 1, min(self.precision_rows, records.shape[0]), device=records.device).long()
                 x, _, _ = T.decode_records(records[idx], self.n)
@@ -104,6 +105,14 @@ class Trainer:
                 if not chk["within_contract"]:
                     log(f"[iter={self.iteration}] WARNING: net outputs differ from the fp32 kernels by |dp| {chk['max_dp']:.2e} |dv| {chk['max_dv']:.2e} "
                         f"(contract 1e-3) in format {chk['fc0_format']}")
+                if self.precision_search_rounds:  # the path the search rounds take (base row + 7x7-window difference rows), on rounds of the new net
+                    games = max(64, -(-3072 // p.evaluate_batch_size)) if self.n == 15 else 128  # (enough rows per round for the difference path)
+                    sr = precision.measure_search_rounds(self.phase.net.tensors(), self.n, games=games, batch_k=p.evaluate_batch_size, rounds=2, plies=1,
+                                                         device=self.local_rank, seed=self.iteration)
+                    self.last_precision["search_rounds"] = sr
+                    if not sr["within_contract"]:
+                        log(f"[iter={self.iteration}] WARNING: search-round outputs differ from the fp32 kernels by |dp| {sr['max_dp']:.2e} |dv| {sr['max_dv']:.2e} "
+                            f"(contract 1e-3) on {sr['rows']} rows")
             if self.rank == 0:  # Trainer::save (:605-626)
                 os.makedirs(self.save_dir, exist_ok=True)
                 final = os.path.join(self.save_dir, p.model_name)  # counter first, then the weights, each by rename: a crash in between

@@ -135,7 +135,8 @@ static void trunk(const orc_net* net, const float* in, float* x, float* h, float
 
 #define SB 8 /* samples per weight pass */
 
-void orc_net_forward(const orc_net* net, const float* in, int B, float* p, float* v, int threads) {
+/* lg / vpre (optional): the policy head's output in front of the softmax (network.rs:227-247) and the value head's in front of tanh */
+static void forward_impl(const orc_net* net, const float* in, int B, float* p, float* v, float* lg, float* vpre, int threads) {
     const int hw = net->hw;
     const int64_t K0 = (int64_t)C * hw;
     if (threads < 1) threads = 1;
@@ -181,6 +182,7 @@ void orc_net_forward(const orc_net* net, const float* in, int B, float* p, float
             float vv = 0.0f;
             for (int k = 0; k < F; ++k) vv += a1[k] * net->t[27][k];
             v[s0 + s] = tanhf(vv + net->t[28][0]);
+            if (vpre) vpre[s0 + s] = vv + net->t[28][0];
             float logits[ORC_MAX_HW];
             for (int o = 0; o < hw; ++o) logits[o] = 0.0f;
             for (int k = 0; k < F; ++k) {
@@ -190,6 +192,7 @@ void orc_net_forward(const orc_net* net, const float* in, int B, float* p, float
             }
             float mx = -INFINITY;
             for (int o = 0; o < hw; ++o) { logits[o] += net->t[30][o]; if (logits[o] > mx) mx = logits[o]; }
+            if (lg) for (int o = 0; o < hw; ++o) lg[(size_t)(s0 + s) * (size_t)hw + o] = logits[o];
             float sum = 0.0f;
             float* po = p + (size_t)(s0 + s) * (size_t)hw;
             for (int o = 0; o < hw; ++o) { po[o] = expf(logits[o] - mx); sum += po[o]; }
@@ -197,4 +200,9 @@ void orc_net_forward(const orc_net* net, const float* in, int B, float* p, float
         }
         free(x); free(h); free(h0);
     }
+}
+
+void orc_net_forward(const orc_net* net, const float* in, int B, float* p, float* v, int threads) { forward_impl(net, in, B, p, v, NULL, NULL, threads); }
+void orc_net_forward_logits(const orc_net* net, const float* in, int B, float* p, float* v, float* logits, float* vpre, int threads) {
+    forward_impl(net, in, B, p, v, logits, vpre, threads);
 }

@@ -83,6 +83,8 @@ int64_t orc_net_tensor_size(const orc_net* net, int idx);
 int orc_net_load(orc_net* net, int idx, const float* data, int64_t count);
 /* in: [B][3*HW] (encoder.rs layout), p: [B][HW] softmax probabilities, v: [B] tanh */
 void orc_net_forward(const orc_net* net, const float* in, int B, float* p, float* v, int threads);
+/* the same forward, also returning logits [B][hw] (in front of the softmax) and vpre [B] (in front of tanh) */
+void orc_net_forward_logits(const orc_net* net, const float* in, int B, float* p, float* v, float* logits, float* vpre, int threads);
 
 /* ---- self-play state: G games x two trees (src/trainer.rs:81-94) ---- */
 typedef struct orc_sp orc_sp;

@@ -66,6 +66,7 @@ def lib():
     L.orc_net_load.argtypes = [C.c_void_p, C.c_int, fp, C.c_int64]
     L.orc_net_load.restype = C.c_int
     L.orc_net_forward.argtypes = [C.c_void_p, fp, C.c_int, fp, fp, C.c_int]
+    L.orc_net_forward_logits.argtypes = [C.c_void_p, fp, C.c_int, fp, fp, fp, fp, C.c_int]
     L.orc_sp_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64]
     L.orc_sp_create.restype = C.c_void_p
     L.orc_sp_destroy.argtypes = [C.c_void_p]
@@ -195,6 +196,17 @@ class Net:
         v = np.zeros(b, dtype=np.float32)
         lib().orc_net_forward(self.h, _fp(inputs), b, _fp(p), _fp(v), threads)
         return p, v
+
+    def forward_logits(self, inputs, threads=1):
+        """(p, v, logits in front of the softmax, value in front of tanh)"""
+        inputs = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 3 * self.n * self.n)
+        b = inputs.shape[0]
+        p = np.zeros((b, self.n * self.n), dtype=np.float32)
+        lg = np.zeros((b, self.n * self.n), dtype=np.float32)
+        v = np.zeros(b, dtype=np.float32)
+        vp = np.zeros(b, dtype=np.float32)
+        lib().orc_net_forward_logits(self.h, _fp(inputs), b, _fp(p), _fp(v), _fp(lg), _fp(vp), threads)
+        return p, v, lg, vp
 
     def __del__(self):
         if getattr(self, "h", None):

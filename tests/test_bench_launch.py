@@ -38,6 +38,21 @@ def test_bench_self_launches_two_ranks_and_gathers_exact_counts(tmp_path):
     assert g["bytes_per_episode"] == 18 * (228 + 900 + 4)
 
 
+def test_bench_self_launches_eight_ranks(tmp_path):
+    """the driver's N = 8 command line (`python bench.py --gpus 8 ...`) end to end on the CPU: eight ranks, eight shards, the replay gather
+    with eight uneven counts, one result line for the whole job"""
+    r = _run(["--gpus", "8", "--steps", "1", "--warmup", "1", "--games", "4", "--gather", "--cpu-seconds", "0"], tmp_path, {"OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["games_finished"] == 8 * 4
+    assert out["config"]["parallelism"].startswith("games sharded x8")
+    ranks = [json.load(open(tmp_path / f"rank{i}.json")) for i in range(8)]
+    assert [x["game_offset"] for x in ranks] == [4 * i for i in range(8)] and all(x["world"] == "8" for x in ranks)
+    g = out["replay_gather"]
+    assert g["last_counts"] == [4 * (i + 1) for i in range(8)]
+    assert g["last_ids"] == [4 * rk + i % 4 for rk in range(8) for i in range(4 * (rk + 1))]  # rank order = global game order
+
+
 def test_bench_says_so_when_the_gpus_are_not_there(tmp_path):
     r = _run(["--gpus", "4"], tmp_path, {"OMOK_BENCH_BACKEND": "nccl"})  # nccl = count real devices: none in this container
     import torch

@@ -1,7 +1,7 @@
 """GPU tests of fc0's operand format: the 1e-3 contract of BASELINE.json's north_star ("policy/value within 1e-3 of the
 reference CPU path") must hold BY DEFAULT -- on random-init, scaled, heavy-tailed and TRAINED weights, for both board sizes -- because
 omok_net_commit measures the fast format (block-scaled fp6 correction terms) on a probe set and falls back to f16 correction terms
-when its worst |dp|, |dv| exceed 5e-4.  The checker is the oracle's fp32 forward (oracle/net.c); the OMOK_NET_F32 kernels are a second
+when its worst |dp|, |dv| exceed 3e-4.  The checker is the oracle's fp32 forward (oracle/net.c); the OMOK_NET_F32 kernels are a second
 reference.  Contract quantities: p after softmax, v after tanh (AgentModel::evaluate_pv, alpha-zero/src/agent_model.rs:116-134); the
 pre-softmax logits / pre-tanh value are reported beside them."""
 import os
@@ -16,7 +16,7 @@ from helpers import random_positions, trained_tensors
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-LIMIT = 5e-4  # NET_PROBE_LIMIT
+LIMIT = 3e-4  # NET_PROBE_LIMIT
 
 
 def _report(n, tensors, x, tag, mode=B.NET_F16X3, via_file=None):
@@ -53,7 +53,7 @@ def _assert_probe_rule(r):
     rows, dp6, dv6, dp16, dv16 = r["probe"]
     assert rows >= 512
     assert r["format"] == ("fp6" if (dp6 <= LIMIT and dv6 <= LIMIT) else "f16"), r
-    if r["format"] == "fp6":  # what was kept has the 2x margin on the probe set
+    if r["format"] == "fp6":  # what was kept has the 3.3x margin on the probe set
         assert dp6 <= LIMIT and dv6 <= LIMIT
     assert dp16 < LIMIT and dv16 < LIMIT, r  # the fallback itself is well inside
 

@@ -216,3 +216,79 @@ def test_both_children_kernels_of_the_difference_path_agree(n, games, k, mode):
         for p, v in ((pa, va), (pb, vb)):
             assert np.abs(p[pick] - pc).max() < TOL and np.abs(v[pick] - vc).max() < TOL
     print(f"children kernels 2 vs 1, n={n} mode {mode}: {differing} rows differ in bits")
+
+
+def test_execute_equals_stepwise_on_the_difference_path_with_deep_trees():
+    """(a) x the difference path: N = 15, 256 games (4096-row rounds >= 3072: sibling base + window differences, base cache, slots
+    handed out by atomics) x 800 simulations x 2 plies in the DEFAULT net mode: omok_execute (fused softmax + scatter, deferred backups, k_scan zeroing the
+    grouping counters, k_group writing the request list) leaves the trees the step-wise rounds leave, bit for bit, and a second run of omok_execute leaves them
+    again.  Compared: root visit policies and sampled moves of ALL games after every ply, full canonical dumps of 16 trees (first and last games)."""
+    n, games, count, k = 15, 256, 800, 16
+    tensors = oa.weights.init_random(n, seed=0)
+    picked = list(range(4)) + list(range(games - 4, games))
+
+    def play(variant):
+        eng = oa.Engine(board_size=n, games=games, max_nodes=4224, max_tables=1056, max_batch_k=k, seed=17)
+        eng.load_weights(tensors)
+        sp = oa.SelfPlay(eng)
+        sp.reset()
+        per_ply = []
+        for _ in range(2):
+            if variant == "stepwise":
+                for rnd in range(count // k):
+                    assert sp.round_generate(rnd, k) >= 3072
+                    sp.round_eval()
+                    sp.round_scatter()
+            else:
+                sp.execute(count, k)
+            pol = sp.compute_policy()[0].copy()
+            dumps = [sp.tree_dump(g, s) for g in picked for s in (0, 1)]
+            acts = np.array(sp.sample_actions(1.0, 30)).copy()
+            if variant == "stepwise":
+                sp.mirror_generate()
+                sp.mirror_eval()
+                sp.mirror_apply()
+            else:
+                sp.advance()
+            per_ply.append((pol, acts, dumps))
+        st = eng.stats()
+        eng.close()
+        return per_ply, st
+
+    a, st_a = play("execute")
+    b, _ = play("stepwise")
+    c, _ = play("execute")
+    assert st_a["children2_launches"] >= 2 * (count // k) - 2, st_a  # (the rounds really took the difference path)
+    for ply in range(2):
+        for other, tag in ((b, "execute vs step-wise"), (c, "execute vs execute")):
+            assert np.array_equal(a[ply][0].view(np.uint32), other[ply][0].view(np.uint32)), f"{tag}: visit policies differ after ply {ply}"
+            assert np.array_equal(a[ply][1], other[ply][1]), f"{tag}: sampled moves differ at ply {ply}"
+            _same_dumps(a[ply][2], other[ply][2], f"{tag}, ply {ply}")
+    shapes = [tree_shape(ints) for ints, _ in a[1][2]]
+    print(f"difference path, 800 sims: fully expanded non-root nodes {max(s[1] for s in shapes)}, depth {max(s[2] for s in shapes)}")
+    assert max(s[1] for s in shapes) >= 1 and max(s[2] for s in shapes) >= 3
+
+
+def test_whole_episodes_at_scale_are_deterministic():
+    """The determinism soak of tools/soak_determinism.py as a test: two fresh engines play the same whole episode -- 1024 games at 15x15, 512 simulations per
+    move (16384-row rounds: multi-tile window bins, the K-split set, the base cache, every thin-round path of the tail) -- and the digests of their packed replay
+    records are equal.  A data race in any kernel of the run loop shows up here."""
+    import hashlib
+    import torch
+    n, games, sims, k = 15, 1024, 512, 16
+    digests = []
+    for run in range(2):
+        eng = oa.Engine(board_size=n, games=games, max_nodes=4 * sims + 1024, max_tables=(4 * sims + 1024) // 4, max_batch_k=k, seed=123)
+        eng.load_random_weights(0)
+        sp = oa.SelfPlay(eng)
+        sp.reset()
+        st = sp.run(sims, k, 0.25, 0.03, 1.0, 30, 0)
+        _, _, plies = sp.game_info()
+        rec, total = sp.replay_record_bytes(), int(plies.sum())
+        buf = torch.zeros(total * rec, dtype=torch.uint8, device="cuda:0")
+        assert sp.replay_pack_into(buf.data_ptr(), total) == total
+        digests.append(hashlib.sha256(buf.cpu().numpy().tobytes()).hexdigest())
+        print(f"run {run}: games {int(st['finished'])} plies {total} sims {int(st['sims'])} sha256 {digests[-1][:16]}")
+        assert st["finished"] == games and st["children2_launches"] > 0
+        eng.close()
+    assert digests[0] == digests[1], digests

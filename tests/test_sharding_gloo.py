@@ -75,6 +75,61 @@ def test_two_rank_sharding_matches_single_process(tmp_path):
     assert np.array_equal(got["all"], single)  # rank-major gather == global game order, bit for bit
 
 
+# ---- the replay gather at the node's full width: 8 ranks, one of them without a single record --------------------------------
+COUNTS8 = [3, 0, 5, 1, 7, 2, 4, 6]  # live records per rank (rank 1: a shard whose games recorded nothing)
+
+
+def _records8(rank):
+    """records whose bytes name their origin: [rank, index, rank ^ index, 0...] + a running pattern"""
+    c = COUNTS8[rank]
+    r = np.zeros((c, REC), dtype=np.uint8)
+    for i in range(c):
+        r[i, :3] = (rank, i, rank ^ i)
+        r[i, 3:] = (np.arange(REC - 3) * (rank + 1) + i) % 251
+    return r
+
+
+def _worker8(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import omok_ai_amd as oa
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    posted = []
+    real = dist.batch_isend_irecv
+
+    def counting(ops):  # (the grouped exchange: ncclGroupStart + one ncclSend / ncclRecv per peer on RCCL)
+        posted.append(len(ops))
+        return real(ops)
+
+    dist.batch_isend_irecv = counting
+    allrec, counts = oa.dist.gather_replay(torch.from_numpy(_records8(rank)))
+    dist.batch_isend_irecv = real
+    assert counts == COUNTS8
+    # sends to the 7 peers unless this rank has nothing, receives from every peer that has something
+    expect = (7 if COUNTS8[rank] else 0) + sum(1 for p in range(world) if p != rank and COUNTS8[p] > 0)
+    assert posted == [expect], (rank, posted, expect)
+    secs, (games, recs) = oa.dist.reduce_timing(float(rank), [1, COUNTS8[rank]], "cpu")
+    assert secs == 7.0 and games == 8 and recs == sum(COUNTS8)
+    np.save(f"{out}.rank{rank}.npy", allrec.numpy())  # every rank holds the whole gather
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gather_replay_with_an_empty_rank(tmp_path):
+    """configs[3] / [4]'s width on the CPU: 8 ranks, uneven counts, rank 1 empty: every rank ends up with all the records in rank
+    order (= global game order), and a rank posts exactly one send per peer and one receive per non-empty peer (14 at most)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "g8")
+    mp.spawn(_worker8, args=(8, port, out), nprocs=8, join=True)
+    want = np.concatenate([_records8(r) for r in range(8)])
+    assert want.shape[0] == sum(COUNTS8)
+    for r in range(8):
+        assert np.array_equal(np.load(f"{out}.rank{r}.npy"), want), r
+
+
 # ---- data-parallel training step: gradients averaged over ranks (omok-ai_amd/train.py) ------------------------------
 def _train_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))

@@ -18,7 +18,7 @@ t0 = time.perf_counter(); st = sp.run(sims, k, max_plies=plies); dt = time.perf_
 print(json.dumps({"n": n, "seconds": dt, "ms_round": st["ms_round"], "ms_tree": st["ms_tree"], "ms_trunk": st["ms_trunk"], "ms_fc0": st["ms_fc0"], "ms_tail": st["ms_tail"]}))
 ''' % ROOT
 for lib in sys.argv[1:]:
-    for cfg in ((15, 4096, 800, 16, 3), (9, 16384, 200, 8, 4)):
+    for cfg in [c for c in ((15, 4096, 800, 16, 3), (9, 16384, 200, 8, 4)) if str(c[0]) in os.environ.get("AB_BOARDS", "15,9").split(",")]:
         env = dict(os.environ, OMOK_MI355X_LIB=os.path.abspath(lib))
         out = subprocess.run([sys.executable, "-c", CHILD] + [str(x) for x in cfg], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]

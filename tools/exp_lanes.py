@@ -1,5 +1,5 @@
 """Experiment: L engines of G / L games each (global game ids by game_offset), driven from L host threads on L streams of ONE GPU,
-against one engine of G games.  python tools/dev_lanes.py [G] [sims] [lanes...]"""
+against one engine of G games.  python tools/exp_lanes.py [G] [sims] [lanes...]"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,6 +1,6 @@
 """Development check of fc0's two operand formats (block-scaled fp6 / f16 correction terms) on the GPU box: evaluate_pv of the
 forced formats against the fp32 kernels and the oracle, the commit-time probe of the automatic mode, commit time, and the sibling
-paths (copy / difference) of search rounds in the f16 format.  Prints; asserts nothing.  `python tools/dev_fc0_fmt.py [quick]`."""
+paths (copy / difference) of search rounds in the f16 format.  Prints; asserts nothing.  `python tools/fc0_format_ab.py [quick]`."""
 import os
 import sys
 import time

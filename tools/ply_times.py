@@ -1,5 +1,5 @@
 """Per-ply wall time of one configs[1] episode against the number of live games (episode mode: omok_selfplay_run one ply at a time).
-usage: python tools/dev_ply_times.py [games sims k board]"""
+usage: python tools/ply_times.py [games sims k board]"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import omok_ai_amd as oa

@@ -1,5 +1,5 @@
 """Phase profile of the children kernels of the difference path (OMOK_SIB_PROF=1: k_sib_children, 2: k_sib_children2): plays the first plies of
-configs[1] and lets the library print its in-kernel cycle counters to stderr.  usage: OMOK_SIB_PROF=2 python tools/dev_sib_prof.py [plies]"""
+configs[1] and lets the library print its in-kernel cycle counters to stderr.  usage: OMOK_SIB_PROF=2 python tools/sib_phase_profile.py [plies]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import omok_ai_amd as oa
