@@ -2,10 +2,11 @@
 //
 // One tree = one arena, owned by exactly one wavefront at a time.  Layout:
 //   tree id t = side * G + game            (side 0 = black agent, 1 = white agent, trainer.rs:83-84)
-//   hdr    [T][cap_nodes]           16 B   NodeHdr  (Node fields of mcts/src/node.rs:10-21)
-//   board  [T][cap_nodes][2*NW]     u64    black words, white words (bit a = cell a)
-//   policy [T][cap_nodes][ROWP]     f32    BoardState.policy (alpha-zero/src/mcts_node.rs:10)
-//   child tables [T][cap_tables][ROWP]: cn u32, cw f32, cidx u16, corder u8; owner [T][cap_tables]
+//   (stride_nodes / stride_tables = the capacities rounded up to odd numbers: Store)
+//   hdr    [T][stride_nodes]        16 B   NodeHdr  (Node fields of mcts/src/node.rs:10-21)
+//   board  [T][stride_nodes][2*NW]     u64    black words, white words (bit a = cell a)
+//   policy [T][stride_nodes][ROWP]     f32    BoardState.policy (alpha-zero/src/mcts_node.rs:10)
+//   child tables [T][stride_tables][ROWP]: cn u32, cw f32, cidx u16, corder u8; owner [T][stride_tables]
 //     a node's (n, w) live in its PARENT's table at index = action (coalesced PUCT scan);
 //     child.p is parent.policy[action] (the reference keeps them equal at all times).
 //   ROWP = HW rounded up to 64 (one wave iteration per 64 cells); pad cells: corder = 0xFF.
@@ -92,6 +93,10 @@ struct Store {
     float* rp_z;        // [G][HW]
     unsigned long long* d_bytes; // kernel-counted algorithmic bytes
     int cap_nodes, cap_tables, games;
+    // Arena STRIDES per tree, in nodes / tables (>= the capacities): odd, so that the same node index of consecutive trees does not fall on the same HBM
+    // channels.  With stride = capacity = 4224 (a multiple of 128: policy rows of 1 KiB -> a tree stride of 33 x 128 KiB) the policy scatter of a round -- 4096
+    // trees writing the rows of about the same node indices -- ran at half the speed it has with 4225 (profiles/r04_arena_stride.txt).
+    int stride_nodes, stride_tables;
 };
 
 struct RoundArgs {

@@ -232,8 +232,10 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     Store& S = e->S;
     S.cap_nodes = cfg->max_nodes;
     S.cap_tables = cfg->max_tables;
+    S.stride_nodes = cfg->max_nodes | 1;   // odd strides: consecutive trees on different HBM channels (common.h, Store)
+    S.stride_tables = cfg->max_tables | 1;
     S.games = cfg->games;
-    const size_t T = (size_t)e->T, cn = (size_t)cfg->max_nodes, ct = (size_t)cfg->max_tables, rp = (size_t)e->rowp;
+    const size_t T = (size_t)e->T, cn = (size_t)S.stride_nodes, ct = (size_t)S.stride_tables, rp = (size_t)e->rowp;
     const size_t G = (size_t)cfg->games, HW = (size_t)e->hw;
     if (cfg->max_tree_waves < 0 || cfg->max_tree_waves > MAX_TREE_WAVES)
         { omok_destroy(e); return fail(nullptr, OMOK_ERR_INVALID, "max_tree_waves must be in [0, %d]", MAX_TREE_WAVES); }
@@ -973,7 +975,7 @@ extern "C" int omok_root_children(omok_engine* e, int32_t game, int32_t side, in
     if (!e || game < 0 || game >= e->cfg.games || (side != 0 && side != 1) || cap < 0) return OMOK_ERR_INVALID;
     ENTER(e);
     const size_t t = (size_t)side * e->cfg.games + game, rp = (size_t)e->rowp, nw2 = 2 * (size_t)e->nw;
-    const size_t tn = t * (size_t)e->cfg.max_nodes, tt = t * (size_t)e->cfg.max_tables;
+    const size_t tn = t * (size_t)e->S.stride_nodes, tt = t * (size_t)e->S.stride_tables;
     NodeHdr h0;
     HIPCHK(e, hipMemcpyAsync(&h0, e->S.hdr + tn, sizeof(h0), hipMemcpyDeviceToHost, e->st));
     if (sync_and_check(e, "root_children")) return OMOK_ERR_HIP;
@@ -1215,7 +1217,7 @@ extern "C" int omok_tree_dump(omok_engine* e, int32_t game, int32_t side, int32_
     std::vector<float> pol((size_t)nn * rp), cw((size_t)nt * rp);
     std::vector<uint32_t> cn((size_t)nt * rp);
     std::vector<uint8_t> co((size_t)nt * rp);
-    const size_t tn = t * (size_t)e->cfg.max_nodes, tt = t * (size_t)e->cfg.max_tables;
+    const size_t tn = t * (size_t)e->S.stride_nodes, tt = t * (size_t)e->S.stride_tables;
     hipMemcpyAsync(hdr.data(), e->S.hdr + tn, sizeof(NodeHdr) * nn, hipMemcpyDeviceToHost, e->st);
     hipMemcpyAsync(board.data(), e->S.board + tn * nw2, 8 * nw2 * nn, hipMemcpyDeviceToHost, e->st);
     hipMemcpyAsync(pol.data(), e->S.policy + tn * rp, 4 * rp * nn, hipMemcpyDeviceToHost, e->st);

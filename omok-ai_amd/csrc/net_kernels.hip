@@ -845,7 +845,7 @@ __device__ inline void sib_window(int n, int action, int& wy0, int& wx0) { // th
 }
 
 // cnt[0] runs, cnt[1] rows outside runs, cnt[2] rows inside runs.  sib_rows[i] = descriptor of a row inside a run: (request row, run
-// index, node record index t * cap_nodes + node, turn | action << 8); a run's rows are adjacent.
+// index, node record index t * stride_nodes + node, turn | action << 8); a run's rows are adjacent.
 // sib_slot[i] (difference path, else NULL) = window bin << 24 | rank of the row among the bin's rows (any order: a row's result does not
 // depend on its slot).
 // One wave per tree, GROUP_TREES trees per workgroup: the workgroup counts in LDS and claims its ranges of the global lists with one
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
     uint32_t tn = 0, ta = 0;
     if (lane < n) {
         const uint32_t node = S.req_node[(size_t)t * KMAX + lane];
-        tn = (uint32_t)t * (uint32_t)S.cap_nodes + node;
+        tn = (uint32_t)t * (uint32_t)S.stride_nodes + node;
         if (do_fill) { // k_fill's work (tree_kernels.hip): the dense (tree, node) list in tree order, then simulation order
             S.req_ref[ts.req_base + (uint32_t)lane] = ((uint32_t)t << 16) | node;
             S.req_aux[ts.req_base + (uint32_t)lane] = 0xFFFFFFFFu;
@@ -2041,7 +2041,23 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
         WAVE_LDS_FENCE();
         uint32_t bits[3];
         input_bits(cw, turn, bpxA, bits);
-        conv_in_tile(x, bits[0], bits[1], bits[2]);
+        if (SIB2_EXP != 9 && SIB2_EXP != 10) conv_in_tile(x, bits[0], bits[1], bits[2]);
+        if (SIB2_EXP == 9) { // (timing experiment: no conv_in, no block 0 -- what a kernel that starts from the base's residual stream in front of block 1 would save)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[m][i] = (float)(bits[0] + m + i);
+        }
+        if (SIB2_EXP == 10) { // (... and with the tile's residual stream loaded instead: 25 pixels x 512 B)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, sb[sib2_x2(HW, bpxA, m, g, h)]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[m][4 * g + i] = v[i] + (float)bits[0];
+                }
+        }
         TP(0);
         // h_child - h_base of the tile -> the wave's cells; `hb` / `db`: the base's h and d pieces of this lane's pixel
         auto grid_write = [&](const f32x16& acc, const uint4 (&hb)[4]) {
@@ -2106,7 +2122,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
             }
             WAVE_LDS_FENCE();
         };
-        { // ---- block 0: h differs from the base's in ONE pixel (P0): its difference goes to one cell, and every tile pixel next to P0 adds one tap of it ----
+        if (SIB2_EXP != 9 && SIB2_EXP != 10) { // ---- block 0: h differs from the base's in ONE pixel (P0): its difference goes to one cell, and every tile pixel next to P0 adds one tap of it ----
             int blk0 = 0;
             asm volatile("" : "+s"(blk0));
             const int tP = (py - vy0) * V2_TW + (pxx - vx0); // P0's pixel index in the tile (wave-uniform)
@@ -2376,6 +2392,15 @@ __device__ inline v8i f16x32_to_fp6(const half8& p0, const half8& p1, const half
    : (SEL_B) == 1 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((A), (B), (ACC), 2, 2, (SEL_A), (int)(SA), 1, (int)(SB))  \
    : (SEL_B) == 2 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((A), (B), (ACC), 2, 2, (SEL_A), (int)(SA), 2, (int)(SB))  \
                   : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((A), (B), (ACC), 2, 2, (SEL_A), (int)(SA), 3, (int)(SB)))
+// XCD-aware dealing of a 1-D grid's work items: workgroups go to the 8 XCDs round-robin (workgroup id % 8) and every XCD has its own L2, so XCD x takes a
+// contiguous eighth of the items.  The dense split-K launches order their items split-major (all tiles of K split 0, then split 1, ...): the tiles of a split stream
+// the same weight slice and then share it through ONE L2 (dealt tile-major, 8 tiles x 16 splits put tile t on XCD t: every L2 streamed the whole 45 MB matrix).
+// The grid must hold ceil(total / 8) * 8 workgroups.
+__device__ inline bool xcd_item(int total, int& item) {
+    const int per_xcd = (total + 7) >> 3, j = (int)blockIdx.x >> 3;
+    item = ((int)blockIdx.x & 7) * per_xcd + j;
+    return j < per_xcd && item < total;
+}
 constexpr bool STAGGER = false; // (skewing the waves by s_nops after the barrier: 3.52 -> 3.88 ms, the delay costs more than it saves)
 // WIN (difference path of the sibling rounds, N = 15): workgroup = one tile of 128 SLOTS whose rows share a 7x7 window (tile_info: bin |
 // live slots << 8; d_count = the path's counters, [4] = tiles).  `act` holds the slots' difference rows (SIB_DROW_U4: 98 super-steps =
@@ -2431,23 +2456,28 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
         count = d_count[0];
         if (count > max_count) count = max_count;
         if (EPI == EPI_PARTIAL && tile_info) { // the number of K splits and the partial slab's row capacity were chosen on the device (tile_info[0], [1]); uneven split.
-            // 1-D grid: workgroup w = (tile w % tiles, split w / tiles) -- a (tiles_max x ways_max) grid of which a few dozen workgroups have work
+            // 1-D grid over (split, tile) items dealt by xcd_item -- a (tiles_max x ways_max) grid of which a few dozen workgroups have work
             // costs more to dispatch (~65-100 workgroups per us) than the work takes
             const int ways = tile_info[0], nsup = full_tiles * 64 + 2 * last_cnt, per = (nsup + ways - 1) / ways;
             const int tiles = (count + GT_BS - 1) / GT_BS;
-            if (tiles == 0 || (int)blockIdx.x >= tiles * ways) return;
-            split_y = (int)blockIdx.x / tiles;
-            b0 = ((int)blockIdx.x % tiles) * GT_BS;
+            int item;
+            if (tiles == 0 || !xcd_item(tiles * ways, item)) return;
+            split_y = item / tiles;
+            b0 = (item % tiles) * GT_BS;
             out_row_u4 = (size_t)tile_info[1];
             ubeg = split_y * per;
             ksup = nsup - ubeg < per ? nsup - ubeg : per;
         } else {
-            if (b0 >= count) return;
-            ubeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksup : 0;
-            if (EPI == EPI_PARTIAL) { // (uneven split: the last split takes what is left; the host never makes it empty)
-                const int nsup = full_tiles * 64 + 2 * last_cnt;
+            if (EPI == EPI_PARTIAL) { // K split chosen on the host: 1-D grid over (split, tile) items, `ksup` super-steps per split, out_row_u4 = tiles x 128 rows of partials per split
+                const int nsup = full_tiles * 64 + 2 * last_cnt, tiles = (int)(out_row_u4 / GT_BS), ways = (nsup + ksup - 1) / ksup;
+                int item;
+                if (!xcd_item(tiles * ways, item)) return;
+                split_y = item / tiles;
+                b0 = (item % tiles) * GT_BS;
+                ubeg = split_y * ksup; // (uneven split: the last split takes what is left; the host never makes it empty)
                 ksup = nsup - ubeg < ksup ? nsup - ubeg : ksup;
             }
+            if (b0 >= count) return;
         }
         if (EPI == EPI_PARTIAL) { // an empty split (never chosen on purpose) contributes zeros and must not stream from beyond the matrix
             const int nsup = full_tiles * 64 + 2 * last_cnt;
@@ -2804,19 +2834,24 @@ __global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, co
         if (EPI == EPI_PARTIAL && tile_info) {
             const int ways = tile_info[0], nsup = full_tiles * 64 + 2 * last_cnt, per = (nsup + ways - 1) / ways;
             const int tiles = (count + GT_BS - 1) / GT_BS;
-            if (tiles == 0 || (int)blockIdx.x >= tiles * ways) return;
-            split_y = (int)blockIdx.x / tiles;
-            b0 = ((int)blockIdx.x % tiles) * GT_BS;
+            int item;
+            if (tiles == 0 || !xcd_item(tiles * ways, item)) return;
+            split_y = item / tiles;
+            b0 = (item % tiles) * GT_BS;
             out_row_u4 = (size_t)tile_info[1];
             ubeg = split_y * per;
             ksup = nsup - ubeg < per ? nsup - ubeg : per;
         } else {
-            if (b0 >= count) return;
-            ubeg = EPI == EPI_PARTIAL ? (int)blockIdx.y * ksup : 0;
-            if (EPI == EPI_PARTIAL) {
-                const int nsup = full_tiles * 64 + 2 * last_cnt;
+            if (EPI == EPI_PARTIAL) { // K split chosen on the host: 1-D grid over (split, tile) items, `ksup` super-steps per split, out_row_u4 = tiles x 128 rows of partials per split
+                const int nsup = full_tiles * 64 + 2 * last_cnt, tiles = (int)(out_row_u4 / GT_BS), ways = (nsup + ksup - 1) / ksup;
+                int item;
+                if (!xcd_item(tiles * ways, item)) return;
+                split_y = item / tiles;
+                b0 = (item % tiles) * GT_BS;
+                ubeg = split_y * ksup; // (uneven split: the last split takes what is left; the host never makes it empty)
                 ksup = nsup - ubeg < ksup ? nsup - ubeg : ksup;
             }
+            if (b0 >= count) return;
         }
         if (EPI == EPI_PARTIAL) { // an empty split contributes zeros and must not stream from beyond the matrix
             const int nsup = full_tiles * 64 + 2 * last_cnt;
@@ -3642,7 +3677,7 @@ static void launch_trunk(Net& net, const Store& S, int max_count, hipStream_t st
     }
     const int wgs = (max_count + TG::SPW - 1) / TG::SPW;
     const int grid = wgs < 256 ? wgs : 256;
-    kern<<<grid, TG::WG_THREADS, TG::LDS_BYTES, st>>>(S.req_ref, S.req_aux, S.board, S.hdr, S.d_count, S.cap_nodes, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first,
+    kern<<<grid, TG::WG_THREADS, TG::LDS_BYTES, st>>>(S.req_ref, S.req_aux, S.board, S.hdr, S.d_count, S.stride_nodes, net.in_f32, (const uint4*)net.wt_trunk, net.wt_first,
                                                        (uint4*)net.a_fc0, net.row_u4, max_count, row_list, d_nrows,
                                                        (ABL & 48) == 48 ? (const uint2*)net.d_comp : (const uint2*)net.d_groups, net.sib_h, d_out_base, (uint4*)net.a_base,
                                                        d_nrows2, v2 ? (uint4*)net.sib_h : nullptr);
@@ -3820,7 +3855,7 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
     const size_t cap_rows = (size_t)tiles_max * GT_BS;
     const int n_cu = net.n_cu;
     // the live count of full rows is only known on the device: k_bin_prefix chose the K split and the partial slab's row stride (d_gcnt[98], [99])
-    const int fgrid = tiles_max > n_cu ? tiles_max : n_cu; // (tiles x ways <= CUs by construction unless there are more tiles than CUs: then 1 way)
+    const int fgrid = ((tiles_max > n_cu ? tiles_max : n_cu) + 7) / 8 * 8; // (tiles x ways <= CUs by construction unless there are more tiles than CUs: then 1 way; whole eighths: xcd_item)
     if (net.fc0_fmt == FC0_F16) { // the same four launches on f16 residuals (k_fc0_x3)
         const int lc = (hw % 32) ? (hw % 32) : 1;
         k_fc0_x3<EPI_PARTIAL, false><<<dim3(fgrid, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32, lc, bias_fc0, nullptr,
@@ -3947,7 +3982,7 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
                                                                               nullptr, S.d_count, max_count, nullptr, nullptr, nullptr, net.n);
             else {
                 const size_t cap_rows = (size_t)tiles128 * GT_BS;
-                k_fc0_x3<EPI_PARTIAL, false><<<dim3(tiles128, nsplit), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.a_fc0, (nsup + nsplit - 1) / nsplit, net.row_u4,
+                k_fc0_x3<EPI_PARTIAL, false><<<dim3((tiles128 * nsplit + 7) / 8 * 8, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.a_fc0, (nsup + nsplit - 1) / nsplit, net.row_u4,
                                                                                      hw / 32, lc, bias_fc0, nullptr, cap_rows, net.part, S.d_count, max_count, nullptr, nullptr, nullptr, net.n);
                 const size_t threads = (size_t)max_count * 64;
                 k_splitk_finish<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(net.part, nsplit, cap_rows, bias_fc0, h0, 128, S.d_count, max_count);
@@ -3962,7 +3997,7 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
                                                       S.d_count, max_count, nullptr, nullptr, nullptr, net.n);
         } else {
             const size_t cap_rows = (size_t)tiles128 * GT_BS;
-            k_fc0_mx<EPI_PARTIAL><<<dim3(tiles128, nsplit), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0,
+            k_fc0_mx<EPI_PARTIAL><<<dim3((tiles128 * nsplit + 7) / 8 * 8, 1), 256, LDS, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0,
                                                                             (nsup + nsplit - 1) / nsplit, net.row_u4, hw / 32, (hw % 32) ? (hw % 32) : 1, sc,
                                                                             bias_fc0, nullptr, cap_rows, net.part, S.d_count, max_count, nullptr, nullptr,
                                                                             nullptr, net.n);

@@ -217,7 +217,7 @@ struct Tree {
     TreeState* ts;
     uint16_t* req;
     __device__ Tree(const Store& S, int t) {
-        const size_t tn = (size_t)t * (size_t)S.cap_nodes, tt = (size_t)t * (size_t)S.cap_tables;
+        const size_t tn = (size_t)t * (size_t)S.stride_nodes, tt = (size_t)t * (size_t)S.stride_tables;
         hdr = S.hdr + tn;
         board = S.board + tn * (2 * G::NW);
         pol = S.policy + tn * G::ROWP;
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(64) void k_scatter_policy(Store S, const float* __r
     // (four requests per iteration, their loads in flight together, measured SLOWER: 100 vs 67 us per 65536 requests)
     for (int d = blockIdx.x; d < count; d += gridDim.x) {
         const uint32_t ref = S.req_ref[d];
-        const size_t tn = (size_t)(ref >> 16) * (size_t)S.cap_nodes + (size_t)(ref & 0xFFFFu);
+        const size_t tn = (size_t)(ref >> 16) * (size_t)S.stride_nodes + (size_t)(ref & 0xFFFFu);
         uint64_t occ[NW];
 #pragma unroll
         for (int i = 0; i < NW; ++i) occ[i] = S.board[tn * (2 * NW) + i] | S.board[tn * (2 * NW) + NW + i];
@@ -933,51 +933,97 @@ __global__ __launch_bounds__(64) void k_scatter_policy(Store S, const float* __r
 // k_softmax (net_kernels.hip) + part 1 in one pass for the rounds of the run loop: the probabilities go from registers straight into the
 // node's policy row instead of through a [requests][ROWP] array in HBM and a second kernel.  The softmax is k_softmax's, operation for
 // operation (the step-wise API evaluates with the separate kernels and must produce the same bits), the rest is part 1's.
+// Round 4: the sequential f32 sum of pme.rs:241-249 (225 dependent additions in cell order: `iter().sum()`) was 450 of the ~600 vector instructions
+// a request cost here (v_readlane + v_add per cell, one request per wave: the kernel was bound by their issue slots, 87 us per 65536 requests).  A wave now
+// takes SSP_BATCH requests: their masked rows go to LDS [request][cell], lane r then adds up request r's row IN THE SAME ORDER (one chain of 225 additions
+// serves the whole batch), and the rows are read back, scaled and stored.  HW is odd, so the lanes of the summing phase hit different banks.
+constexpr int SSP_BATCH = 8;
 template <int N>
 __global__ __launch_bounds__(64) void k_softmax_scatter_policy(Store S, const float* __restrict__ logits, int lrow, float* __restrict__ V,
                                                                float* __restrict__ Vpre, int max_count) {
     using G = Geo<N>;
     constexpr int ROWP = G::ROWP, NW = G::NW, hw = G::HW;
+    static_assert((hw & 1) == 1, "odd row stride: conflict-free column reads");
+    __shared__ float srow[SSP_BATCH * hw];
+    __shared__ float sinv[SSP_BATCH];
     int count = S.d_count[0];
     if (count > max_count) count = max_count;
     const int lane = LANE;
-    for (int d = blockIdx.x; d < count; d += gridDim.x) {
-        const float* l = logits + (size_t)d * lrow;
-        // (the node's occupancy first: a chain of two dependent loads that runs under the softmax)
-        const uint32_t ref = S.req_ref[d];
-        const size_t tn = (size_t)(ref >> 16) * (size_t)S.cap_nodes + (size_t)(ref & 0xFFFFu);
-        uint64_t occ[NW];
+    const int nb = (count + SSP_BATCH - 1) / SSP_BATCH;
+    for (int b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int d0 = b * SSP_BATCH;
+        const int nreq = count - d0 < SSP_BATCH ? count - d0 : SSP_BATCH; // (wave-uniform)
+        // ---- every load of the batch up front: request refs (lane i = request i), logits, occupancy words of the nodes ----
+        const uint32_t my_ref = lane < nreq ? S.req_ref[d0 + lane] : 0u;
+        float lv[SSP_BATCH][G::IT];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) occ[i] = S.board[tn * (2 * NW) + i] | S.board[tn * (2 * NW) + NW + i];
-        float lv[G::IT];
+        for (int i = 0; i < SSP_BATCH; ++i) {
+            const float* l = logits + (size_t)(d0 + (i < nreq ? i : 0)) * lrow;
 #pragma unroll
-        for (int i = 0; i < G::IT; ++i) lv[i] = lane + 64 * i < hw ? l[lane + 64 * i] : -INFINITY;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < G::IT; ++i) mx = fmaxf(mx, lv[i]); // (ascending cells, as k_softmax's loop)
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        float sum = 0.0f, row[G::IT];
-#pragma unroll
-        for (int i = 0; i < G::IT; ++i) {
-            const int a = lane + 64 * i;
-            row[i] = 0.0f;
-            if (a < hw) { row[i] = expf(lv[i] - mx); sum += row[i]; }
+            for (int jj = 0; jj < G::IT; ++jj) lv[i][jj] = lane + 64 * jj < hw ? l[lane + 64 * jj] : -INFINITY;
         }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        if (lane == 0) { V[d] = tanhf(l[hw]); Vpre[d] = l[hw]; }
+        const float my_vpre = lane < nreq ? logits[(size_t)(d0 + lane) * lrow + hw] : 0.0f;
+        size_t tn[SSP_BATCH];
+        uint64_t occ[SSP_BATCH][NW];
 #pragma unroll
-        for (int j = 0; j < G::IT; ++j) {
-            const int a = j * 64 + lane;
-            const float p = a < hw ? row[j] / sum : 0.0f;       // the softmax output of this cell
-            const bool empty = a < hw && !((occ[j] >> lane) & 1ULL);
-            row[j] = empty ? p : 0.0f;                           // pme.rs:235-239
+        for (int i = 0; i < SSP_BATCH; ++i) {
+            const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)my_ref, i);
+            tn[i] = (size_t)(ref >> 16) * (size_t)S.stride_nodes + (size_t)(ref & 0xFFFFu);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) occ[i][w] = i < nreq ? (S.board[tn[i] * (2 * NW) + w] | S.board[tn[i] * (2 * NW) + NW + w]) : 0ULL;
         }
-        const float msum = seq_sum_regs<N>(row);
-        const bool renorm = F32_EPS <= msum;
-        const float inv = renorm ? __fdiv_rn(1.0f, msum) : 1.0f;
+        if (lane < nreq) { V[d0 + lane] = tanhf(my_vpre); Vpre[d0 + lane] = my_vpre; }
+        // ---- phase 1: k_softmax's arithmetic per request, the masked row -> LDS ----
 #pragma unroll
-        for (int j = 0; j < G::IT; ++j) S.policy[tn * ROWP + j * 64 + lane] = renorm ? row[j] * inv : row[j];
-        if (lane == 0) S.hdr[tn].has_policy = 1;
+        for (int i = 0; i < SSP_BATCH; ++i) {
+            if (i < nreq) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int jj = 0; jj < G::IT; ++jj) mx = fmaxf(mx, lv[i][jj]); // (ascending cells, as k_softmax's loop)
+                for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                float sum = 0.0f, row[G::IT];
+#pragma unroll
+                for (int jj = 0; jj < G::IT; ++jj) {
+                    const int a = lane + 64 * jj;
+                    row[jj] = 0.0f;
+                    if (a < hw) { row[jj] = expf(lv[i][jj] - mx); sum += row[jj]; }
+                }
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+#pragma unroll
+                for (int jj = 0; jj < G::IT; ++jj) {
+                    const int a = jj * 64 + lane;
+                    const float p = a < hw ? row[jj] / sum : 0.0f;       // the softmax output of this cell
+                    const bool empty = a < hw && !((occ[i][jj] >> lane) & 1ULL);
+                    if (a < hw) srow[i * hw + a] = empty ? p : 0.0f;     // pme.rs:235-239
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: lane r = request r: the sequential sum over its row, cells ascending (pme.rs:241-249) ----
+        if (lane < nreq) {
+            float acc = 0.0f;
+#pragma unroll 15
+            for (int a = 0; a < hw; ++a) acc += srow[lane * hw + a];
+            const bool renorm = F32_EPS <= acc;
+            sinv[lane] = renorm ? __fdiv_rn(1.0f, acc) : 0.0f; // (0 = no renormalisation: a kept sum is >= EPS, its reciprocal > 0)
+        }
+        __syncthreads();
+        // ---- phase 3: rows back from LDS, scaled, into the nodes' policy rows ----
+#pragma unroll
+        for (int i = 0; i < SSP_BATCH; ++i) {
+            if (i < nreq) {
+                const float inv = sinv[i];
+                const bool renorm = inv != 0.0f;
+#pragma unroll
+                for (int jj = 0; jj < G::IT; ++jj) {
+                    const int a = jj * 64 + lane;
+                    const float r = a < hw ? srow[i * hw + a] : 0.0f;
+                    S.policy[tn[i] * ROWP + a] = renorm ? r * inv : r;
+                }
+                if (lane == 0) S.hdr[tn[i]].has_policy = 1;
+            }
+        }
+        __syncthreads(); // (the next batch overwrites the rows)
     }
 }
 
@@ -1358,7 +1404,7 @@ __global__ __launch_bounds__(256) void k_set_actions(Store S, int side, const in
         if (a < 0) atomicAdd(&flags[1], 1u);
         else if (a >= G::HW) atomicAdd(&flags[0], 1u);
         else {
-            const uint64_t* bb = S.board + (size_t)(side * S.games + g) * (size_t)S.cap_nodes * (2 * NW); // root = node 0
+            const uint64_t* bb = S.board + (size_t)(side * S.games + g) * (size_t)S.stride_nodes * (2 * NW); // root = node 0
             const uint64_t occ = bb[a >> 6] | bb[NW + (a >> 6)];
             if ((occ >> (a & 63)) & 1ULL) atomicAdd(&flags[0], 1u);
             else gs.last_action = a;
@@ -1644,7 +1690,7 @@ template <int N>
 __device__ inline void load_request_board(const Store& S, uint32_t ref, uint32_t aux, uint64_t* bb, int& turn, int& mode) {
     constexpr int NW = Geo<N>::NW;
     const int t = (int)(ref >> 16), node = (int)(ref & 0xFFFFu);
-    const size_t tn = (size_t)t * (size_t)S.cap_nodes + (size_t)node;
+    const size_t tn = (size_t)t * (size_t)S.stride_nodes + (size_t)node;
     const NodeHdr h = S.hdr[tn];
 #pragma unroll
     for (int i = 0; i < 2 * NW; ++i) bb[i] = S.board[tn * (2 * NW) + i];
@@ -1924,7 +1970,8 @@ void launch_backups(int n, const Store& S, int side, const float* v, hipStream_t
 }
 void launch_softmax_scatter(int n, const Store& S, int side, const float* logits, int lrow, float* v, float* vpre, int max_count, hipStream_t st,
                             bool backups) {
-    const int grid = max_count < 8192 ? (max_count > 0 ? max_count : 1) : 8192;
+    const int nb = (max_count + SSP_BATCH - 1) / SSP_BATCH; // (a wave takes SSP_BATCH requests at a time)
+    const int grid = nb < 8192 ? (nb > 0 ? nb : 1) : 8192;
     DISPATCH_N(n, (k_softmax_scatter_policy<9><<<grid, 64, 0, st>>>(S, logits, lrow, v, vpre, max_count)),
                (k_softmax_scatter_policy<15><<<grid, 64, 0, st>>>(S, logits, lrow, v, vpre, max_count)));
     if (backups) launch_backups(n, S, side, v, st);
