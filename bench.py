@@ -54,10 +54,10 @@ def parse(argv=None):
     ap.add_argument("--max-plies", type=int, default=0, help="debug: stop every episode after this many plies")
     ap.add_argument("--max-nodes", type=int, default=0)
     ap.add_argument("--max-tables", type=int, default=0)
-    ap.add_argument("--net-mode", default="f16x3", choices=["f16x3", "fp6", "f16", "f32"],
+    ap.add_argument("--net-mode", default="f16x3", choices=["f16x3", "fp6", "mixed", "f16", "f32"],
                     help="f16x3: split-operand MFMA, fc0's correction terms in the format omok_net_commit's probe keeps (the headline); fp6 / f16: that format forced "
                          "(f16 meets north_star's 1e-3 on the LOGITS too); f32: the fp32 VALU kernels")
-    ap.add_argument("--f16-leg", type=int, default=1, help="extra leg: one more whole episode with fc0 forced into the f16 operand format -> value_f16_format (0 = skip)")
+    ap.add_argument("--f16-leg", type=int, default=1, help="extra legs: one more whole episode each with fc0 forced into the f16 / the fp6 operand format -> value_f16_format, value_fp6_format (0 = skip)")
     ap.add_argument("--gather", action="store_true", help="RCCL all-gather-v of replay tuples at episode end")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=20, help="training steps timed after the episode (0 = skip; batch 128)")
@@ -304,7 +304,7 @@ def main():
     max_nodes = args.max_nodes or min(16384, 4 * args.sims + 1024)
     max_tables = args.max_tables or max(256, max_nodes // 4)
     eng = oa.Engine(board_size=n, games=games, max_nodes=max_nodes, max_tables=max_tables, max_batch_k=k,
-                    device=gpu, net_mode={"f16x3": B.NET_F16X3, "fp6": B.NET_F16X3_FP6, "f16": B.NET_F16X3_F16, "f32": B.NET_F32}[args.net_mode],
+                    device=gpu, net_mode={"f16x3": B.NET_F16X3, "fp6": B.NET_F16X3_FP6, "mixed": B.NET_F16X3_MIXED, "f16": B.NET_F16X3_F16, "f32": B.NET_F32}[args.net_mode],
                     seed=args.seed, game_offset=oa.dist.game_offset(rank, games))
     eng.load_random_weights(0)
     sp = oa.SelfPlay(eng)
@@ -391,8 +391,9 @@ def main():
         # + per run of ~15 siblings whose base is not cached (22 % of the runs over a configs[1] episode, OMOK_SIB_STATS) a full row written twice
         # (fc0's compact copy, the base slot) and the base's three h grids; fc0 = the difference row + that share of a full row.
         # (bytes per pixel of an operand row: 2 x 192 in the fp6 format, 2 x 256 in the f16 format; a difference row = 49 pixels)
-        ppx = 512.0 if int(st.get("fc0_format", 0)) == 1 else 384.0
-        drow = 49.0 * ppx
+        fcode = int(st.get("fc0_format", 0))  # 0 fp6, 1 f16, 2 mixed (f16 full rows, fp6 difference rows)
+        ppx = 512.0 if fcode in (1, 2) else 384.0
+        drow = 49.0 * (512.0 if fcode == 1 else 384.0)
         miss, run = (0.22, 15.0) if n == 15 else (0.25, 7.5)  # share of the runs whose base is evaluated in full, siblings per run
         # (k_sib_children2, the default: a base slot also holds the base's d grids and its residual stream in front of block 2 -- 1280 B per pixel instead of
         #  384 -- written with the base and read once per run by its children; OMOK_SIB_V2=0: k_sib_children, 3 h grids)
@@ -441,14 +442,16 @@ def main():
                   "mfma_busy_pmc / valu_busy_pmc / lds_busy_pmc.  By arithmetic intensity (13.0 MFLOP over ~50 KB per row = 260 FLOP/B, under the 312 FLOP/B ridge) the HBM "
                   "roof is the lower one; measured (profiles/r04_children_traffic_experiments.txt): with every base read an L2 hit the group is 13 % faster, with no stores 17 % -- "
                   "the rest is the dependent instruction chain of two waves per SIMD")
-    mix = ("Per K = 64 the kernel (k_fc0_mx) issues 4 f16 + 2 block-scaled fp6 MFMAs (split operands) = 1.5x the pipe time of a plain-f16 product (frac <= 0.67 for a dense fc0)"
-           if int(st.get("fc0_format", 0)) == 0 else
-           "f16 operand format (k_fc0_x3): 3 f16 MFMAs per product = 3x the pipe time of a plain-f16 product (frac <= 0.33 for a dense fc0)")
+    fcode = int(st.get("fc0_format", 0))
+    mix = {0: "Per K = 64 the kernel (k_fc0_mx) issues 4 f16 + 2 block-scaled fp6 MFMAs (split operands) = 1.5x the pipe time of a plain-f16 product (frac <= 0.67 for a dense fc0)",
+           1: "f16 operand format (k_fc0_x3): 3 f16 MFMAs per product = 3x the pipe time of a plain-f16 product (frac <= 0.33 for a dense fc0)",
+           2: "mixed operand format: the window tiles of the difference rows -- where the time goes -- run on k_fc0_mx (4 f16 + 2 block-scaled fp6 MFMAs per K = 64, 1.5x the pipe time of a "
+              "plain-f16 product), full rows (one per run of siblings whose base is not cached, thin rounds) on k_fc0_x3 (3 f16 MFMAs per product)"}.get(fcode, "")
     note_fc0 = ("ALGORITHMIC flops 2*128*HW*512 per eval / HIP-event time of all fc0 launches.  " + mix + ".  A search round "
                 "runs the dense fc0 only on one full row per run of siblings whose base is not cached and 98 of the 2*HW K-steps (the 7x7 window) on each "
                 "child's difference row, i.e. ~0.28x (N = 15) / ~0.65x (N = 9) of the algorithmic work is EXECUTED: `achieved` counts useful work and can exceed "
                 "what a dense kernel could reach")
-    fc0_fmt = {0: "block-scaled fp6 (e2m3)", 1: "f16"}.get(int(st.get("fc0_format", 0)), "f32")
+    fc0_fmt = {0: "block-scaled fp6 (e2m3)", 1: "f16", 2: "mixed: f16 on full operand rows, block-scaled fp6 on the difference rows of sibling rounds"}.get(int(st.get("fc0_format", 0)), "f32")
     net_s = (st["ms_trunk"] + st["ms_fc0"] + st["ms_tail"]) * 1e-3
     tree_s = st["ms_tree"] * 1e-3
     tree_traffic = pmc.get("tree_hbm_bytes_per_sim")
@@ -461,8 +464,16 @@ def main():
         "fc0_format": {"in_use": fc0_fmt, "probe_rows": st.get("probe_rows"), "probe_limit": st.get("probe_limit"),
                        "fp6_max_dp_dv": [st.get("probe_dp_fp6"), st.get("probe_dv_fp6")], "f16_max_dp_dv": [st.get("probe_dp_f16"), st.get("probe_dv_f16")],
                        "probe_logit_abs_max": st.get("probe_logit_max"),
-                       "rule": "fp6 correction terms are kept while the probe's worst |dp| and |dv| against the fp32 kernels are <= probe_limit (0.3 of the 1e-3 "
-                               "contract); otherwise f16 correction terms (DESIGN 3.4)"} if args.net_mode != "f32" else None,
+                       "plain_rows_max_dlogit": {"fp6": st.get("probe_dlogit_fp6"), "f16": st.get("probe_dlogit_f16")}, "probe_logit_limit": st.get("probe_logit_limit"),
+                       "sibling_round": {"rows_checked": st.get("probe_round_rows"),
+                                         "fp6_dp_dv_dlogit": [st.get("probe_round_dp_fp6"), st.get("probe_round_dv_fp6"), st.get("probe_round_dlogit_fp6")],
+                                         "mixed_dp_dv_dlogit": [st.get("probe_round_dp_mixed"), st.get("probe_round_dv_mixed"), st.get("probe_round_dlogit_mixed")],
+                                         "f16_dp_dv_dlogit": [st.get("probe_round_dp_f16"), st.get("probe_round_dv_f16"), st.get("probe_round_dlogit_f16")],
+                                         "what": "one synthetic round of sibling runs through the difference path (base rows + 7x7-window difference rows) in each format, "
+                                                 "against the fp32 kernels"},
+                       "rule": "omok_net_commit keeps the fastest of fp6 < mixed (f16 full rows, fp6 difference rows) < f16 whose probe figures are inside the limits "
+                               "(|dp|, |dv| <= probe_limit = 3e-4, |dlogit| <= probe_logit_limit = 5e-4 against the fp32 kernels): fp6 on the plain rows AND the synthetic "
+                               "sibling round, mixed on the sibling round (its full rows are the f16 format's); f16 otherwise (DESIGN 3.4)"} if args.net_mode != "f32" else None,
         "children_kernel_launches": {"k_sib_children2": st.get("children2_launches"), "k_sib_children": st.get("children1_launches"),
                                      "note": "sibling rounds of the timed region by the kernel that evaluated the runs' children: k_sib_children2 on the difference path "
                                              "(rounds of >= 3072 rows at N = 15, >= 1024 at N = 9), k_sib_children on the copy path (smaller rounds)"},
@@ -516,11 +527,15 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if use_cuda and world == 1 and complete and args.f16_leg and args.net_mode == "f16x3" and room(30 + 1.6 * dt / max(args.steps, 1)):
-        # north_star's sentence as written asks for LOGITS within 1e-3: the f16 operand format meets that too (`precision.vs_oracle` below), the format the
-        # probe keeps for this net (fp6) meets it on p and v.  One more whole episode of the same workload with fc0 forced into the f16 format:
+    for leg_name, leg_mode in (("f16", "NET_F16X3_F16"), ("fp6", "NET_F16X3_FP6")):
+        # The other operand formats on the same workload, one more whole episode each with its own engine: f16 everywhere (the most precise: three f16 MFMAs per
+        # product of fc0) and fp6 everywhere (the fastest; its LOGITS miss north_star's 1e-3 on this net, which is why omok_net_commit's probe does not keep it).
+        if not (use_cuda and world == 1 and complete and args.f16_leg and args.net_mode == "f16x3" and room(30 + 1.6 * dt / max(args.steps, 1))):
+            break
+        if B.FC0_FORMATS.get(int(st.get("fc0_format", -1))) == leg_name:
+            continue  # (the headline already ran in this format)
         try:
-            eng2 = oa.Engine(board_size=n, games=games, max_nodes=max_nodes, max_tables=max_tables, max_batch_k=k, device=gpu, net_mode=B.NET_F16X3_F16,
+            eng2 = oa.Engine(board_size=n, games=games, max_nodes=max_nodes, max_tables=max_tables, max_batch_k=k, device=gpu, net_mode=getattr(B, leg_mode),
                              seed=args.seed, game_offset=oa.dist.game_offset(rank, games))
             eng2.load_random_weights(0)
             sp2 = oa.SelfPlay(eng2)
@@ -535,17 +550,16 @@ def main():
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t1
             st2 = eng2.stats()
-            out["value_f16_format"] = st2["finished"] / dt2
-            out["f16_format_leg"] = {"games_per_s": st2["finished"] / dt2, "seconds": dt2, "episodes": 1, "games_finished": st2["finished"],
-                                     "mcts_sims_per_s": st2["sims"] / dt2, "fc0_format": B.FC0_FORMATS[int(st2["fc0_format"])],
-                                     "ratio_to_value": st2["finished"] / dt2 / max(games_per_s, 1e-9),
-                                     "note": "extra leg outside the timed region: the same workload (one whole episode after a cut warm-up episode, its own engine) with "
-                                             "net mode OMOK_NET_F16X3_F16: fc0's correction terms on f16 operands (three f16 MFMAs per product), the mode that meets "
-                                             "north_star's 1e-3 on the pre-softmax logits as well as on p and v"}
+            out[f"value_{leg_name}_format"] = st2["finished"] / dt2
+            out[f"{leg_name}_format_leg"] = {"games_per_s": st2["finished"] / dt2, "seconds": dt2, "episodes": 1, "games_finished": st2["finished"],
+                                             "mcts_sims_per_s": st2["sims"] / dt2, "fc0_format": B.FC0_FORMATS[int(st2["fc0_format"])],
+                                             "ratio_to_value": st2["finished"] / dt2 / max(games_per_s, 1e-9),
+                                             "note": "extra leg outside the timed region: the same workload (one whole episode after a cut warm-up episode, its own engine) with "
+                                                     f"fc0's operand format forced ({leg_mode})"}
             eng2.close()
             del sp2, eng2
         except Exception as ex:
-            out["f16_format_leg"] = {"error": repr(ex)}
+            out[f"{leg_name}_format_leg"] = {"error": repr(ex)}
         extras = True
     if use_cuda and world == 1 and complete:
         if args.precision_rows > 0 and room(25):
@@ -640,7 +654,7 @@ def main():
                 # the GPU's outputs against the ORACLE (not the GPU's own fp32 kernels) on those rows: the headline's net mode and the f16 format
                 try:
                     vs = {"rows": int(len(chk["x"])), "reference": "oracle/net.c (fp32 restatement of network.rs, the checker of the -m gpu tests), rows of real search rounds"}
-                    for tag, mode in (("headline_mode", {"f16x3": B.NET_F16X3, "fp6": B.NET_F16X3_FP6, "f16": B.NET_F16X3_F16, "f32": B.NET_F32}[args.net_mode]),
+                    for tag, mode in (("headline_mode", {"f16x3": B.NET_F16X3, "fp6": B.NET_F16X3_FP6, "mixed": B.NET_F16X3_MIXED, "f16": B.NET_F16X3_F16, "f32": B.NET_F32}[args.net_mode]),
                                       ("f16_format", B.NET_F16X3_F16)):
                         e3 = oa.Engine(board_size=n, games=64, max_nodes=8, max_tables=4, max_batch_k=k, device=gpu, net_mode=mode)
                         e3.load_random_weights(0)

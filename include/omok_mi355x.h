@@ -50,6 +50,9 @@ extern "C" {
 
 #define OMOK_NET_F16X3_FP6 3 /* OMOK_NET_F16X3 with fc0's correction terms forced to block-scaled fp6 (no probe) */
 #define OMOK_NET_F16X3_F16 4 /* ... forced to f16 */
+#define OMOK_NET_F16X3_MIXED 5 /* ... forced to the mixed format: full operand rows (base positions of sibling rounds, single rows, omok_evaluate_pv) with f16
+                                  correction terms, the 7x7-window DIFFERENCE rows of sibling rounds -- where the time goes -- with block-scaled fp6 ones: the
+                                  quantisation error then scales with the differences, not with the activations */
 
 #define OMOK_MAX_ARENA 16384 /* largest max_nodes / max_tables: node and table indices are 16-bit, and the re-rooting kernel keeps
                                3 B per node + 2 B per table of scratch in LDS (82 KiB at the maximum, inside gfx950's 160 KiB) */
@@ -193,6 +196,10 @@ int omok_round_generate(omok_engine* e, int32_t round, int32_t batch_size, float
 int omok_round_inputs(omok_engine* e, float* inputs /* [n_requests][N][N][3] */);
 int omok_round_eval(omok_engine* e);
 int omok_round_outputs(omok_engine* e, float* p, float* v);
+/* Precision evidence (tests, bench): the policy logits in front of the softmax [n_requests][HW] and the value in front of tanh [n_requests] (may be NULL)
+ * of the round evaluated by omok_round_eval -- the quantities north_star's tolerance names (alpha-zero/src/network.rs:227-247), on the path the search
+ * rounds take (sibling base + window differences).  Call between omok_round_eval and omok_round_scatter. */
+int omok_round_logits(omok_engine* e, float* logits, float* vpre);
 int omok_round_inject(omok_engine* e, const float* p, const float* v);
 int omok_round_scatter(omok_engine* e);
 /* step-wise form of the opponent-tree mirror eval inside omok_advance */
@@ -268,7 +275,7 @@ int omok_debug_set_children_kernel(omok_engine* e, int32_t which);
 #define OMOK_STAT_MS_ROUND 13   /* HIP-event ms in the round (select/expand/backup) kernel only */
 #define OMOK_STAT_PEAK_NODES 14  /* largest node / table arena use seen so far */
 #define OMOK_STAT_PEAK_TABLES 15
-#define OMOK_STAT_FC0_FORMAT 16  /* operand format of fc0's correction terms in use: 0 = block-scaled fp6, 1 = f16 (-1: OMOK_NET_F32) */
+#define OMOK_STAT_FC0_FORMAT 16  /* operand format of fc0's correction terms in use: 0 = block-scaled fp6, 1 = f16, 2 = mixed (f16 full rows, fp6 difference rows) (-1: OMOK_NET_F32) */
 #define OMOK_STAT_PROBE_ROWS 17  /* rows of the last omok_net_commit's probe (0: no probe: forced format / OMOK_NET_F32) */
 #define OMOK_STAT_PROBE_DP_FP6 18 /* the probe's max |dp|, |dv| against the fp32 kernels: fp6 correction terms ... */
 #define OMOK_STAT_PROBE_DV_FP6 19
@@ -278,7 +285,15 @@ int omok_debug_set_children_kernel(omok_engine* e, int32_t which);
 #define OMOK_STAT_PROBE_LOGIT_MAX 23 /* largest |policy logit| of the probe rows (fp32 kernels) */
 #define OMOK_STAT_CHILDREN2_LAUNCHES 24 /* sibling rounds whose children ran on k_sib_children2 (difference path, default) ... */
 #define OMOK_STAT_CHILDREN1_LAUNCHES 25 /* ... on k_sib_children (copy path; difference path after omok_debug_set_children_kernel(1)) */
-#define OMOK_STAT_COUNT 26
+#define OMOK_STAT_PROBE_DLOGIT_FP6 26 /* the probe's plain rows: max(|dlogit|, |dv before tanh|) against the fp32 kernels, fp6 / f16 correction terms */
+#define OMOK_STAT_PROBE_DLOGIT_F16 27
+#define OMOK_STAT_PROBE_ROUND_ROWS 28 /* rows of the probe's synthetic sibling round (difference path) that were checked against the fp32 kernels (0: this engine's
+                                         rounds never take that path: games x max_batch_k below 3072 (board 15) / 1024 (board 9), or OMOK_NET_F16X3_ROWS) */
+#define OMOK_STAT_PROBE_ROUND_FP6 29   /* [29..31] |dp|, |dv|, |dlogit| of that round with fp6 rows and fp6 difference rows */
+#define OMOK_STAT_PROBE_ROUND_MIXED 32 /* [32..34] ... f16 rows, fp6 difference rows */
+#define OMOK_STAT_PROBE_ROUND_F16 35   /* [35..37] ... f16 rows, f16 difference rows */
+#define OMOK_STAT_PROBE_LOGIT_LIMIT 38 /* limit on the |dlogit| figures (5e-4); OMOK_STAT_PROBE_LIMIT (3e-4) is the one on |dp|, |dv| */
+#define OMOK_STAT_COUNT 39
 int omok_get_stats(omok_engine* e, double* stats /* [OMOK_STAT_COUNT] */);
 int omok_reset_stats(omok_engine* e);
 /* Per-category HIP-event timing of the kernels on the engine's stream (off by default).  enabled = 1: every launch; enabled = N > 1:

@@ -318,6 +318,14 @@ class SelfPlay:
             self._chk(B.lib().omok_round_outputs(self.h, B.fptr(p), B.fptr(v)))
         return p, v
 
+    def round_logits(self):
+        """pre-softmax policy logits [n][HW] and pre-tanh values [n] of the round just evaluated (call between round_eval and round_scatter)"""
+        lg = np.zeros((self._nreq, self.hw), dtype=np.float32)
+        vp = np.zeros(self._nreq, dtype=np.float32)
+        if self._nreq:
+            self._chk(B.lib().omok_round_logits(self.h, B.fptr(lg), B.fptr(vp)))
+        return lg, vp
+
     def round_inject(self, p, v):
         p = np.ascontiguousarray(p, dtype=np.float32)
         v = np.ascontiguousarray(v, dtype=np.float32)

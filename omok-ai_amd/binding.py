@@ -11,13 +11,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OMOK_MI355X_LIB") or os.path.join(_HERE, "libomok_mi355x.so")
 
 OK = 0
-NET_F16X3, NET_F32, NET_F16X3_ROWS, NET_F16X3_FP6, NET_F16X3_F16 = 0, 1, 2, 3, 4
-FC0_FORMATS = {-1: "f32", 0: "fp6", 1: "f16"}
+NET_F16X3, NET_F32, NET_F16X3_ROWS, NET_F16X3_FP6, NET_F16X3_F16, NET_F16X3_MIXED = 0, 1, 2, 3, 4, 5
+FC0_FORMATS = {-1: "f32", 0: "fp6", 1: "f16", 2: "mixed"}
 MODE_PLAYER, MODE_OPPONENT = 0, 1
 STAT_NAMES = ["sims", "evals", "ply_games", "finished", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply",
               "fc0_launches", "fc0_rows", "tree_bytes", "round_launches", "ms_round", "peak_nodes", "peak_tables",
               "fc0_format", "probe_rows", "probe_dp_fp6", "probe_dv_fp6", "probe_dp_f16", "probe_dv_f16", "probe_limit", "probe_logit_max",
-              "children2_launches", "children1_launches"]
+              "children2_launches", "children1_launches", "probe_dlogit_fp6", "probe_dlogit_f16", "probe_round_rows",
+              "probe_round_dp_fp6", "probe_round_dv_fp6", "probe_round_dlogit_fp6", "probe_round_dp_mixed", "probe_round_dv_mixed", "probe_round_dlogit_mixed",
+              "probe_round_dp_f16", "probe_round_dv_f16", "probe_round_dlogit_f16", "probe_logit_limit"]
 
 # every symbol include/omok_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -25,7 +27,7 @@ SYMBOLS = [
     "omok_net_commit", "omok_net_load_file", "omok_net_save_file", "omok_evaluate_pv", "omok_evaluate_logits", "omok_env_play", "omok_env_place_stone", "omok_encode_nn_input", "omok_selfplay_reset", "omok_set_episode", "omok_execute", "omok_execute_shared", "omok_execute_shared_recorded",
     "omok_compute_policy", "omok_play_actions", "omok_set_actions", "omok_root_children",
     "omok_sample_actions", "omok_advance", "omok_selfplay_run", "omok_selfplay_run_slots", "omok_round_generate", "omok_round_inputs",
-    "omok_round_eval", "omok_round_outputs", "omok_round_inject", "omok_round_scatter", "omok_mirror_generate",
+    "omok_round_eval", "omok_round_outputs", "omok_round_logits", "omok_round_inject", "omok_round_scatter", "omok_mirror_generate",
     "omok_mirror_inputs", "omok_mirror_eval", "omok_mirror_outputs", "omok_mirror_inject", "omok_mirror_apply",
     "omok_alive_count", "omok_current_ply", "omok_game_info", "omok_tree_dump", "omok_tree_root", "omok_replay_game",
     "omok_operand_row_bytes", "omok_debug_operand_rows", "omok_debug_set_base_cache", "omok_debug_set_children_kernel",
@@ -103,6 +105,7 @@ def lib():
     L.omok_round_inputs.argtypes = [H, fp]
     L.omok_round_eval.argtypes = [H]
     L.omok_round_outputs.argtypes = [H, fp, fp]
+    L.omok_round_logits.argtypes = [H, fp, fp]
     L.omok_round_inject.argtypes = [H, fp, fp]
     L.omok_round_scatter.argtypes = [H]
     L.omok_mirror_generate.argtypes = [H, ip]

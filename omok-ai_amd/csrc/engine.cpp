@@ -200,7 +200,7 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
         return fail(nullptr, OMOK_ERR_INVALID, "max_nodes must be in [2, %d] and max_tables in [1, %d]", OMOK_MAX_ARENA, OMOK_MAX_ARENA);
     if (cfg->max_batch_k < 1 || cfg->max_batch_k > KMAX) return fail(nullptr, OMOK_ERR_INVALID, "max_batch_k must be in [1, 64]");
     if (cfg->net_mode != OMOK_NET_F16X3 && cfg->net_mode != OMOK_NET_F32 && cfg->net_mode != OMOK_NET_F16X3_ROWS && cfg->net_mode != OMOK_NET_F16X3_FP6 &&
-        cfg->net_mode != OMOK_NET_F16X3_F16)
+        cfg->net_mode != OMOK_NET_F16X3_F16 && cfg->net_mode != OMOK_NET_F16X3_MIXED)
         return fail(nullptr, OMOK_ERR_INVALID, "bad net_mode");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -292,7 +292,8 @@ extern "C" int omok_create(const omok_config* cfg, omok_engine** out) {
     e->net.rowp = e->rowp;
     e->net.mode = cfg->net_mode == OMOK_NET_F32 ? OMOK_NET_F32 : OMOK_NET_F16X3;
     e->net.siblings = cfg->net_mode != OMOK_NET_F16X3_ROWS;
-    e->net.fc0_policy = cfg->net_mode == OMOK_NET_F16X3_FP6 ? FC0_FP6 : cfg->net_mode == OMOK_NET_F16X3_F16 ? FC0_F16 : FC0_AUTO;
+    e->net.fc0_policy = cfg->net_mode == OMOK_NET_F16X3_FP6 ? FC0_FP6 : cfg->net_mode == OMOK_NET_F16X3_F16 ? FC0_F16
+                      : cfg->net_mode == OMOK_NET_F16X3_MIXED ? FC0_MIXED : FC0_AUTO;
     e->net.max_b = (int)max_b;
     e->net.games = cfg->games;
     for (int i = 0; i < NET_TENSORS; ++i) e->net.wsize[i] = net_tensor_size(e->n, i);
@@ -1098,6 +1099,25 @@ extern "C" int omok_round_outputs(omok_engine* e, float* p, float* v) {
     if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
     return outputs_to_host(e, e->round_reqs, p, v);
 }
+// the pre-softmax policy logits and the pre-tanh value of the pending round's evaluation (precision evidence for the path the search rounds take)
+extern "C" int omok_round_logits(omok_engine* e, float* logits, float* vpre) {
+    if (!e || !logits) return OMOK_ERR_INVALID;
+    ENTER(e);
+    if (e->round_reqs < 0) return fail(e, OMOK_ERR_STATE, "no generated round");
+    if (e->round_reqs == 0) return OMOK_OK;
+    if (e->net.mode != OMOK_NET_F32 && !net_logits_cover_batch(e->net, e->round_reqs))
+        return fail(e, OMOK_ERR_STATE, "omok_round_logits: the round was evaluated in chunks (OMOK_NET_CHUNK): its logits are not kept");
+    if (e->net.mode == OMOK_NET_F32 && e->round_reqs > e->net.chunk)
+        return fail(e, OMOK_ERR_STATE, "omok_round_logits: OMOK_NET_F32 keeps the logits of its last chunk of %d rows only", e->net.chunk);
+    int stride = 0;
+    const float* lg = net_logits(e->net, &stride);
+    float* d_pack = e->net.in_f32;
+    const size_t tot = (size_t)e->round_reqs * e->hw;
+    k_pack_rows<<<(unsigned)((tot + 255) / 256), 256, 0, e->st>>>(lg, d_pack, e->hw, stride, e->round_reqs);
+    HIPCHK(e, hipMemcpyAsync(logits, d_pack, sizeof(float) * tot, hipMemcpyDeviceToHost, e->st));
+    if (vpre) HIPCHK(e, hipMemcpyAsync(vpre, e->net.vpre, sizeof(float) * e->round_reqs, hipMemcpyDeviceToHost, e->st));
+    return sync_and_check(e, "round_logits") ? OMOK_ERR_HIP : OMOK_OK;
+}
 extern "C" int omok_round_inject(omok_engine* e, const float* p, const float* v) {
     if (!e || !p || !v) return OMOK_ERR_INVALID;
     ENTER(e);
@@ -1389,7 +1409,7 @@ extern "C" int omok_get_stats(omok_engine* e, double* stats) {
     stats[OMOK_STAT_MS_ROUND] = e->prof.total_ms(PC_ROUND);
     stats[OMOK_STAT_PEAK_NODES] = (double)e->peak_nodes;
     stats[OMOK_STAT_PEAK_TABLES] = (double)e->peak_tables;
-    stats[OMOK_STAT_FC0_FORMAT] = e->net.mode == OMOK_NET_F32 ? -1.0 : (double)e->net.fc0_fmt;
+    stats[OMOK_STAT_FC0_FORMAT] = e->net.mode == OMOK_NET_F32 ? -1.0 : (e->net.diff_fp6 ? (double)FC0_MIXED : (double)e->net.fc0_fmt);
     stats[OMOK_STAT_PROBE_ROWS] = e->net.probe[6] != 0.0f ? (double)e->net.probe[0] : 0.0;
     stats[OMOK_STAT_PROBE_DP_FP6] = e->net.probe[1];
     stats[OMOK_STAT_PROBE_DV_FP6] = e->net.probe[2];
@@ -1399,6 +1419,11 @@ extern "C" int omok_get_stats(omok_engine* e, double* stats) {
     stats[OMOK_STAT_PROBE_LOGIT_MAX] = e->net.probe[5];
     stats[OMOK_STAT_CHILDREN2_LAUNCHES] = e->net.children_launches[0];
     stats[OMOK_STAT_CHILDREN1_LAUNCHES] = e->net.children_launches[1];
+    stats[OMOK_STAT_PROBE_DLOGIT_FP6] = e->net.probe[7];
+    stats[OMOK_STAT_PROBE_DLOGIT_F16] = e->net.probe[8];
+    stats[OMOK_STAT_PROBE_ROUND_ROWS] = e->net.probe[9];
+    for (int i = 0; i < 9; ++i) stats[OMOK_STAT_PROBE_ROUND_FP6 + i] = e->net.probe[10 + i];
+    stats[OMOK_STAT_PROBE_LOGIT_LIMIT] = NET_PROBE_LOGIT_LIMIT;
     return OMOK_OK;
 }
 

@@ -9,10 +9,12 @@ constexpr int NET_TENSORS = 31;
 constexpr int NC = 128; // RESIDUAL_CHANNELS (alpha-zero/src/network.rs:24)
 constexpr int NM = 32;  // RESIDUAL_MIDDLE_CHANNELS (:25)
 constexpr int NF = 512; // FC_0_SIZE / FC_1_SIZE (:29-30)
-enum { FC0_AUTO = -1, FC0_FP6 = 0, FC0_F16 = 1 };
+enum { FC0_AUTO = -1, FC0_FP6 = 0, FC0_F16 = 1, FC0_MIXED = 2 }; // MIXED: full rows as FC0_F16, the difference rows of sibling rounds as FC0_FP6
 // fp6 correction terms are kept only while the probe's worst |dp|, |dv| stay below this.  Round 4: 3e-4 (was 5e-4): held-out positions exceeded the probe's figure by up to 1.7x
 // (profiles/r03_precision_sweep.log) and the difference path of the search rounds adds up to 3e-4 against row-by-row evaluation, so 3e-4 x 1.7 + 3e-4 stays inside the 1e-3 contract
 constexpr float NET_PROBE_LIMIT = 3e-4f;
+// ... and the logits in front of the softmax / the value in front of tanh (north_star: "policy/value logits within 1e-3") within half of that bar
+constexpr float NET_PROBE_LOGIT_LIMIT = 5e-4f;
 constexpr int NET_PROBE_ROWS = 2048;
 
 struct Net {
@@ -82,10 +84,12 @@ struct Net {
     // weights for both and, with fc0_policy = FC0_AUTO, measures both against the fp32 kernels on a fixed probe set and keeps the
     // faster one (fp6) only if its worst |dp|, |dv| stay within NET_PROBE_LIMIT (3e-4 against the 1e-3 contract).
     int fc0_policy = FC0_AUTO; // FC0_AUTO / FC0_FP6 / FC0_F16 (forced)
-    int fc0_fmt = 0;          // format in use: FC0_FP6 or FC0_F16
+    int fc0_fmt = 0;          // format of FULL operand rows in use: FC0_FP6 or FC0_F16
+    bool diff_fp6 = false;    // FC0_MIXED: fc0_fmt == FC0_F16, but the difference rows of sibling rounds (and their window tiles) are in the fp6 format
     void* wt_fc0x = nullptr;  // fc0 weights for FC0_F16: [half-step][stage g][m-tile i][hi s0, hi s1, lo s0, lo s1][lane][8] f16
     size_t row_u4_fmt[2] = {0, 0}; // a_fc0 row stride per format (row_u4 = the one in use)
-    float probe[8] = {};      // commit-time probe: [0] rows, [1] |dp| fp6, [2] |dv| fp6, [3] |dp| f16, [4] |dv| f16, [5] max |logit| (fp32), [6] 1 = measured
+    float probe[24] = {};     // commit-time probe: [0] plain rows, [1] |dp| fp6, [2] |dv| fp6, [3] |dp| f16, [4] |dv| f16, [5] max |logit| (fp32), [6] 1 = measured,
+                              // [7] |dlogit| fp6, [8] |dlogit| f16 (plain rows); [9] rows of the synthetic sibling round checked, [10..18] its |dp|, |dv|, |dlogit| in fp6 / mixed / f16
     size_t bytes = 0;         // device bytes held
 };
 

@@ -2,11 +2,12 @@
 given set of weights and input rows.  The contract (BASELINE.json north_star) is 1e-3 on the outputs of AgentModel::evaluate_pv
 (alpha-zero/src/agent_model.rs:116-134): p after softmax, v after tanh.
 
-`omok_net_commit` measures fc0's fast operand format (block-scaled fp6 correction terms, products good to ~2^-15) on a fixed probe
-set against the fp32 kernels and falls back to f16 correction terms (~2^-22, ~1.5x the fc0 time) when its worst |dp| or |dv| exceeds
-3e-4 (`Engine.stats()`: fc0_format, probe_*).  The probe is a measurement on 2048 synthetic positions through the plain-row
-path, not a proof: held-out positions have exceeded its figure by up to 1.7x and the search rounds' difference path adds up to 3e-4
-(which is what the 3e-4 limit is sized for).  The functions below are the independent check on rows of the caller's choosing: tests,
+`omok_net_commit` measures fc0's operand formats against the fp32 kernels -- 2048 synthetic positions through the plain-row path and, where
+the engine's rounds are large enough for it, one synthetic round of sibling runs through the difference path -- and keeps the fastest of
+fp6 (block-scaled fp6 correction terms, products good to ~2^-15), mixed (f16 correction terms on full rows, fp6 on the difference rows:
++2..3 %) and f16 (~2^-22, +20 %) whose worst |dp|, |dv| stay within 3e-4 and whose logits stay within 5e-4 (`Engine.stats()`:
+fc0_format, probe_*).  The probe is a measurement, not a proof: held-out positions have exceeded its figures by up to 1.7x (what the
+limits are sized for).  The functions below are the independent check on rows of the caller's choosing: tests,
 bench.py and `Trainer` (on by default) use them.
 
 At board_size 15 the SEARCH ROUNDS take a different path through the first two stages of the net (sibling requests = one base row
@@ -56,7 +57,7 @@ def measure_search_rounds(tensors, n, games=64, batch_k=16, rounds=6, plies=3, d
     ref.load_weights(tensors)
     sp = api.SelfPlay(eng)
     sp.reset()
-    out = {"rows": 0, "max_dp": 0.0, "max_dv": 0.0}
+    out = {"rows": 0, "max_dp": 0.0, "max_dv": 0.0, "max_dlogit": 0.0, "max_dvpre": 0.0, "fc0_format": B.FC0_FORMATS[int(eng.stats()["fc0_format"])]}
     for _ in range(plies):
         if sp.alive_count == 0:
             break
@@ -65,15 +66,20 @@ def measure_search_rounds(tensors, n, games=64, batch_k=16, rounds=6, plies=3, d
             x = sp.round_inputs().copy()
             p, v = sp.round_eval()
             p, v = np.array(p).reshape(nreq, -1), np.array(v).reshape(-1)
+            lg, vp = sp.round_logits()  # (the quantities in front of softmax / tanh, on the path the round took)
             sp.round_scatter()
             if nreq:
                 p32, v32 = ref.evaluate_pv(x)
+                lg32, vp32 = ref.evaluate_logits(x)
                 out["max_dp"] = max(out["max_dp"], float(np.abs(p - p32.reshape(nreq, -1)).max()))
                 out["max_dv"] = max(out["max_dv"], float(np.abs(v - v32.reshape(-1)).max()))
+                out["max_dlogit"] = max(out["max_dlogit"], float(np.abs(lg - lg32.reshape(nreq, -1)).max()))
+                out["max_dvpre"] = max(out["max_dvpre"], float(np.abs(vp - vp32.reshape(-1)).max()))
                 out["rows"] += int(nreq)
         sp.sample_actions(1.0, 30)
         sp.advance()
     eng.close()
     ref.close()
     out["within_contract"] = bool(out["max_dp"] < 1e-3 and out["max_dv"] < 1e-3)
+    out["logits_within_1e-3"] = bool(out["max_dlogit"] < 1e-3 and out["max_dvpre"] < 1e-3)
     return out

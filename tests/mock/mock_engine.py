@@ -12,7 +12,7 @@ import omok_ai_amd as _real
 
 dist = _real.dist
 weights = _real.weights
-binding = types.SimpleNamespace(NET_F16X3=0, NET_F32=1, NET_F16X3_ROWS=2, NET_F16X3_FP6=3, NET_F16X3_F16=4, FC0_FORMATS={-1: "f32", 0: "fp6", 1: "f16"})
+binding = types.SimpleNamespace(NET_F16X3=0, NET_F32=1, NET_F16X3_ROWS=2, NET_F16X3_FP6=3, NET_F16X3_F16=4, NET_F16X3_MIXED=5, FC0_FORMATS={-1: "f32", 0: "fp6", 1: "f16", 2: "mixed"})
 
 
 class Engine:

@@ -38,7 +38,7 @@ def _report(n, tensors, x, tag, mode=B.NET_F16X3, via_file=None):
            "dp_f32": float(np.abs(p - p32).max()), "dv_f32": float(np.abs(v - v32).max()),
            "dlogit": float(np.abs(lg - lg32).max()), "dvpre": float(np.abs(vp - vp32).max()), "logit_max": float(np.abs(lg32).max()),
            "f32_vs_oracle_dp": float(np.abs(p32 - pc).max()), "format": B.FC0_FORMATS[int(st["fc0_format"])],
-           "probe": (st["probe_rows"], st["probe_dp_fp6"], st["probe_dv_fp6"], st["probe_dp_f16"], st["probe_dv_f16"])}
+           "probe": (st["probe_rows"], st["probe_dp_fp6"], st["probe_dv_fp6"], st["probe_dp_f16"], st["probe_dv_f16"]), "stats": st}
     print(f"precision[{tag}] " + " ".join(f"{k}={val:.3e}" if isinstance(val, float) else f"{k}={val}" for k, val in out.items()))
     eng.close()
     ref.close()
@@ -49,24 +49,39 @@ def _assert_contract(r, tag):
     assert r["dp_oracle"] < TOL and r["dv_oracle"] < TOL and r["dp_f32"] < TOL and r["dv_f32"] < TOL, (tag, r)
 
 
+def expected_format(st):
+    """omok_net_commit's rule (net_probe) restated on the statistics it publishes: the fastest of fp6 < mixed < f16 whose every probe figure -- plain rows
+    and, where the engine's rounds can take the difference path, the synthetic sibling round -- is inside the limits (|dp|, |dv| <= 3e-4, |dlogit| <= 5e-4)."""
+    lim, llim = st["probe_limit"], st["probe_logit_limit"]
+
+    def inside(dp, dv, dl):
+        return dp <= lim and dv <= lim and dl <= llim
+    rounds = st["probe_round_rows"] > 0
+    fp6 = inside(st["probe_dp_fp6"], st["probe_dv_fp6"], st["probe_dlogit_fp6"]) and \
+        (not rounds or inside(st["probe_round_dp_fp6"], st["probe_round_dv_fp6"], st["probe_round_dlogit_fp6"]))
+    mixed = rounds and inside(st["probe_round_dp_mixed"], st["probe_round_dv_mixed"], st["probe_round_dlogit_mixed"])  # (its full rows are the f16 format's)
+    return "fp6" if fp6 else "mixed" if mixed else "f16"
+
+
 def _assert_probe_rule(r):
     rows, dp6, dv6, dp16, dv16 = r["probe"]
-    assert rows >= 512
-    assert r["format"] == ("fp6" if (dp6 <= LIMIT and dv6 <= LIMIT) else "f16"), r
-    if r["format"] == "fp6":  # what was kept has the 3.3x margin on the probe set
-        assert dp6 <= LIMIT and dv6 <= LIMIT
+    st = r["stats"]
+    assert rows >= 512 and abs(st["probe_limit"] - LIMIT) < 1e-9 and abs(st["probe_logit_limit"] - 5e-4) < 1e-9
+    assert r["format"] == expected_format(st), r
+    if r["format"] == "fp6":  # what was kept has the margin on the probe set, logits included
+        assert dp6 <= LIMIT and dv6 <= LIMIT and st["probe_dlogit_fp6"] <= 5e-4
     assert dp16 < LIMIT and dv16 < LIMIT, r  # the fallback itself is well inside
 
 
 @pytest.mark.parametrize("n", [9, 15])
-@pytest.mark.parametrize("mode,name", [(B.NET_F16X3_FP6, "fp6"), (B.NET_F16X3_F16, "f16")])
+@pytest.mark.parametrize("mode,name", [(B.NET_F16X3_FP6, "fp6"), (B.NET_F16X3_F16, "f16"), (B.NET_F16X3_MIXED, "mixed")])
 def test_forced_formats_on_random_init(n, mode, name):
     """Both formats against the oracle on the random initialiser; the f16 format with a 4x margin."""
     x = random_positions(n, 192, 9)
     r = _report(n, oa.weights.init_random(n, seed=1), x, f"n={n} forced {name}", mode)
     assert r["format"] == name and r["probe"][0] == 0  # (no probe when the format is forced)
     _assert_contract(r, name)
-    if name == "f16":
+    if name in ("f16", "mixed"):  # (plain rows of the mixed format ARE f16-format rows)
         assert max(r["dp_oracle"], r["dv_oracle"], r["dp_f32"], r["dv_f32"]) < 2.5e-4, r
 
 
@@ -162,4 +177,53 @@ def test_format_switch_between_commits_keeps_results_consistent():
     print("formats:", fmts)
     assert np.array_equal(outs[0][0].view(np.uint32), outs[2][0].view(np.uint32)) and np.array_equal(outs[0][1].view(np.uint32), outs[2][1].view(np.uint32))
     assert fmts[0] == fmts[2]
+    eng.close()
+
+
+@pytest.mark.parametrize("n,games,k", [(15, 256, 16), (9, 160, 8)])
+@pytest.mark.parametrize("seed", [0, 2])
+def test_probe_covers_the_difference_path_and_logits_hold_there(n, games, k, seed):
+    """Round 4 ("probe what is actually run"): an engine whose rounds are large enough for the difference path (4096 / 1280 rows) also probes one
+    synthetic sibling round -- base rows + window difference rows -- in the fp6, mixed (f16 rows + fp6 differences) and f16 formats and keeps the fastest format whose
+    every figure, LOGITS included, is inside the limits.  Then, on real rounds of that engine: p, v AND the pre-softmax logits / pre-tanh value against the oracle's
+    forward -- north_star's tolerance as written ("policy/value logits within 1e-3") in the mode the engine chose by itself."""
+    tensors = oa.weights.init_random(n, seed=seed)
+    eng = oa.Engine(board_size=n, games=games, max_nodes=512, max_tables=128, max_batch_k=k, seed=31)
+    eng.load_weights(tensors)
+    st = eng.stats()
+    fmt = B.FC0_FORMATS[int(st["fc0_format"])]
+    assert st["probe_round_rows"] >= 256, st
+    assert fmt == expected_format(st), st
+    for tag in ("mixed", "f16"):  # the formats with f16 rows are far inside on the synthetic round
+        assert st[f"probe_round_dp_{tag}"] < LIMIT and st[f"probe_round_dv_{tag}"] < LIMIT, st
+    net = O.Net(n, tensors)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    rng = np.random.default_rng(seed)
+    rows, dp, dv, dl, dvp, lmax = 0, 0.0, 0.0, 0.0, 0.0, 0.0
+    for ply in range(2):
+        for rnd in range(4):
+            nreq = sp.round_generate(rnd, k, 0.25, 0.03)
+            x = sp.round_inputs().copy()
+            p, v = sp.round_eval()
+            lg, vp = sp.round_logits()
+            sp.round_scatter()
+            if rnd == 0:
+                continue
+            pick = rng.choice(nreq, size=48, replace=False)
+            pc, vc, lgc, vpc = net.forward_logits(x[pick], threads=8)
+            p, v = np.array(p).reshape(nreq, -1), np.array(v).reshape(-1)
+            dp, dv = max(dp, float(np.abs(p[pick] - pc).max())), max(dv, float(np.abs(v[pick] - vc).max()))
+            dl, dvp = max(dl, float(np.abs(lg[pick] - lgc).max())), max(dvp, float(np.abs(vp[pick] - vpc).max()))
+            lmax = max(lmax, float(np.abs(lgc).max()))
+            rows += len(pick)
+        sp.sample_actions(1.0, 30)
+        sp.advance()
+    print(f"precision[n={n} seed {seed} difference path, format {fmt}] rows={rows} dp={dp:.2e} dv={dv:.2e} dlogit={dl:.2e} dvpre={dvp:.2e} |logit|max={lmax:.1f} "
+          f"probe round: fp6 {st['probe_round_dp_fp6']:.1e}/{st['probe_round_dv_fp6']:.1e}/{st['probe_round_dlogit_fp6']:.1e} "
+          f"mixed {st['probe_round_dp_mixed']:.1e}/{st['probe_round_dv_mixed']:.1e}/{st['probe_round_dlogit_mixed']:.1e} "
+          f"f16 {st['probe_round_dp_f16']:.1e}/{st['probe_round_dv_f16']:.1e}/{st['probe_round_dlogit_f16']:.1e}")
+    assert rows >= 256 and dp < TOL and dv < TOL
+    assert dl < TOL and dvp < TOL, "north_star's tolerance on the logits themselves"
+    assert eng.stats()["children2_launches"] >= 6  # (the rounds took the difference path)
     eng.close()
