@@ -3909,6 +3909,15 @@ static int chunk_env() {
 }
 // THE decision whether a forward of request rows groups them by parent (launch_trunk_siblings): forward_f16x3 takes it from here, and so does the engine's
 // prediction of it (net_round_takes_sibling_path), on which it hands the request-list fill and the zeroing of d_gcnt to that path
+// Rounds below this many request rows take the copy path (forward_f16x3).  N = 15: 3072 in the fp6 format (measured break-even between 2048 and 4096 rows); with f16 full
+// rows the copy path's dense fc0 costs 1.5x more while the difference path's window tiles stay fp6 (FC0_MIXED): break-even between 1024 and 2048 rows (per three plies at
+// 2048 / 2560 rows: copy 65.4 / 74.7 ms, difference 60.2 / 63.4 ms; at 1024 rows 51.4 against 56.0)
+static int sib_delta_min_rows(const Net& net) {
+    static const int delta_min_env = getenv("OMOK_SIB_DELTA_MIN") ? atoi(getenv("OMOK_SIB_DELTA_MIN")) : 0;
+    if (delta_min_env > 0) return delta_min_env;
+    if (net.n != 15) return 1024;
+    return net.diff_fp6 ? 2048 : 3072;
+}
 static bool sibling_path(const Net& net, bool from_f32, int sib_side) { return !from_f32 && sib_side >= 0 && sib_env() && net.siblings && net.d_groups; }
 bool net_round_takes_sibling_path(const Net& net, int max_count) { // (forward_chunked: a chunked forward passes no sibling side)
     if (net.mode == OMOK_NET_F32 || max_count <= 0) return false;
@@ -3932,9 +3941,7 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     // (81 + 1) however few rows there are, the copy path rows / 128 tiles of the full K -- measured break-even between 2048 and 4096 rows.  The choice is a
     // function of the host's bound on the request count (alive games x K) only, so a run is reproducible.
     // (N = 9: 9 window bins + the single rows = 10 tiles at least)
-    static const int delta_min_env = getenv("OMOK_SIB_DELTA_MIN") ? atoi(getenv("OMOK_SIB_DELTA_MIN")) : 0;
-    const int delta_min_rows = delta_min_env > 0 ? delta_min_env : (net.n == 15 ? 3072 : 1024);
-    const bool delta = sib && use_sib >= 2 && max_count >= delta_min_rows;
+    const bool delta = sib && use_sib >= 2 && max_count >= sib_delta_min_rows(net);
     if (prof) prof->begin(PC_TRUNK, st);
     if (sib) launch_trunk_siblings(net, S, sib_side, max_count, st, delta);
     else if (net.n == 9) { if (from_f32) launch_trunk_fmt<9, true>(net, S, max_count, st); else launch_trunk_fmt<9, false>(net, S, max_count, st); }
@@ -4226,7 +4233,7 @@ static int net_probe(Net& net, const Store& S, hipStream_t st) {
     // ---- part 2: one synthetic sibling round on the difference path (only if this engine's rounds can be large enough to take it) in fp6 / mixed / f16 ----
     ProbeErr rounds[3];
     int round_rows = 0, checked = 0;
-    const int delta_min = net.n == 15 ? 3072 : 1024; // (forward_f16x3's threshold)
+    const int delta_min = net.n == 15 ? 3072 : 1024; // (forward_f16x3's threshold in the fp6 format: the largest of the three)
     int pg = net.games < 256 ? net.games : 256, pk = pg > 0 ? net.max_b / pg : 0; // trees, children per tree: 256 x 16 = 4096 rows where the engine is large enough
     if (pk > 32) pk = 32;
     if (pk > 16 && pg * 16 >= delta_min) pk = 16;

@@ -1,3 +1,3 @@
-OMOK_PROBE_LOG=1 python tools/play_plies.py 15 4096 800 16 1 2>&1 | grep -v amdgpu.ids | tail -3
-OMOK_PROBE_LOG=1 python tools/play_plies.py 9 16384 200 8 1 2>&1 | grep -v amdgpu.ids | tail -3
-python -m pytest tests/test_gpu_fc0_format.py -x -q -m gpu -s 2>&1 | grep -v amdgpu.ids | grep "precision\[n=.*difference path\|passed\|failed\|Error\|error\|assert" | tail -20
+tools/kstats_plies.sh gpurun_out/exp11 mixed 15 4096 800 16 2 5 | head -18
+tools/kstats_plies.sh gpurun_out/exp11 fp6 15 4096 800 16 2 3 | head -18
+for g in 64 128 160; do for dm in 0 1024 2048; do echo "games $g delta_min $dm"; OMOK_SIB_DELTA_MIN=$dm python tools/play_plies.py 15 $g 800 16 3 5 2>/dev/null | tail -1; done; done
