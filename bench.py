@@ -476,7 +476,7 @@ def main():
                                "sibling round, mixed on the sibling round (its full rows are the f16 format's); f16 otherwise (DESIGN 3.4)"} if args.net_mode != "f32" else None,
         "children_kernel_launches": {"k_sib_children2": st.get("children2_launches"), "k_sib_children": st.get("children1_launches"),
                                      "note": "sibling rounds of the timed region by the kernel that evaluated the runs' children: k_sib_children2 on the difference path "
-                                             "(rounds of >= 3072 rows at N = 15, >= 1024 at N = 9), k_sib_children on the copy path (smaller rounds)"},
+                                             "(rounds of >= 2048 rows at N = 15 in the mixed operand format, >= 3072 in the fp6 / f16 formats, >= 1024 at N = 9), k_sib_children on the copy path (smaller rounds)"},
         "data": "synthetic (games from the empty board, random-init net seed 0, one RNG stream per step)",
         "config": {"workload": f"{games} concurrent {n}x{n} games per GPU, {args.sims} sims/move, K={k}, two trees per game"
                                + ("" if complete else f", first {args.max_plies} plies only (games/s extrapolated)"),

@@ -3982,8 +3982,12 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
                 n_cu = (hipGetDeviceProperties(&prop, net.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
             }
             double best = 1e30;
-            for (int d = 1; d <= 16; ++d) { // (uneven splits: ceil(nsup / d) super-steps per split, the last one shorter but never empty; 30 ways
-                                            //  measured slower than 15 at 8 tiles: 100 vs 80 us -- every split writes and re-reads a 256-KB partial tile)
+            static const int dmax_env = getenv("OMOK_FC0_DMAX") ? atoi(getenv("OMOK_FC0_DMAX")) : 0; // (A-B runs)
+            // Up to 64 ways (round 4; 16 before): a thin round's few tiles then spread over all CUs -- per three plies at 16 / 32 / 64 live games: fp6 42.7 / 44.0 / 45.6 ->
+            // 38.0 / 39.3 / 42.3 ms, mixed (f16 rows) 48.0 / 49.1 / 51.5 -> 40.1 / 41.7 / 47.8 ms.  (Round 2 had measured 30 ways slower than 15 at 8 tiles; with the items
+            // dealt per XCD -- xcd_item -- it is the other way round.)
+            const int dmax = dmax_env > 0 ? dmax_env : 64;
+            for (int d = 1; d <= dmax; ++d) { // (uneven splits: ceil(nsup / d) super-steps per split, the last one shorter but never empty)
                 const int per = (nsup + d - 1) / d;
                 if ((d - 1) * per >= nsup) continue;
                 if (d > 1 && (size_t)d * (size_t)(tiles128 * GT_BS) > net.part_rows) continue;
