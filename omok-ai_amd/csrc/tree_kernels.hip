@@ -544,6 +544,221 @@ __device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>&
     }
 }
 
+// The K simulations of a round, BATCHED where the reference's sequence allows it (round 4).  Between two backups the descent reaches the same leaf (the memo), so the
+// simulations of a round are: pick the r-th untried cell of that leaf (r from the simulation's own Philox block), place the stone, expand -- K times -- and only a terminal
+// child (its backup changes n / w along the path) or a full leaf sends the next simulation down a new path.  run_sim does one simulation at a time (~550 instructions each, the
+// wave's stream bound by their issue); here a leaf's simulations are taken together: lane i computes simulation i's Philox block, the picks are made in order (each shrinks
+// the untried set: the sequential part, ~50 instructions per pick), the win checks follow pick by pick up to the first terminal child, and the children up to that one are
+// written in ONE pass (lane i: table slot and header of child i; 2 NW lanes per child: its board words; requests in simulation order).  Node indices, insertion ranks, request
+// order, statuses, the memo and the byte counter are those of the one-by-one sequence: the tests compare the trees with the oracle's bit for bit.
+template <int N>
+__device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>& C, const RoundArgs& A, uint32_t first_sim, int count, uint32_t tree_global) {
+    using G = Geo<N>;
+    constexpr int ROWP = G::ROWP, NW = G::NW;
+    const int lane = LANE;
+    int done = 0;
+    while (done < count) {
+        // ---- the leaf (run_sim's head) ----
+        int node = 0;
+        uint32_t node_n = R.root_n;
+        unsigned long long path_bytes = 0;
+        if (R.memo_node >= 0) {
+            node = R.memo_node;
+            node_n = R.memo_n;
+            path_bytes = R.memo_bytes;
+        } else C.node = -1;
+        NodeHdr h;
+        if (C.node == node) h = C.h;
+        else { fence_own_stores(R); h = T.hdr[node]; }
+        if (h.nch == h.legal && h.nch != 0) { fence_own_stores(R); C.node = -1; }
+        while (h.nch == h.legal && h.nch != 0) {
+            const uint32_t pn = node_n > 1u ? node_n : 1u;
+            const float sq = __fsqrt_rn((float)pn);
+            const size_t tb = (size_t)h.table * ROWP;
+            const float ph = __fdiv_rn(1.0f, (float)h.legal);
+            unsigned long long best = 0ULL;
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) {
+                const int a = j * 64 + lane;
+                const uint8_t ord = T.corder[tb + a];
+                if (ord != NONE8) {
+                    const uint32_t n = T.cn[tb + a];
+                    const float w = T.cw[tb + a];
+                    const float p = h.has_policy ? T.pol[(size_t)node * ROWP + a] : ph;
+                    const float q = __fdiv_rn(w, (float)n + F32_EPS);
+                    const float bias = __fdiv_rn(sq, (float)(1u + n));
+                    const float score = q + (1.0f * p) * bias;
+                    const unsigned long long v = ((unsigned long long)total_key_biased(score) << 32) | ((unsigned long long)ord << 16) | (unsigned long long)a;
+                    best = v > best ? v : best;
+                }
+            }
+            best = wave_max_u64(best);
+            const int a_best = (int)(best & 0xFFFFu);
+            path_bytes += 12ull * h.nch;
+            node_n = T.cn[tb + a_best];
+            node = (int)T.cidx[tb + a_best];
+            h = T.hdr[node];
+        }
+        R.memo_node = node;
+        R.memo_n = node_n;
+        R.memo_bytes = path_bytes;
+        if (h.status != ST_IN_PROGRESS) { // terminal leaf (pme.rs:92-97): one simulation
+            R.bytes += path_bytes;
+            fence_own_stores(R);
+            backup<N>(T, R, node, h.status >= ST_BLACK_WIN ? 1.0f : 0.0f);
+            R.memo_node = -1;
+            C.node = -1;
+            __syncthreads();
+            done += 1;
+            continue;
+        }
+        // ---- the leaf's board and untried cells (cached, or loaded once) ----
+        uint64_t bb[2 * NW];
+        unsigned long long cand[G::IT];
+        int total = 0;
+        if (C.node == node) {
+#pragma unroll
+            for (int i = 0; i < 2 * NW; ++i) bb[i] = C.bb[i];
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) { cand[j] = C.cand[j]; total += __popcll(cand[j]); }
+        } else {
+            fence_own_stores(R);
+#pragma unroll
+            for (int i = 0; i < 2 * NW; ++i) bb[i] = T.board[(size_t)node * (2 * NW) + i];
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) {
+                const int a = j * 64 + lane;
+                bool c = a < G::HW && !(((bb[j] | bb[NW + j]) >> lane) & 1ULL);
+                if (c && h.table != NONE16) c = T.corder[(size_t)h.table * ROWP + a] == NONE8;
+                cand[j] = __ballot(c);
+                total += __popcll(cand[j]);
+            }
+            C.node = node;
+#pragma unroll
+            for (int i = 0; i < 2 * NW; ++i) C.bb[i] = bb[i];
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) C.cand[j] = cand[j];
+            C.h = h;
+        }
+        const unsigned long long sim_bytes = path_bytes + 2 * (G::HW / 8);
+        if (total == 0) { R.bytes += sim_bytes; done += 1; continue; } // "There's no action for now": this simulation is consumed
+        // ---- how many simulations this leaf can take: the rest of the round, its untried cells, the room in the arenas ----
+        int m = count - done;
+        if (m > total) m = total;
+        const int room = S.cap_nodes - (int)R.n_nodes;
+        if (m > room) m = room > 0 ? room : 0;
+        if (h.table == NONE16 && R.n_tables >= (uint32_t)S.cap_tables) m = 0;
+        if (m == 0) { // arena overflow: this and every later simulation of the round fails in expand, as one by one
+            R.error |= 1u;
+            R.bytes += sim_bytes * (unsigned long long)(count - done);
+            C.node = -1;
+            return;
+        }
+        // ---- the picks, in simulation order (pme.rs:101-125): simulation done + i takes the r-th cell of what the earlier ones left ----
+        uint32_t my_x = 0u;
+        if (lane < m) my_x = philox(A.seed, first_sim + (uint32_t)(done + lane), (uint32_t)A.ply, tree_global, RNG_EXPAND).x;
+        int my_action = 0, my_status = ST_IN_PROGRESS;
+        {
+            int tot = total;
+            for (int i = 0; i < m; ++i) {
+                const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)my_x, i);
+                int r = (int)__umulhi(x, (uint32_t)tot);
+                int action = 0;
+                bool found = false;
+#pragma unroll
+                for (int j = 0; j < G::IT; ++j) {
+                    const int c = __popcll(cand[j]);
+                    if (!found) {
+                        if (r < c) { action = j * 64 + nth_set_bit(cand[j], r); found = true; }
+                        else r -= c;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < G::IT; ++j) cand[j] &= ~((action >> 6) == j ? (1ULL << (action & 63)) : 0ULL);
+                if (lane == i) my_action = action;
+                tot -= 1;
+            }
+        }
+        // ---- place the stones (pme.rs:128-135): win check per child, up to the first terminal one ----
+        int n_commit = m, term_status = ST_IN_PROGRESS;
+        for (int i = 0; i < m; ++i) {
+            const int a = __builtin_amdgcn_readlane(my_action, i);
+            uint64_t mine[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) mine[w] = h.turn == 0 ? bb[w] : bb[NW + w];
+            set_bit<NW>(mine, a);
+            const int five = exactly_five<N>(mine, a);
+            const int st = five ? (h.turn == 0 ? ST_BLACK_WIN : ST_WHITE_WIN) : (h.legal == 1 ? ST_DRAW : ST_IN_PROGRESS);
+            if (lane == i) my_status = st;
+            if (st != ST_IN_PROGRESS) { n_commit = i + 1; term_status = st; break; }
+        }
+        // ---- expand (node.rs:61-81), n_commit children in one pass ----
+        int tab = h.table;
+        if (tab == NONE16) {
+            tab = (int)R.n_tables++;
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) T.corder[(size_t)tab * ROWP + j * 64 + lane] = NONE8;
+            if (lane == 0) { T.owner[tab] = (uint16_t)node; T.hdr[node].table = (uint16_t)tab; }
+            __syncthreads(); // corder row init must land before the slot stores below
+        }
+        const int idx0 = (int)R.n_nodes;
+        R.n_nodes += (uint32_t)n_commit;
+        if (lane < n_commit) {
+            const size_t slot = (size_t)tab * ROWP + my_action;
+            T.corder[slot] = (uint8_t)(h.nch + lane);
+            T.cidx[slot] = (uint16_t)(idx0 + lane);
+            T.cn[slot] = 0u;
+            T.cw[slot] = 0.0f;
+            NodeHdr c;
+            c.parent = (uint16_t)node;
+            c.table = NONE16;
+            c.legal = (uint16_t)(h.legal - 1);
+            c.nch = 0;
+            c.action = (uint8_t)my_action;
+            c.status = (uint8_t)my_status;
+            c.turn = (uint8_t)(1 - h.turn);
+            c.has_policy = 0;
+            c.pad = 0;
+            T.hdr[idx0 + lane] = c;
+        }
+        if (lane == 0) T.hdr[node].nch = (uint16_t)(h.nch + n_commit);
+        for (int t0 = 0; t0 < n_commit * 2 * NW; t0 += 64) { // the children's boards: the leaf's words + the new stone
+            const int t = t0 + lane, ci = t / (2 * NW), wi = t % (2 * NW);
+            const int a = __shfl(my_action, ci < n_commit ? ci : 0, 64);
+            if (t < n_commit * 2 * NW) {
+                uint64_t w = bb[0];
+#pragma unroll
+                for (int k = 1; k < 2 * NW; ++k) w = wi == k ? bb[k] : w;
+                const bool own = (wi < NW) == (h.turn == 0);
+                if (own && (a >> 6) == (wi % NW)) w |= 1ULL << (a & 63);
+                T.board[(size_t)(idx0 + ci) * (2 * NW) + wi] = w;
+            }
+        }
+        const int n_new_req = n_commit - (term_status != ST_IN_PROGRESS ? 1 : 0); // (only the last committed child can be terminal)
+        if (lane < n_new_req) T.req[R.n_req + lane] = (uint16_t)(idx0 + lane);
+        R.n_req += (uint32_t)n_new_req;
+        R.bytes += (sim_bytes + 24 + 8 * 2 * NW) * (unsigned long long)n_commit + (unsigned long long)(4 + (G::HW + 2)) * (unsigned long long)n_new_req;
+        R.dirty = true;
+        h.table = (uint16_t)tab;
+        h.nch = (uint16_t)(h.nch + n_commit);
+        if (term_status != ST_IN_PROGRESS) { // pme.rs:177-181: the terminal child's reward goes up the path now; the next simulation starts at the root again
+            fence_own_stores(R);
+            backup<N>(T, R, idx0 + n_commit - 1, term_status == ST_DRAW ? 0.0f : 1.0f);
+            R.memo_node = -1;
+            C.node = -1;
+            __syncthreads();
+        } else { // the leaf as it is now (no terminal child: every pick was committed)
+            C.h = h;
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) C.cand[j] = cand[j];
+        }
+        done += n_commit;
+    }
+}
+
+#ifndef KROUND_BATCH
+#define KROUND_BATCH 1 // 0: one simulation at a time (run_sim; A-B builds and the reference point of the batched form)
+#endif
 #ifndef KROUND_WPS
 #define KROUND_WPS 4 // minimum waves per SIMD the register allocation of k_round must allow (A-B builds: -DKROUND_WPS=...)
 #endif
@@ -568,7 +783,8 @@ __global__ __launch_bounds__(64, KROUND_WPS) void k_round(Store S, RoundArgs A) 
     const uint32_t tree_global = (uint32_t)((A.game_offset + gs0.gid) * 2 + A.side);
     if (A.round == 0) apply_noise<N>(T, A, tree_global, s_row);
     LeafCache<N> C;
-    for (int i = 0; i < A.K; ++i) run_sim<N>(S, T, R, C, A, (uint32_t)(A.round * A.K + i), tree_global);
+    if (KROUND_BATCH) run_sims<N>(S, T, R, C, A, (uint32_t)(A.round * A.K), A.K, tree_global);
+    else for (int i = 0; i < A.K; ++i) run_sim<N>(S, T, R, C, A, (uint32_t)(A.round * A.K + i), tree_global);
     if (LANE == 0) {
         TreeState o = ts;
         o.n_nodes = R.n_nodes; o.n_tables = R.n_tables; o.root_n = R.root_n; o.root_w = R.root_w;
