@@ -435,7 +435,7 @@ def main():
 
     note_trunk = ("`kernel` = the trunk GROUP of a forward: conv_in + 3 bottleneck blocks (k_group + k_bin_prefix + k_trunk<BASE> + k_sib_children2 + k_trunk on the "
                   "rows outside sibling runs); avg_launch_ms = the group per forward, averaged over ALL rounds of the timed region (thin ones included; "
-                  "`--max-plies 4` gives the full-round figure that profiles/r03_rocprofv3_kernel_stats_c2_first4plies.csv sums to).  "
+                  "`--max-plies 4` gives the full-round figure that profiles/r04_rocprofv3_kernel_stats_c2_first4plies.csv sums to).  "
                   "ALGORITHMIC flops 2*MAC of a full evaluation (13.0 MFLOP/eval at N = 15) / HIP-event time on the engine's stream.  Every product "
                   "runs as 3 f16 MFMAs (split operands), and at N = 15 sibling requests share a base pass and recompute only a 5x5 / 7x7 window each, so "
                   "the EXECUTED matrix work is ~0.2x the algorithmic figure: the mfma side of `both_roofs` counts useful work; the group's own unit utilisation is in "

@@ -25,6 +25,21 @@ def test_net_matches_torch_fixture(n):
     assert np.allclose(p.sum(axis=1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("n", [9, 15])
+def test_forward_logits_is_the_same_forward(n):
+    """orc_net_forward_logits (the checker of north_star's tolerance on the LOGITS, network.rs:227-247): p and v are those of orc_net_forward bit for bit, and they
+    are softmax / tanh of the logits it hands out."""
+    g = np.load(os.path.join(GOLD, f"net_n{n}.npz"))
+    net = O.Net(n, weights.init_random(n, seed=int(g["seed"])))
+    x = g["inputs"][:6]
+    p, v = net.forward(x, threads=2)
+    p2, v2, lg, vp = net.forward_logits(x, threads=2)
+    assert np.array_equal(p.view(np.uint32), p2.view(np.uint32)) and np.array_equal(v.view(np.uint32), v2.view(np.uint32))
+    e = np.exp(lg.astype(np.float64) - lg.max(axis=1, keepdims=True))
+    assert np.abs(e / e.sum(axis=1, keepdims=True) - p).max() < 1e-6
+    assert np.abs(np.tanh(vp.astype(np.float64)) - v).max() < 1e-6
+
+
 def test_weight_tensor_sizes():
     for n, total in ((9, 5643250), (15, 15154306)):  # SURVEY Appendix B
         shapes = weights.tensor_shapes(n)
