@@ -420,26 +420,13 @@ __device__ void apply_noise(const Tree<N>& T, const RoundArgs& A, uint32_t tree_
     __syncthreads();
 }
 
+// select_leaf (node.rs:43-58) with the PUCT selector (pme.rs:81-90): from (node, h) down while the node is fully expanded; the last maximal child in
+// insertion order wins (max_by).  Updates node, its header, its visit count as stored in its parent's table, and the algorithmic bytes of the path.
 template <int N>
-__device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>& C, const RoundArgs& A, uint32_t sim_index,
-                        uint32_t tree_global) {
+__device__ inline void select_leaf(const Tree<N>& T, NodeHdr& h, int& node, uint32_t& node_n, unsigned long long& path_bytes) {
     using G = Geo<N>;
-    constexpr int ROWP = G::ROWP, NW = G::NW;
+    constexpr int ROWP = G::ROWP;
     const int lane = LANE;
-    int node = 0;
-    uint32_t node_n = R.root_n;
-    unsigned long long path_bytes = 0;
-    if (R.memo_node >= 0) { // resume at the remembered leaf
-        node = R.memo_node;
-        node_n = R.memo_n;
-        path_bytes = R.memo_bytes;
-    } else C.node = -1;
-    const bool cached = C.node == node;
-    NodeHdr h;
-    if (cached) h = C.h;
-    else { fence_own_stores(R); h = T.hdr[node]; }
-    if (h.nch == h.legal && h.nch != 0) { fence_own_stores(R); C.node = -1; } // the descent reads the tables this wave has been writing
-    // ---- select_leaf (node.rs:43-58) with the PUCT selector (pme.rs:81-90) ----
     while (h.nch == h.legal && h.nch != 0) {
         const uint32_t pn = node_n > 1u ? node_n : 1u;
         const float sq = __fsqrt_rn((float)pn);
@@ -469,6 +456,28 @@ __device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>&
         node = (int)T.cidx[tb + a_best];
         h = T.hdr[node];
     }
+}
+
+template <int N>
+__device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>& C, const RoundArgs& A, uint32_t sim_index,
+                        uint32_t tree_global) {
+    using G = Geo<N>;
+    constexpr int ROWP = G::ROWP, NW = G::NW;
+    const int lane = LANE;
+    int node = 0;
+    uint32_t node_n = R.root_n;
+    unsigned long long path_bytes = 0;
+    if (R.memo_node >= 0) { // resume at the remembered leaf
+        node = R.memo_node;
+        node_n = R.memo_n;
+        path_bytes = R.memo_bytes;
+    } else C.node = -1;
+    const bool cached = C.node == node;
+    NodeHdr h;
+    if (cached) h = C.h;
+    else { fence_own_stores(R); h = T.hdr[node]; }
+    if (h.nch == h.legal && h.nch != 0) { fence_own_stores(R); C.node = -1; } // the descent reads the tables this wave has been writing
+    select_leaf<N>(T, h, node, node_n, path_bytes);
     R.bytes += path_bytes;
     R.memo_node = node;
     R.memo_n = node_n;
@@ -571,34 +580,7 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
         if (C.node == node) h = C.h;
         else { fence_own_stores(R); h = T.hdr[node]; }
         if (h.nch == h.legal && h.nch != 0) { fence_own_stores(R); C.node = -1; }
-        while (h.nch == h.legal && h.nch != 0) {
-            const uint32_t pn = node_n > 1u ? node_n : 1u;
-            const float sq = __fsqrt_rn((float)pn);
-            const size_t tb = (size_t)h.table * ROWP;
-            const float ph = __fdiv_rn(1.0f, (float)h.legal);
-            unsigned long long best = 0ULL;
-#pragma unroll
-            for (int j = 0; j < G::IT; ++j) {
-                const int a = j * 64 + lane;
-                const uint8_t ord = T.corder[tb + a];
-                if (ord != NONE8) {
-                    const uint32_t n = T.cn[tb + a];
-                    const float w = T.cw[tb + a];
-                    const float p = h.has_policy ? T.pol[(size_t)node * ROWP + a] : ph;
-                    const float q = __fdiv_rn(w, (float)n + F32_EPS);
-                    const float bias = __fdiv_rn(sq, (float)(1u + n));
-                    const float score = q + (1.0f * p) * bias;
-                    const unsigned long long v = ((unsigned long long)total_key_biased(score) << 32) | ((unsigned long long)ord << 16) | (unsigned long long)a;
-                    best = v > best ? v : best;
-                }
-            }
-            best = wave_max_u64(best);
-            const int a_best = (int)(best & 0xFFFFu);
-            path_bytes += 12ull * h.nch;
-            node_n = T.cn[tb + a_best];
-            node = (int)T.cidx[tb + a_best];
-            h = T.hdr[node];
-        }
+        select_leaf<N>(T, h, node, node_n, path_bytes);
         R.memo_node = node;
         R.memo_n = node_n;
         R.memo_bytes = path_bytes;
@@ -1153,7 +1135,10 @@ __global__ __launch_bounds__(64) void k_scatter_policy(Store S, const float* __r
 // a request cost here (v_readlane + v_add per cell, one request per wave: the kernel was bound by their issue slots, 87 us per 65536 requests).  A wave now
 // takes SSP_BATCH requests: their masked rows go to LDS [request][cell], lane r then adds up request r's row IN THE SAME ORDER (one chain of 225 additions
 // serves the whole batch), and the rows are read back, scaled and stored.  HW is odd, so the lanes of the summing phase hit different banks.
-constexpr int SSP_BATCH = 8;
+#ifndef SSP_BATCH_N
+#define SSP_BATCH_N 4 // (per 65536 requests: 4 -> 46.9 us, 8 -> 50.0, 16 -> 80.1: the LDS rows limit the waves per CU; A-B builds: -DSSP_BATCH_N=...)
+#endif
+constexpr int SSP_BATCH = SSP_BATCH_N;
 template <int N>
 __global__ __launch_bounds__(64) void k_softmax_scatter_policy(Store S, const float* __restrict__ logits, int lrow, float* __restrict__ V,
                                                                float* __restrict__ Vpre, int max_count) {
