@@ -755,7 +755,10 @@ __global__ __launch_bounds__(64, KROUND_WPS) void k_round(Store S, RoundArgs A) 
     const Tree<N> T(S, t);
     const TreeState ts = *T.ts;
     Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
-    if (A.scatter_v && ts.n_req > 0) { // the previous round's backups, deferred into this kernel (run loop)
+#ifndef KROUND_EXP
+#define KROUND_EXP 0 // timing-only A-B builds: 1 = no deferred backups, 2 = no simulations
+#endif
+    if (KROUND_EXP != 1 && A.scatter_v && ts.n_req > 0) { // the previous round's backups, deferred into this kernel (run loop)
         scatter_tree<N>(S, T, ts, R, A.scatter_v);
         R.dirty = true;
     }
@@ -765,7 +768,8 @@ __global__ __launch_bounds__(64, KROUND_WPS) void k_round(Store S, RoundArgs A) 
     const uint32_t tree_global = (uint32_t)((A.game_offset + gs0.gid) * 2 + A.side);
     if (A.round == 0) apply_noise<N>(T, A, tree_global, s_row);
     LeafCache<N> C;
-    if (KROUND_BATCH) run_sims<N>(S, T, R, C, A, (uint32_t)(A.round * A.K), A.K, tree_global);
+    if (KROUND_EXP == 2) { /* timing only */ }
+    else if (KROUND_BATCH) run_sims<N>(S, T, R, C, A, (uint32_t)(A.round * A.K), A.K, tree_global);
     else for (int i = 0; i < A.K; ++i) run_sim<N>(S, T, R, C, A, (uint32_t)(A.round * A.K + i), tree_global);
     if (LANE == 0) {
         TreeState o = ts;
