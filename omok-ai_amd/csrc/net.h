@@ -62,11 +62,11 @@ struct Net {
     size_t d_slots = 0;              // slots allocated
     // base cache: a leaf stays the expansion target of its tree for ~14 rounds, so its base evaluation (operand row, h grids, fp32 fc0 row)
     // is kept per game slot and reused while the tree's runs keep the same parent (~78 % of the runs of a configs[1] episode)
-    int games = 0;                   // game slots of the engine (base slots [0, 2 games): two per game; [2 games, base_slots): other runs of a round)
+    int games = 0;                   // game slots of the engine (base slots [0, 2 games): two per game (SIB_WAYS); behind them: other runs of a round)
     size_t base_slots = 0;
     void* a_base = nullptr;          // [base_slots] operand rows of base positions (row_u4 each)
     float* facc = nullptr;           // [base_slots + max_b][512] fp32 fc0 rows: base slots, then the round's single rows
-    int32_t* d_tags = nullptr;       // [games][2] (leaf node | slot << 16) of the bases in the game's two slots, most recently used first; -1 = none
+    int32_t* d_tags = nullptr;       // [games][2] (leaf node | slot << 16) of the bases in the game's slots (SIB_WAYS), most recently used first; -1 = none
     void* d_comp = nullptr;          // the round's positions to evaluate in full: (request row of the first child, base slot)
     bool gcnt_zeroed = false;        // the engine's k_scan of this round has zeroed d_gcnt (launch_trunk_siblings then skips k_zero_ints)
     bool fill_in_group = false;      // ... and left the dense request list to k_group (launch_scan(fill = false))

@@ -821,6 +821,11 @@ __global__ __launch_bounds__(TrunkGeo<N>::WG_THREADS) void k_trunk(const uint32_
 // depthwise taps accumulate in (dy, dx) order, operand-row entries are per pixel), so the rows are BIT-IDENTICAL to a full
 // evaluation.  DIFFERENCE path: one more rounding (the quantisation of the difference), |dp| < 1e-4 measured; rounds of fewer than
 // 3072 rows stay on the copy path (forward_f16x3).  DESIGN.md 3.3.
+#ifndef SIB_WAYS_N
+#define SIB_WAYS_N 2 // (round 4, -DSIB_WAYS_N=4 measured on whole configs[1] episodes: 567.2 / 567.9 against 566.5 games/s with 2 -- four slots hit 88 % instead of 86 % of the runs and
+                     //  cost 3.5 GB more: not worth it)
+#endif
+constexpr int SIB_WAYS = SIB_WAYS_N;              // cached base evaluations per game (most recently used leaves of its tree)
 constexpr int SIB_MIN = 3;                       // runs shorter than this go to k_trunk (a base pass would not pay)
 constexpr int SIB_WIN = 7, SIB_GW = SIB_WIN + 2; // window side, child grid side (window + halo ring)
 constexpr int SIB_CGRID_ROWS = SIB_GW * SIB_GW + 1;
@@ -854,7 +859,7 @@ constexpr int GROUP_TREES = 16;
 __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, uint2* __restrict__ groups, int32_t* __restrict__ singles,
                                                              uint4* __restrict__ sib_rows, int32_t* __restrict__ cnt, uint32_t* __restrict__ sib_slot,
                                                              int32_t* __restrict__ tags, uint2* __restrict__ comp, int bn, int do_fill) {
-    // Difference path (sib_slot != NULL): base slots.  The FIRST run of a tree uses one of the game's two slots (2 g, 2 g + 1), whose content is
+    // Difference path (sib_slot != NULL): base slots.  The FIRST run of a tree uses one of the game's SIB_WAYS slots (SIB_WAYS g + way), whose content is
     // reused while a tag names the run's parent (a leaf is its tree's expansion target for ~14 rounds); further runs of the tree in the same
     // round (rare) take a slot behind the games' and are always evaluated.  comp[] lists the (first request row, slot) pairs to evaluate.
     __shared__ int l_cnt[3 + SIB_BINS + 2], l_base[3 + SIB_BINS + 2];
@@ -900,19 +905,35 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
         rbase = atomicAdd(&l_cnt[2], len);
         if (sib_slot) {
             if (lane == __ffsll((long long)qual) - 1) {
-                // two slots per game, most recently used first; a tag = leaf node | slot << 16, -1 = empty (one slot hits 77 % of the
-                // runs of a configs[1] episode, two 86 %, four 88 %: the descent alternates between two leaves while their scores cross)
-                const int t0 = tags[2 * g], t1 = tags[2 * g + 1];
-                int way;
-                if (t0 >= 0 && (t0 & 0xFFFF) == parent) way = t0 >> 16;
-                else if (t1 >= 0 && (t1 & 0xFFFF) == parent) { way = t1 >> 16; tags[2 * g] = t1; tags[2 * g + 1] = t0; }
-                else {
-                    way = t1 >= 0 ? (t1 >> 16) : (t0 >= 0 ? 1 - (t0 >> 16) : 0);
-                    tags[2 * g + 1] = t0;
-                    tags[2 * g] = parent | (way << 16);
+                // SIB_WAYS slots per game, most recently used first; a tag = leaf node | slot << 16, -1 = empty (one slot hits 77 % of the
+                // runs of a configs[1] episode, two 86 %, four 88 %: the descent alternates between a few leaves while their scores cross)
+                int tg[SIB_WAYS], hit = -1, way = 0;
+#pragma unroll
+                for (int i = 0; i < SIB_WAYS; ++i) tg[i] = tags[SIB_WAYS * g + i];
+#pragma unroll
+                for (int i = 0; i < SIB_WAYS; ++i)
+                    if (hit < 0 && tg[i] >= 0 && (tg[i] & 0xFFFF) == parent) hit = i;
+                if (hit >= 0) way = tg[hit] >> 16;
+                else { // miss: the least recently used slot, or the lowest slot never used
+                    if (tg[SIB_WAYS - 1] >= 0) way = tg[SIB_WAYS - 1] >> 16;
+                    else {
+                        unsigned used = 0u;
+#pragma unroll
+                        for (int i = 0; i < SIB_WAYS; ++i) used |= tg[i] >= 0 ? 1u << (tg[i] >> 16) : 0u;
+                        way = __ffs((int)~used) - 1;
+                    }
+                    hit = SIB_WAYS - 1;
                     mi = atomicAdd(&l_cnt[3 + SIB_BINS], 1);
                 }
-                bslot = 2 * g + way;
+                if (hit > 0 || mi >= 0) { // move to the front
+#pragma unroll
+                    for (int i = SIB_WAYS - 1; i > 0; --i)
+                        if (i <= hit) tg[i] = tg[i - 1];
+                    tg[0] = parent | (way << 16);
+#pragma unroll
+                    for (int i = 0; i < SIB_WAYS; ++i) tags[SIB_WAYS * g + i] = tg[i];
+                }
+                bslot = SIB_WAYS * g + way;
             } else {
                 ex = atomicAdd(&l_cnt[3 + SIB_BINS + 1], 1);
                 mi = atomicAdd(&l_cnt[3 + SIB_BINS], 1);
@@ -936,7 +957,7 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
     if (start && len >= SIB_MIN) {
         groups[l_base[0] + gslot] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)len);
         if (sib_slot) {
-            if (ex >= 0) bslot = 2 * S.games + l_base[3 + SIB_BINS + 1] + ex;
+            if (ex >= 0) bslot = SIB_WAYS * S.games + l_base[3 + SIB_BINS + 1] + ex;
             if (mi >= 0) comp[l_base[3 + SIB_BINS] + mi] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)bslot);
         }
     }
@@ -3440,7 +3461,7 @@ size_t net_alloc(Net& net) {
             ok = ok && A((void**)&net.d_singles, sizeof(int32_t) * mb);
             ok = ok && A((void**)&net.d_gcnt, sizeof(int32_t) * SIB_CNT_INTS);
             ok = ok && A((void**)&net.d_sib_rows, sizeof(uint4) * mb);
-            net.base_slots = (size_t)2 * net.games + mb / SIB_MIN + 1; // two slots per game + the other runs a round can hold
+            net.base_slots = (size_t)SIB_WAYS * net.games + mb / SIB_MIN + 1; // SIB_WAYS slots per game + the other runs a round can hold
             { // V2 children (default; OMOK_SIB_V2=0 or omok_debug_set_children_kernel(1): k_sib_children on the difference path too): a base slot holds 1280 B per pixel instead of 3 h grids
                 const char* e = getenv("OMOK_SIB_V2");
                 net.sib_v2 = !(e && atoi(e) == 0);
@@ -3455,7 +3476,7 @@ size_t net_alloc(Net& net) {
             ok = ok && A(&net.d_rows, net.d_slots * (size_t)SIBX_DROW_U4 * 16);
             ok = ok && A(&net.a_base, net.base_slots * row_u4 * 16);
             ok = ok && A((void**)&net.facc, sizeof(float) * (net.base_slots + mb) * NF);
-            ok = ok && A((void**)&net.d_tags, sizeof(int32_t) * (size_t)(net.games > 0 ? 2 * net.games : 2));
+            ok = ok && A((void**)&net.d_tags, sizeof(int32_t) * (size_t)SIB_WAYS * (size_t)(net.games > 0 ? net.games : 1));
             ok = ok && A(&net.d_comp, sizeof(uint2) * (mb / SIB_MIN + 1));
             hipDeviceProp_t prop;
             net.n_cu = (hipGetDeviceProperties(&prop, net.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -3752,7 +3773,7 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
     const int do_fill = net.fill_in_group ? 1 : 0;
     net.gcnt_zeroed = net.fill_in_group = false; // (one round's worth: the engine sets them per round)
     if (delta && (!net.sib_cache_valid || !net.base_cache)) { // the trees changed since the last search round: no cached base is valid
-        hipMemsetAsync(net.d_tags, 0xFF, sizeof(int32_t) * (size_t)net.games * 2, st);
+        hipMemsetAsync(net.d_tags, 0xFF, sizeof(int32_t) * (size_t)net.games * SIB_WAYS, st);
         net.sib_cache_valid = true;
     }
     k_group<<<(S.games + GROUP_TREES - 1) / GROUP_TREES, 64 * GROUP_TREES, 0, st>>>(S, side, (uint2*)net.d_groups, net.d_singles, (uint4*)net.d_sib_rows, net.d_gcnt,
