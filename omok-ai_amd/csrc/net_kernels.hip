@@ -3735,7 +3735,10 @@ static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_
 // K splits of the difference path's fc0 launches (chosen on the device, k_bin_prefix): the full rows up to 30 ways as far as the
 // partial slab holds ways x (the launch's row capacity); window tiles of the split set up to 14 ways (7 super-steps each)
 constexpr int SIB_MAX_WWAYS = 14;
-static int sib_max_fways(const Net&, int) { return 30; } // (capped on the device by the slab: part_rows / (tiles of full rows x 128))
+static int sib_max_fways(const Net&, int) { // (capped on the device by the slab: part_rows / (tiles of full rows x 128), and by CUs / tiles)
+    static const int env = getenv("OMOK_SIB_FWAYS") ? atoi(getenv("OMOK_SIB_FWAYS")) : 0; // (A-B runs)
+    return env > 0 ? env : 64; // (30 until round 4; per full round in the mixed format: k_fc0_x3 on the full rows 73.7 -> 64.5 us, k_facc_reduce 9.6 -> 13.2 us)
+}
 __global__ void k_zero_ints(int32_t* __restrict__ p, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }
