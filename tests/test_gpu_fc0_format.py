@@ -141,6 +141,7 @@ def test_contract_after_training_steps(n, seed):
         rounds = oa.precision.measure_search_rounds(trained, n, games=256, batch_k=16, rounds=4, plies=2, seed=9 + seed)
         print(f"n=15 seed {seed} trained, search rounds: {rounds}")
         assert rounds["rows"] > 20000 and rounds["max_dp"] < TOL and rounds["max_dv"] < TOL, rounds
+        assert rounds["logits_within_1e-3"], rounds  # (round 4: the logits of the difference path too, in the format the probe chose)
 
 
 @pytest.mark.parametrize("n", [9, 15])
