@@ -559,7 +559,7 @@ __device__ void run_sim(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>&
 // wave's stream bound by their issue); here a leaf's simulations are taken together: lane i computes simulation i's Philox block, the picks are made in order (each shrinks
 // the untried set: the sequential part, ~50 instructions per pick), the win checks follow pick by pick up to the first terminal child, and the children up to that one are
 // written in ONE pass (lane i: table slot and header of child i; 2 NW lanes per child: its board words; requests in simulation order).  Node indices, insertion ranks, request
-// order, statuses, the memo and the byte counter are those of the one-by-one sequence: the tests compare the trees with the oracle's bit for bit.
+// order, statuses, the memo and the byte counter are those of the one-by-one sequence: the tests compare the trees bit for bit with the CPU restatement's.
 template <int N>
 __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>& C, const RoundArgs& A, uint32_t first_sim, int count, uint32_t tree_global) {
     using G = Geo<N>;
