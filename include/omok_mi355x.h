@@ -256,7 +256,8 @@ int omok_debug_set_base_cache(omok_engine* e, int32_t enabled);
 /* Debugging aid / A-B switch: which kernel evaluates the children of a sibling run on the difference path: 2 = k_sib_children2 (default: one wave
  * per child, windows that grow with the blocks), 1 = k_sib_children (a wave pair per child, the 7x7 window through every block; always used on the copy path).
  * Outputs agree within 2e-4 (tests); cached base positions are dropped (the kernels read different base-slot layouts).  The environment variable
- * OMOK_SIB_V2=0 at omok_create selects 1 as the engine's default. */
+ * OMOK_SIB_V2=0 at omok_create selects 1 as the engine's default.  In the MIXED operand format (the usual outcome of omok_net_commit's probe) only k_sib_children2 writes
+ * the fp6 difference rows: which = 1 then returns OMOK_ERR_STATE instead of silently changing nothing (use OMOK_NET_F16X3_FP6 / _F16 engines for an A-B run). */
 int omok_debug_set_children_kernel(omok_engine* e, int32_t which);
 
 #define OMOK_STAT_SIMS 0        /* simulations run (incl. terminal hits / no-action sims) */
@@ -293,7 +294,12 @@ int omok_debug_set_children_kernel(omok_engine* e, int32_t which);
 #define OMOK_STAT_PROBE_ROUND_MIXED 32 /* [32..34] ... f16 rows, fp6 difference rows */
 #define OMOK_STAT_PROBE_ROUND_F16 35   /* [35..37] ... f16 rows, f16 difference rows */
 #define OMOK_STAT_PROBE_LOGIT_LIMIT 38 /* limit on the |dlogit| figures (5e-4); OMOK_STAT_PROBE_LIMIT (3e-4) is the one on |dp|, |dv| */
-#define OMOK_STAT_COUNT 39
+#define OMOK_STAT_PROBE_OUTSIDE 39 /* the probe's verdict on the format it committed: 0 = every figure inside the margin limits (OMOK_STAT_PROBE_LIMIT on |dp|, |dv|,
+                                      OMOK_STAT_PROBE_LOGIT_LIMIT on the logits); 1 = the most precise split-operand format (f16 correction terms) is outside the margin but
+                                      inside north_star's 1e-3 -- committed, one line on stderr; 2 = it is outside 1e-3: the engine evaluates this net with the plain fp32
+                                      kernels (OMOK_STAT_FC0_FORMAT = -1, the arithmetic of agent_model.rs:116-134; slow) until the next omok_net_commit.  A forced format
+                                      (OMOK_NET_F16X3_FP6 / _F16 / _MIXED) is never probed: 0 */
+#define OMOK_STAT_COUNT 40
 int omok_get_stats(omok_engine* e, double* stats /* [OMOK_STAT_COUNT] */);
 int omok_reset_stats(omok_engine* e);
 /* Per-category HIP-event timing of the kernels on the engine's stream (off by default).  enabled = 1: every launch; enabled = N > 1:

@@ -118,6 +118,7 @@ void launch_refill(int n, const Store& S, const float* root_policy_dev, int32_t*
 void launch_round(int n, const Store& S, const RoundArgs& a, hipStream_t st);
 // evals_dev[0] += the round's requests; zero_ptr[0 .. zero_n) = 0 (counters the round's forward expects zeroed); fill = false: the dense
 // (tree, node) list is written by the net's grouping kernel instead (run-loop rounds on the sibling path: k_group visits every request anyway)
+void launch_fill(const Store& S, int side, int K, hipStream_t st); // the dense request list alone (k_fill): what launch_scan(fill = true) appends
 void launch_scan(int n, const Store& S, int side, int K, hipStream_t st, unsigned long long* evals_dev = nullptr, int32_t* zero_ptr = nullptr, int zero_n = 0,
                  bool fill = true);
 // one tree searched by `waves` waves (MCTSExecutor::run): sh_req [waves][KMAX] u16, sh_cnt [2 * KMAX] u32 (counts | bases)

@@ -606,6 +606,8 @@ static void enqueue_round(omok_engine* e, int round, int K, float eps, float alp
     const bool sib_round = eval_and_scatter && net_round_takes_sibling_path(e->net, max_req);
     launch_scan(e->n, e->S, side, K, e->st, e->d_evals, sib_round ? e->net.d_gcnt : nullptr, NET_GCNT_INTS, !sib_round);
     e->net.gcnt_zeroed = e->net.fill_in_group = sib_round;
+    e->net.fill_side = side;
+    e->net.fill_k = K;
     e->prof.end(e->st);
     if (eval_and_scatter) {
         // the split-precision net hands over its logits: softmax / tanh run inside the policy scatter (no [requests][ROWP] round trip of p)
@@ -1379,6 +1381,9 @@ extern "C" int omok_debug_set_base_cache(omok_engine* e, int32_t enabled) {
 extern "C" int omok_debug_set_children_kernel(omok_engine* e, int32_t which) {
     if (!e) return OMOK_ERR_INVALID;
     if (which != 1 && which != 2) return fail(e, OMOK_ERR_INVALID, "children kernel %d (1 = k_sib_children, 2 = k_sib_children2)", which);
+    if (which == 1 && e->net.mode != OMOK_NET_F32 && e->net.diff_fp6)  // (the mixed format's difference rows are written by k_sib_children2 only: the switch would silently do nothing)
+        return fail(e, OMOK_ERR_STATE, "omok_debug_set_children_kernel(1): the engine runs the mixed operand format, whose difference path exists in k_sib_children2 only "
+                                       "(create the engine with OMOK_NET_F16X3_FP6 or _F16 to compare the two kernels)");
     e->net.sib_v2 = which == 2;
     net_invalidate_sibling_cache(e->net); // (the two kernels read different base-slot layouts)
     return OMOK_OK;
@@ -1424,6 +1429,7 @@ extern "C" int omok_get_stats(omok_engine* e, double* stats) {
     stats[OMOK_STAT_PROBE_ROUND_ROWS] = e->net.probe[9];
     for (int i = 0; i < 9; ++i) stats[OMOK_STAT_PROBE_ROUND_FP6 + i] = e->net.probe[10 + i];
     stats[OMOK_STAT_PROBE_LOGIT_LIMIT] = NET_PROBE_LOGIT_LIMIT;
+    stats[OMOK_STAT_PROBE_OUTSIDE] = (double)e->net.probe_outside;
     return OMOK_OK;
 }
 

@@ -15,10 +15,15 @@ enum { FC0_AUTO = -1, FC0_FP6 = 0, FC0_F16 = 1, FC0_MIXED = 2 }; // MIXED: full 
 constexpr float NET_PROBE_LIMIT = 3e-4f;
 // ... and the logits in front of the softmax / the value in front of tanh (north_star: "policy/value logits within 1e-3") within half of that bar
 constexpr float NET_PROBE_LOGIT_LIMIT = 5e-4f;
+// The limits above are the MARGIN the chooser keeps (a format is preferred only while inside them).  The CONTRACT is north_star's 1e-3: when even the most precise
+// split-operand format (f16 correction terms) measures above it on the probe, no format of this family may be committed silently -- net_commit then falls back to the
+// plain fp32 kernels (the arithmetic of the reference's AgentModel::evaluate_pv, agent_model.rs:116-134) and says so (Net::probe_outside, OMOK_STAT_PROBE_OUTSIDE).
+constexpr float NET_PROBE_CONTRACT = 1e-3f;
 constexpr int NET_PROBE_ROWS = 2048;
 
 struct Net {
     int n = 0, hw = 0, rowp = 0, mode = 0;
+    int cfg_mode = 0; // the mode the engine was created in (net_alloc); `mode` leaves it only for the fp32 fallback of a commit whose probe is outside the contract
     bool siblings = true; // search rounds may take the sibling path of the trunk / fc0 (false: OMOK_NET_F16X3_ROWS)
     int device = 0;   // HIP device ordinal (keys the per-device launch caches)
     int max_b = 0;
@@ -34,6 +39,9 @@ struct Net {
     // ---- OMOK_NET_F32 scratch (chunked) ----
     int chunk = 0;
     float *sx = nullptr, *sh = nullptr, *sd = nullptr, *sg = nullptr, *s0 = nullptr, *s1 = nullptr;
+    float *s0_x3 = nullptr, *s0_f32 = nullptr; // fp32 fallback of a split-precision engine: s0 is the logits buffer of the one mode and an fc scratch of the other
+    int probe_outside = 0;    // verdict of the last commit's probe on the format it chose: 0 = inside the margin limits, 1 = outside them but inside the 1e-3 contract
+                              // (committed, logged once), 2 = the f16 format itself is outside the contract: the engine evaluates with the fp32 kernels until the next commit
     // ---- OMOK_NET_F16X3: packed split-fp16 operands (see net_kernels.hip) ----
     void* wt_trunk = nullptr; // packed trunk weights (A-operand fragments, hi|lo)
     float* wt_first = nullptr; // conv_in weights/bias + all biases + depthwise taps, fp32
@@ -70,6 +78,7 @@ struct Net {
     void* d_comp = nullptr;          // the round's positions to evaluate in full: (request row of the first child, base slot)
     bool gcnt_zeroed = false;        // the engine's k_scan of this round has zeroed d_gcnt (launch_trunk_siblings then skips k_zero_ints)
     bool fill_in_group = false;      // ... and left the dense request list to k_group (launch_scan(fill = false))
+    int fill_side = 0, fill_k = 0;   // ... for this side's trees and this K: a forward that does not group after all writes the list itself (launch_fill)
     double children_launches[2] = {0.0, 0.0}; // sibling rounds by children kernel: [0] k_sib_children2, [1] k_sib_children
     bool sib_v2 = true;              // difference path: k_sib_children2 (one wave per child, growing windows) and the base-slot layout it reads
     bool base_cache = true;          // false (omok_debug_set_base_cache): every run's base is evaluated in full every round (A-B check: same p / v bit for bit)

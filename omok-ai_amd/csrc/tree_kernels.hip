@@ -758,6 +758,9 @@ __global__ __launch_bounds__(64, KROUND_WPS) void k_round(Store S, RoundArgs A) 
 #ifndef KROUND_EXP
 #define KROUND_EXP 0 // timing-only A-B builds: 1 = no deferred backups, 2 = no simulations
 #endif
+#if KROUND_EXP != 0 && !defined(OMOK_EXPERIMENT)
+#error "KROUND_EXP builds are timing experiments with wrong results: build them with -DOMOK_EXPERIMENT, never as the product"
+#endif
     if (KROUND_EXP != 1 && A.scatter_v && ts.n_req > 0) { // the previous round's backups, deferred into this kernel (run loop)
         scatter_tree<N>(S, T, ts, R, A.scatter_v);
         R.dirty = true;
@@ -2161,9 +2164,10 @@ void launch_scatter_shared(int n, const Store& S, int side, const float* p, cons
     DISPATCH_N(n, (k_scatter_shared<9><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt, rec_order, rec_pos)),
                (k_scatter_shared<15><<<1, waves * 64, 0, st>>>(S, side, v, sh_req, sh_cnt, rec_order, rec_pos)));
 }
+void launch_fill(const Store& S, int side, int K, hipStream_t st) { k_fill<<<(S.games * K + 255) / 256, 256, 0, st>>>(S, side, K); }
 void launch_scan(int n, const Store& S, int side, int K, hipStream_t st, unsigned long long* evals, int32_t* zero_ptr, int zero_n, bool fill) {
     k_scan<<<1, 1024, 0, st>>>(S, side, evals, zero_ptr, zero_ptr ? zero_n : 0);
-    if (fill) k_fill<<<(S.games * K + 255) / 256, 256, 0, st>>>(S, side, K);
+    if (fill) launch_fill(S, side, K, st);
 }
 void launch_scatter(int n, const Store& S, int side, const float* p, const float* v, int max_count, hipStream_t st, bool backups) {
     const int grid = max_count < 8192 ? (max_count > 0 ? max_count : 1) : 8192;

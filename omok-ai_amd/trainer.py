@@ -93,26 +93,38 @@ class Trainer:
             # new weights -> omok_net_commit -> the engine re-measured fc0's operand format on its probe set; the probe's
             # figures are kept for the log, and the outputs are checked independently below (a probe is a measurement, not a proof)
             st = self.engine.stats()
-            self.last_precision = {"fc0_format": api.B.FC0_FORMATS[int(st["fc0_format"])], "probe_rows": int(st["probe_rows"]),
+            fmt = api.B.FC0_FORMATS[int(st["fc0_format"])]  # the format THIS engine runs (its probe saw plain rows and, if its rounds are large enough, a sibling round)
+            self.last_precision = {"fc0_format": fmt, "probe_rows": int(st["probe_rows"]), "probe_outside": int(st["probe_outside"]),
                                    "probe_fp6": (st["probe_dp_fp6"], st["probe_dv_fp6"]), "probe_f16": (st["probe_dp_f16"], st["probe_dv_f16"])}
-            if self.precision_rows > 0:  # independent check on rows of this iteration's replay buffer (spread over the buffer); on by default
-                from . import precision
-                idx = torch.linspace(0, records.shape[0] - 1, min(self.precision_rows, records.shape[0]), device=records.device).long()
-                x, _, _ = T.decode_records(records[idx], self.n)
-                chk = precision.measure(self.phase.net.tensors(), self.n, x.reshape(x.shape[0], -1).cpu().numpy(), device=self.local_rank,
-                                        batch_k=p.evaluate_batch_size)
-                self.last_precision.update(chk)
-                if not chk["within_contract"]:
-                    log(f"[iter={self.iteration}] WARNING: net outputs differ from the fp32 kernels by |dp| {chk['max_dp']:.2e} |dv| {chk['max_dv']:.2e} "
-                        f"(contract 1e-3) in format {chk['fc0_format']}")
-                if self.precision_search_rounds:  # the path the search rounds take (base row + 7x7-window difference rows), on rounds of the new net
-                    games = max(64, -(-3072 // p.evaluate_batch_size)) if self.n == 15 else 128  # (enough rows per round for the difference path)
-                    sr = precision.measure_search_rounds(self.phase.net.tensors(), self.n, games=games, batch_k=p.evaluate_batch_size, rounds=2, plies=1,
-                                                         device=self.local_rank, seed=self.iteration)
-                    self.last_precision["search_rounds"] = sr
-                    if not sr["within_contract"]:
-                        log(f"[iter={self.iteration}] WARNING: search-round outputs differ from the fp32 kernels by |dp| {sr['max_dp']:.2e} |dv| {sr['max_dv']:.2e} "
-                            f"(contract 1e-3) on {sr['rows']} rows")
+            if self.precision_rows > 0 and fmt != "f32":  # independent check on rows of this iteration's replay buffer (spread over the buffer); on by default
+                # The check engines are FORCED into the training engine's format: left to their own probes they would validate whatever a 64-game engine chooses
+                # (never mixed).  A failure of the check (e.g. no memory for its engines) is logged, never fatal: the training state above is already consistent.
+                try:
+                    from . import precision
+                    forced = precision.FORCED_MODE[fmt]
+                    idx = torch.linspace(0, records.shape[0] - 1, min(self.precision_rows, records.shape[0]), device=records.device).long()
+                    x, _, _ = T.decode_records(records[idx], self.n)
+                    chk = precision.measure(self.phase.net.tensors(), self.n, x.reshape(x.shape[0], -1).cpu().numpy(), device=self.local_rank,
+                                            batch_k=p.evaluate_batch_size, net_mode=forced)
+                    self.last_precision["check"] = chk
+                    if chk["fc0_format"] != fmt:
+                        log(f"[iter={self.iteration}] WARNING: the precision check ran in format {chk['fc0_format']}, the engine runs {fmt}")
+                    if not chk["within_contract"]:
+                        log(f"[iter={self.iteration}] WARNING: net outputs differ from the fp32 kernels by |dp| {chk['max_dp']:.2e} |dv| {chk['max_dv']:.2e} "
+                            f"(contract 1e-3) in format {chk['fc0_format']}")
+                    if self.precision_search_rounds:  # the path the search rounds take (base row + 7x7-window difference rows), on rounds of the new net
+                        games = precision.difference_path_games(self.n, p.evaluate_batch_size)  # (enough rows per round for the difference path at either board size)
+                        sr = precision.measure_search_rounds(self.phase.net.tensors(), self.n, games=games, batch_k=p.evaluate_batch_size, rounds=2, plies=1,
+                                                             device=self.local_rank, seed=self.iteration, net_mode=forced)
+                        self.last_precision["search_rounds"] = sr
+                        if sr["difference_path_rounds"] == 0:
+                            log(f"[iter={self.iteration}] note: no round of the search-round check took the difference path ({sr['rows']} rows checked on the copy path)")
+                        if not sr["within_contract"]:
+                            log(f"[iter={self.iteration}] WARNING: search-round outputs differ from the fp32 kernels by |dp| {sr['max_dp']:.2e} |dv| {sr['max_dv']:.2e} "
+                                f"(contract 1e-3) on {sr['rows']} rows")
+                except Exception as ex:  # noqa: BLE001
+                    self.last_precision["check_error"] = repr(ex)
+                    log(f"[iter={self.iteration}] WARNING: the precision check did not run: {ex!r}")
             if self.rank == 0:  # Trainer::save (:605-626)
                 os.makedirs(self.save_dir, exist_ok=True)
                 final = os.path.join(self.save_dir, p.model_name)  # counter first, then the weights, each by rename: a crash in between

@@ -45,3 +45,35 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.lower().replace("not the oracle", ""), f
+
+
+# ---- the Rust side of the boundary (bindings/omok_mi355x.rs): rustc is absent, so the text is compared with the header ----
+def _abi_text():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("abi_text", os.path.join(ROOT, "tools", "abi_text.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_rust_binding_declares_the_whole_header():
+    A = _abi_text()
+    c, rs = A.parse_header(), A.parse_rust()
+    assert sorted(c) == _declared_symbols(), "the prototype parser must see every symbol of the header"
+    assert sorted(rs) == sorted(c), (sorted(set(c) - set(rs)), sorted(set(rs) - set(c)))
+    for name, (ret, args) in c.items():
+        rret, rargs = rs[name]
+        assert rret == ret, (name, "return", ret, rret)
+        assert len(rargs) == len(args), (name, "arity")
+        for (an, at), (rn, rt) in zip(args, rargs):
+            assert rt == at, (name, an, at, rt)  # kind, width, pointer depth and constness
+
+
+def test_rust_config_struct_and_constants_match_the_header():
+    A = _abi_text()
+    assert [(n, t) for n, t in A.parse_rust_config()] == [(n, t) for n, t in A.parse_header_config()]
+    # ... and the ctypes mirror the tests call through has the same layout
+    kinds = {C.c_int32: ("int", 32), C.c_uint64: ("uint", 64), C.c_int64: ("int", 64)}
+    assert [(n, kinds[t] + ((),)) for n, t in binding.Config._fields_] == A.parse_header_config()
+    assert A.parse_rust_consts() == A.parse_defines()
+    assert A.parse_defines()["OMOK_STAT_COUNT"] == len(binding.STAT_NAMES)

@@ -228,3 +228,70 @@ def test_probe_covers_the_difference_path_and_logits_hold_there(n, games, k, see
     assert dl < TOL and dvp < TOL, "north_star's tolerance on the logits themselves"
     assert eng.stats()["children2_launches"] >= 6  # (the rounds took the difference path)
     eng.close()
+
+
+def expected_verdict(st):
+    """OMOK_STAT_PROBE_OUTSIDE restated (net_probe): the figures of the COMMITTED format -- its plain rows (f16's for mixed / f16) and, where measured, its sibling round --
+    0 inside the margin limits, 1 inside north_star's 1e-3 only, 2 outside 1e-3 (the engine then runs the fp32 kernels and reports format f32)."""
+    fmt = expected_format(st)
+    plain = "fp6" if fmt == "fp6" else "f16"
+    figs = [(st[f"probe_dp_{plain}"], st[f"probe_dv_{plain}"], st[f"probe_dlogit_{plain}"])]
+    if st["probe_round_rows"] > 0:
+        figs.append((st[f"probe_round_dp_{fmt}"], st[f"probe_round_dv_{fmt}"], st[f"probe_round_dlogit_{fmt}"]))
+    if all(dp <= st["probe_limit"] and dv <= st["probe_limit"] and dl <= st["probe_logit_limit"] for dp, dv, dl in figs):
+        return 0
+    return 1 if all(max(f) <= 1e-3 for f in figs) else 2
+
+
+@pytest.mark.parametrize("n", [9, 15])
+def test_probe_verdict_is_published_and_a_net_outside_the_contract_falls_back_to_fp32(n):
+    """VERDICT round 4, weak 2 / missing 4: the chooser must never commit a net outside its limits silently, and the ladder needs a safe last rung.
+    (a) random-init nets: the verdict follows the published figures (0 or 1; the headline net's f16 plain-row |dlogit| 5.2e-4 is a 1).
+    (b) fc matrices x4 (logits x ~64: |logit| in the thousands): even f16 correction terms miss 1e-3 on the logits -> verdict 2, the engine evaluates with the fp32
+        kernels (format f32: the arithmetic of AgentModel::evaluate_pv, agent_model.rs:116-134) and its outputs ARE the fp32 engine's, bit for bit.
+    (c) a commit of an ordinary net on the same engine returns to the split-precision path with the results a fresh engine gives."""
+    x = random_positions(n, 96, 13)
+    base = oa.weights.init_random(n, seed=1)
+    eng = oa.Engine(board_size=n, games=32, max_nodes=256, max_tables=64, max_batch_k=16)
+    eng.load_weights(base)
+    st = eng.stats()
+    assert int(st["probe_outside"]) == expected_verdict(st) and int(st["probe_outside"]) in (0, 1), st
+    fmt0 = B.FC0_FORMATS[int(st["fc0_format"])]
+    p0, v0 = eng.evaluate_pv(x)
+    big = [a.copy() for a in base]
+    for i in (23, 25, 29):
+        big[i] = big[i] * np.float32(4.0)
+    eng.load_weights(big)
+    st = eng.stats()
+    print(f"n={n} x4 net: verdict {st['probe_outside']}, format {B.FC0_FORMATS[int(st['fc0_format'])]}, probe f16 |dp| {st['probe_dp_f16']:.2e} |dv| {st['probe_dv_f16']:.2e} "
+          f"|dlogit| {st['probe_dlogit_f16']:.2e}, max |logit| {st['probe_logit_max']:.0f}")
+    assert int(st["probe_outside"]) == 2 and B.FC0_FORMATS[int(st["fc0_format"])] == "f32", st
+    ref = oa.Engine(board_size=n, games=32, max_nodes=256, max_tables=64, max_batch_k=16, net_mode=B.NET_F32)
+    ref.load_weights(big)
+    p, v = eng.evaluate_pv(x)
+    p32, v32 = ref.evaluate_pv(x)
+    assert np.array_equal(p.view(np.uint32), p32.view(np.uint32)) and np.array_equal(v.view(np.uint32), v32.view(np.uint32)), "the fallback must be the fp32 kernels"
+    lg, vp = eng.evaluate_logits(x)
+    lg32, vp32 = ref.evaluate_logits(x)
+    assert np.array_equal(lg.view(np.uint32), lg32.view(np.uint32)) and np.array_equal(vp.view(np.uint32), vp32.view(np.uint32))
+    pc, vc = O.Net(n, big).forward(x, threads=8)
+    assert np.abs(p.reshape(len(x), -1) - pc).max() < TOL and np.abs(v.reshape(-1) - vc).max() < TOL  # ... and it holds the contract against the oracle
+    # the fallback also carries a search: two plies of a small self-play, trees equal to those of the fp32 engine
+    sp, spr = oa.SelfPlay(eng), oa.SelfPlay(ref)
+    for s in (sp, spr):
+        s.reset()
+        for _ in range(2):
+            s.execute(32, 8, 0.25, 0.03)
+            s.sample_actions(1.0, 30)
+            s.advance()
+    for g in range(4):
+        for side in (0, 1):
+            (ai, af), (bi, bf) = sp.tree_dump(g, side), spr.tree_dump(g, side)
+            assert np.array_equal(ai, bi) and np.array_equal(af.view(np.uint32), bf.view(np.uint32)), (g, side)
+    ref.close()
+    eng.load_weights(base)  # (c)
+    st = eng.stats()
+    assert B.FC0_FORMATS[int(st["fc0_format"])] == fmt0 and int(st["probe_outside"]) in (0, 1)
+    p1, v1 = eng.evaluate_pv(x)
+    assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32)) and np.array_equal(v0.view(np.uint32), v1.view(np.uint32))
+    eng.close()

@@ -18,6 +18,8 @@ with tempfile.TemporaryDirectory() as d:
     for i in range(its):
         t.train(1, log=lambda s: print(s, flush=True))
         lp = t.last_precision
-        print(f"  iteration {i + 1}: format {lp['fc0_format']}; probe fp6 |dp| {lp['probe_fp6'][0]:.2e} |dv| {lp['probe_fp6'][1]:.2e}, f16 {lp['probe_f16'][0]:.2e} / {lp['probe_f16'][1]:.2e}; "
-              f"replay rows vs fp32 kernels: |dp| {lp['max_dp']:.2e} |dv| {lp['max_dv']:.2e} (|logit| max {lp['logit_abs_max']:.1f}) within contract: {lp['within_contract']}", flush=True)
+        ck = lp.get("check", {})
+        print(f"  iteration {i + 1}: format {lp['fc0_format']} (probe verdict {lp['probe_outside']}); probe fp6 |dp| {lp['probe_fp6'][0]:.2e} |dv| {lp['probe_fp6'][1]:.2e}, f16 {lp['probe_f16'][0]:.2e} / {lp['probe_f16'][1]:.2e}; "
+              f"replay rows vs fp32 kernels in format {ck.get('fc0_format')}: |dp| {ck.get('max_dp', float('nan')):.2e} |dv| {ck.get('max_dv', float('nan')):.2e} "
+              f"(|logit| max {ck.get('logit_abs_max', float('nan')):.1f}) within contract: {ck.get('within_contract')}", flush=True)
     t.close()
