@@ -1667,6 +1667,10 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
 #endif
 #if SIB2_EXP == 4
 #define ROW_STORE(V, P) (*(P) = (V))
+#elif SIB2_EXP == 12 // (timing only: everything of the store phase -- staging, read-back, addresses -- except the store instructions themselves)
+#define ROW_STORE(V, P) do { const uint4 v_ = (V); const uint4* p_ = (P); asm volatile("" ::"v"(v_.x), "v"(v_.y), "v"(v_.z), "v"(v_.w), "v"(p_)); } while (0)
+#elif SIB2_EXP == 13 // (timing only: every store goes to the first row of the wave's workgroup: the instructions without their HBM traffic)
+#define ROW_STORE(V, P) nt_store((V), d_rows + ((size_t)blockIdx.x * 2048 + (size_t)((P) - d_rows) % 2048))
 #else
 #define ROW_STORE(V, P) nt_store((V), (P))
 #endif
@@ -3756,6 +3760,16 @@ static void launch_trunk_fmt(Net& net, const Store& S, int max_count, hipStream_
     else launch_trunk<N, FROM_F32, ABL>(net, S, max_count, st, row_list, d_nrows, d_out_base, d_nrows2, v2);
 }
 
+// ring depth of the full-round fc1 / heads launches and a raised wave priority around their MFMA blocks (A-B knobs: same arithmetic, same bits)
+#ifndef FC1_NST
+#define FC1_NST 3
+#endif
+#ifndef HEADS_NST
+#define HEADS_NST 3
+#endif
+#ifndef TAIL_PRIO
+#define TAIL_PRIO 0
+#endif
 template <int MT, int EPI, int TAG, int NST = 3, int PRIO = 0>
 static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_row_u4, int k_full, int last_cnt, int lo_off,
                         const float* bias, void* out_split, size_t out_row_u4, float* out_logits, const Store& S, int max_count,
@@ -4116,8 +4130,8 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     const size_t cap_t = (size_t)tiles_t * GT_BS;
     const size_t fin_threads = (size_t)max_count * 64;
     if (tsplit == 1) {
-        launch_gemm<16, EPI_SPLIT, 1>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st, net.device);
-        if (MT == 8) launch_gemm<8, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
+        launch_gemm<16, EPI_SPLIT, 1, FC1_NST, TAIL_PRIO>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st, net.device);
+        if (MT == 8) launch_gemm<8, EPI_LOGITS, 2, HEADS_NST, TAIL_PRIO>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
         else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
     } else {
         launch_gemm<16, EPI_PARTIAL, 1>(net.wt_fc1, h0, 32 / tsplit, 128, 32, 1, 2, bias_fc1, nullptr, cap_t, net.part, S, max_count, st, net.device, tsplit);
