@@ -1921,12 +1921,15 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
     uint4 bs_hi[2][4], bs_lo[2];
     uint2 bs_lt[2];
     uint32_t bs_sc[2];
-    auto base_fetch = [&](const uint4* frow, int px) {
+    auto base_fetch = [&](const uint4* frow, int px, int (&cpx4)[4]) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const uint4* bp = frow + (size_t)((px >> 5) * 2 + q) * BLK_U4;
 #pragma unroll
-            for (int p4 = 0; p4 < 4; ++p4) bs_hi[q][p4] = bp[(px & 31) * 8 + p4 * 2 + h];
+            for (int p4 = 0; p4 < 4; ++p4) {
+                if (SIB2_EXP == 14) bs_hi[q][p4] = (frow + (size_t)((cpx4[p4] >> 5) * 2 + q) * BLK_U4)[(cpx4[p4] & 31) * 8 + (lane & 7)]; // (timing only: whole lines per load)
+                else bs_hi[q][p4] = bp[(px & 31) * 8 + p4 * 2 + h];
+            }
             if (F16LO) continue;
             const uint4* lp = bp + OP_LO_U4 + (px & 31) * 4;
             bs_lo[q] = lp[h];
@@ -1951,13 +1954,16 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
                 }
             }
     };
-    auto base_sub_f16lo = [&](f32x16 (&x)[4], const uint4* frow, int px) {
+    auto base_sub_f16lo = [&](f32x16 (&x)[4], const uint4* frow, int px, int (&cpx4)[4]) {
         uint4 lo[2][4];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const uint4* bp = frow + (size_t)((px >> 5) * 2 + q) * BLK_U4 + OP_LO_U4;
 #pragma unroll
-            for (int p4 = 0; p4 < 4; ++p4) lo[q][p4] = bp[(px & 31) * 8 + p4 * 2 + h];
+            for (int p4 = 0; p4 < 4; ++p4) {
+                if (SIB2_EXP == 14) lo[q][p4] = (frow + (size_t)((cpx4[p4] >> 5) * 2 + q) * BLK_U4 + OP_LO_U4)[(cpx4[p4] & 31) * 8 + (lane & 7)];
+                else lo[q][p4] = bp[(px & 31) * 8 + p4 * 2 + h];
+            }
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) sub_pieces(x, q, bs_hi[q]);
@@ -2058,6 +2064,22 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
             ring_at(RING_B(OL()), wyB, wxB);
             bpxB = (wy0 + wyB) * N + wx0 + wxB;
         }
+        // SIB2_EXP == 14 (timing only, wrong data): every base load covers WHOLE 128-B lines -- lanes 8 p' .. 8 p' + 7 read the eight pieces of pixel 8 i + p' (instruction i of
+        // a group of four) instead of each lane reading one piece of its own pixel: the same bytes and lines per group, each line touched by ONE instruction
+        int cpxA[4] = {0, 0, 0, 0}, cpxB[4] = {0, 0, 0, 0};
+        if (SIB2_EXP == 14) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int t = 8 * i + (lane >> 3);
+                asm volatile("" : "+v"(t));
+                const int ta = t < V2_TPX ? t : V2_TPX - 1;
+                cpxA[i] = (vy0 + ta / V2_TW) * N + vx0 + ta % V2_TW;
+                int wy, wx;
+                ring_at(t < V2_RING ? t : V2_RING - 1, wy, wx);
+                cpxB[i] = (wy0 + wy) * N + wx0 + wx;
+            }
+        }
+#define GIDX(BLK, KIND, RING, G) (SIB2_EXP == 14 ? ((size_t)((BLK) * 2 + (KIND)) * HW + ((RING) ? cpxB[G] : cpxA[G])) * 8 + (lane & 7) : sib2_grid(HW, BLK, KIND, (RING) ? bpxB : bpxA, G, h))
 
         const int slot = bin_start[slot_c >> 24] + (int)(slot_c & 0xFFFFFFu);
         uint4* crow_p = d_rows + (size_t)slot * DROW_U4;
@@ -2163,7 +2185,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
             for (int g = 0; g < 4; ++g) {
                 hb[g] = make_uint4(0u, 0u, 0u, 0u);
                 if (at_p0) hb[g] = sb[sib2_grid(HW, 0, 0, bpxA, g, h)];
-                db[g] = sb[sib2_grid(HW, 0, 1, bpxA, g, h)];
+                db[g] = sb[GIDX(0, 1, false, g)];
             }
             f32x16 acc;
             L0_tile(x, blk0, acc);
@@ -2202,8 +2224,8 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
             uint4 hb[4], db[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                hb[g] = sb[sib2_grid(HW, 1, 0, bpxA, g, h)];
-                db[g] = sb[sib2_grid(HW, 1, 1, bpxA, g, h)];
+                hb[g] = sb[GIDX(1, 0, false, g)];
+                db[g] = sb[GIDX(1, 1, false, g)];
             }
             f32x16 acc;
             L0_tile(x, blk1, acc);
@@ -2222,9 +2244,9 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
             uint4 hb[4], db[4], dbB[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                hb[g] = sb[sib2_grid(HW, 2, 0, bpxA, g, h)];
-                dbB[g] = sb[sib2_grid(HW, 2, 1, bpxB, g, h)];
-                db[g] = sb[sib2_grid(HW, 2, 1, bpxA, g, h)];
+                hb[g] = sb[GIDX(2, 0, false, g)];
+                dbB[g] = sb[GIDX(2, 1, true, g)];
+                db[g] = sb[GIDX(2, 1, false, g)];
             }
             f32x16 acc;
             L0_tile(x, blk2, acc);
@@ -2269,7 +2291,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
             strip_dw(dwt, db);
         }
         TP(4);
-        base_fetch(frow, bpxA);
+        base_fetch(frow, bpxA, cpxA);
         L1L2_tile(x, blk2, d);
         TP(5);
         {
@@ -2283,7 +2305,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
                 rd_px[i] = (oy + tc / V2_TW) * SIB_WIN + ox + tc % V2_TW;
                 rd_ok[i] = t < V2_TPX;
             }
-            if constexpr (F16LO) base_sub_f16lo(x, frow, bpxA);
+            if constexpr (F16LO) base_sub_f16lo(x, frow, bpxA, cpxA);
             else base_subtract(x);
             if (lane == 0) slot_desc[slot] = make_uint2((uint32_t)crow, ent.y);
             TP(6);
@@ -2295,11 +2317,17 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = __builtin_bit_cast(f32x4, sb[sib2_x2(HW, bpxB, m, g, h)]);
+                size_t xi = sib2_x2(HW, bpxB, m, g, h);
+                if (SIB2_EXP == 14) { // (two pixels x 512 B per instruction; the ring's 24 pixels take 12 of the 16, the last four repeat)
+                    int t = 2 * (4 * m + g) + (lane >> 5);
+                    t = t < V2_RING ? t : V2_RING - 1;
+                    xi = (size_t)48 * HW + (size_t)cpxB[(t >> 3) & 3] * 32 + (lane & 31); // (pixel 8 i + p' of the table; the pixel within the group is that of lane t & 7 -- close enough for timing)
+                }
+                const f32x4 v = __builtin_bit_cast(f32x4, sb[xi]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[m][4 * g + i] = v[i];
             }
-        base_fetch(frow, bpxB);
+        base_fetch(frow, bpxB, cpxB);
 #pragma unroll
         for (int i = 0; i < 16; ++i) d[i] = dBk[i];
         TP(8);
@@ -2317,7 +2345,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
                 rd_px[i] = wy * SIB_WIN + wx;
                 rd_ok[i] = t < V2_RING;
             }
-            if constexpr (F16LO) base_sub_f16lo(x, frow, bpxB);
+            if constexpr (F16LO) base_sub_f16lo(x, frow, bpxB, cpxB);
             else base_subtract(x);
             TP(10);
             store_rows(x, crow_p, (OL() & 31) < V2_RING, rd_px, rd_ok);
@@ -2338,6 +2366,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
 #undef ROW_STORE
 #undef TILE_A
 #undef RING_B
+#undef GIDX
 // ===============================================================================================
 // OMOK_NET_F16X3: fc0 with block-scaled fp6 (or fp8) correction terms
 // ===============================================================================================

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 evidence on the GPU box (run from the repo root): tools/collect_r04.sh gpurun_out/r04 [part...]   parts: tests bench pmc c3 misc (default: all)
-out=${1:-gpurun_out/r04}; shift; parts=${@:-tests bench pmc c3 misc driver}; mkdir -p $out; R=$PWD
+# Round-5 evidence on the GPU box (run from the repo root): tools/collect_r05.sh gpurun_out/r05 [part...]   parts: tests bench pmc c3 misc (default: all)
+out=${1:-gpurun_out/r05}; shift; parts=${@:-tests bench pmc c3 misc driver}; mkdir -p $out; R=$PWD
 has() { [[ " $parts " == *" $1 "* ]]; }
 if has tests; then
   echo "[tests]"; python -m pytest tests -q -m gpu -s > $out/gputests_full.log 2>&1; tail -2 $out/gputests_full.log
