@@ -151,6 +151,7 @@ pub mod ffi {
         pub fn omok_debug_operand_rows(e: *mut OmokEngine, first_row: i32, rows: i32, out: *mut c_void) -> c_int;
         pub fn omok_debug_set_base_cache(e: *mut OmokEngine, enabled: i32) -> c_int;
         pub fn omok_debug_set_children_kernel(e: *mut OmokEngine, which: i32) -> c_int;
+        pub fn omok_debug_set_window_rects(e: *mut OmokEngine, enabled: i32) -> c_int;
         pub fn omok_get_stats(e: *mut OmokEngine, stats: *mut f64) -> c_int;
         pub fn omok_reset_stats(e: *mut OmokEngine) -> c_int;
         pub fn omok_set_profiling(e: *mut OmokEngine, enabled: i32) -> c_int;

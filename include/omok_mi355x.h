@@ -259,6 +259,10 @@ int omok_debug_set_base_cache(omok_engine* e, int32_t enabled);
  * OMOK_SIB_V2=0 at omok_create selects 1 as the engine's default.  In the MIXED operand format (the usual outcome of omok_net_commit's probe) only k_sib_children2 writes
  * the fp6 difference rows: which = 1 then returns OMOK_ERR_STATE instead of silently changing nothing (use OMOK_NET_F16X3_FP6 / _F16 engines for an A-B run). */
 int omok_debug_set_children_kernel(omok_engine* e, int32_t which);
+/* Debugging aid: enabled = 0 makes the fc0 window tiles of sibling rounds walk the whole 7x7 window of their bin instead of the rectangle of window pixels their rows can
+ * differ in (a child differs from its base only within its stone's pixel +- 3 clipped to the board; outside that region its difference row holds exact zeros).
+ * Results must not change by a bit (tests): skipped pixels contribute exact zeros. */
+int omok_debug_set_window_rects(omok_engine* e, int32_t enabled);
 
 #define OMOK_STAT_SIMS 0        /* simulations run (incl. terminal hits / no-action sims) */
 #define OMOK_STAT_EVALS 1       /* net evaluations (search requests + mirror evals + root) */

@@ -140,6 +140,10 @@ class Engine:
     def set_base_cache(self, on=True):
         self._chk(B.lib().omok_debug_set_base_cache(self.h, int(bool(on))))
 
+    def set_window_rects(self, on=True):
+        """False: fc0 window tiles walk their bin's whole 7x7 window instead of the rectangle their rows can differ in (same bits: tests)."""
+        self._chk(B.lib().omok_debug_set_window_rects(self.h, int(bool(on))))
+
     def set_children_kernel(self, which=2):
         """2: k_sib_children2 (default), 1: k_sib_children on the difference path of sibling rounds (A-B / tests)."""
         self._chk(B.lib().omok_debug_set_children_kernel(self.h, int(which)))

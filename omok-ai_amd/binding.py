@@ -30,7 +30,7 @@ SYMBOLS = [
     "omok_round_eval", "omok_round_outputs", "omok_round_logits", "omok_round_inject", "omok_round_scatter", "omok_mirror_generate",
     "omok_mirror_inputs", "omok_mirror_eval", "omok_mirror_outputs", "omok_mirror_inject", "omok_mirror_apply",
     "omok_alive_count", "omok_current_ply", "omok_game_info", "omok_tree_dump", "omok_tree_root", "omok_replay_game",
-    "omok_operand_row_bytes", "omok_debug_operand_rows", "omok_debug_set_base_cache", "omok_debug_set_children_kernel",
+    "omok_operand_row_bytes", "omok_debug_operand_rows", "omok_debug_set_base_cache", "omok_debug_set_children_kernel", "omok_debug_set_window_rects",
     "omok_replay_pack_dev", "omok_replay_record_bytes", "omok_replay_augment_dev", "omok_replay_augmented_game", "omok_get_stats", "omok_reset_stats", "omok_set_profiling",
 ]
 
@@ -87,6 +87,7 @@ def lib():
     L.omok_debug_operand_rows.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p]
     L.omok_debug_set_base_cache.argtypes = [H, C.c_int32]
     L.omok_debug_set_children_kernel.argtypes = [H, C.c_int32]
+    L.omok_debug_set_window_rects.argtypes = [H, C.c_int32]
     L.omok_set_episode.argtypes = [H, C.c_uint64]
     L.omok_env_place_stone.argtypes = [H, u8p, u8p, C.POINTER(C.c_uint16), ip, C.c_int32, ip]
     L.omok_compute_policy.argtypes = [H, fp, u8p]

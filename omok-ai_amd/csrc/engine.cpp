@@ -1378,6 +1378,12 @@ extern "C" int omok_debug_set_base_cache(omok_engine* e, int32_t enabled) {
     return OMOK_OK;
 }
 
+extern "C" int omok_debug_set_window_rects(omok_engine* e, int32_t enabled) {
+    if (!e) return OMOK_ERR_INVALID;
+    e->net.win_rects = enabled != 0;
+    return OMOK_OK;
+}
+
 extern "C" int omok_debug_set_children_kernel(omok_engine* e, int32_t which) {
     if (!e) return OMOK_ERR_INVALID;
     if (which != 1 && which != 2) return fail(e, OMOK_ERR_INVALID, "children kernel %d (1 = k_sib_children, 2 = k_sib_children2)", which);

@@ -63,8 +63,8 @@ struct Net {
     float* sib_h = nullptr;     // [run][3 blocks][225][32] the base passes' depthwise inputs
     // difference path: a child's fc0 input = its run's base row + a 7x7-window difference row
     uint32_t* d_sib_slot = nullptr;  // per row inside a run: window bin << 24 | rank inside the bin
-    int32_t* d_bin_start = nullptr;  // first slot of every bin (bins padded to whole 128-sample tiles); [81] = the single rows
-    int32_t* d_tile_info = nullptr;  // per fc0 window tile: bin | live slots << 8
+    int32_t* d_bin_start = nullptr;  // [pixel] first slot of the children whose stone lands in that net pixel (a bin's pixels in row-major order, bins padded to whole 128-sample tiles)
+    int32_t* d_tile_info = nullptr;  // per fc0 window tile: bin | live slots << 8 | the rectangle of window pixels its rows can differ in (y0 << 16 | y1 << 19 | x0 << 22 | x1 << 25)
     void* d_slot_desc = nullptr;     // per slot: (request row, full-row index of its base / of itself)
     void* d_rows = nullptr;          // [slot][2 q][49 window pixels] f16 parts, then residual parts: the difference rows
     size_t d_slots = 0;              // slots allocated
@@ -81,6 +81,7 @@ struct Net {
     int fill_side = 0, fill_k = 0;   // ... for this side's trees and this K: a forward that does not group after all writes the list itself (launch_fill)
     double children_launches[2] = {0.0, 0.0}; // sibling rounds by children kernel: [0] k_sib_children2, [1] k_sib_children
     bool sib_v2 = true;              // difference path: k_sib_children2 (one wave per child, growing windows) and the base-slot layout it reads
+    bool win_rects = true;           // fc0 window tiles walk only the rectangle of window pixels their rows can differ in (k_bin_prefix); false (omok_debug_set_window_rects): the whole 7x7 window -- same bits
     bool base_cache = true;          // false (omok_debug_set_base_cache): every run's base is evaluated in full every round (A-B check: same p / v bit for bit)
     bool sib_cache_valid = false;    // false: the trees changed outside the search rounds (reset, advance, refill): tags are cleared first
     float* part_w = nullptr;         // fp32 partials of the K-split window tiles: [7][part_w_rows][512]
@@ -134,7 +135,8 @@ bool net_logits_cover_batch(const Net& net, int max_count);
 // true if net_forward_requests(net, S, max_count, ..., sibling_side >= 0) will group the requests by parent (k_group): the caller may then hand
 // the zeroing of net.d_gcnt and the request-list fill to it (Net::gcnt_zeroed, Net::fill_in_group)
 bool net_round_takes_sibling_path(const Net& net, int max_count);
-constexpr int NET_GCNT_INTS = 8 + 81 + 7 + 16; // ints of Net::d_gcnt
+constexpr int NET_GCNT_P0 = 8 + 81 + 7 + 16;   // Net::d_gcnt[NET_GCNT_P0 + pixel]: children whose stone lands in net pixel `pixel` (their rows take consecutive slots inside the window bin)
+constexpr int NET_GCNT_INTS = NET_GCNT_P0 + 225; // ints of Net::d_gcnt
 // skip_softmax (split-precision modes only): stop behind the heads; the caller turns net_logits() into p / v itself (launch_softmax_scatter).
 void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, struct Prof* prof, int sibling_side = -1, bool skip_softmax = false);
 // Forward of explicit f32 inputs already in net.in_f32 ([count][3HW]); count is a host value

@@ -851,8 +851,8 @@ __device__ inline void sib_window(int n, int action, int& wy0, int& wx0) { // th
 
 // cnt[0] runs, cnt[1] rows outside runs, cnt[2] rows inside runs.  sib_rows[i] = descriptor of a row inside a run: (request row, run
 // index, node record index t * stride_nodes + node, turn | action << 8); a run's rows are adjacent.
-// sib_slot[i] (difference path, else NULL) = window bin << 24 | rank of the row among the bin's rows (any order: a row's result does not
-// depend on its slot).
+// sib_slot[i] (difference path, else NULL) = net pixel of the child's stone (P0) << 24 | rank of the row among that pixel's rows (any order: a row's
+// result does not depend on its slot).
 // One wave per tree, GROUP_TREES trees per workgroup: the workgroup counts in LDS and claims its ranges of the global lists with one
 // atomic per counter (per-row atomics on 3 + 81 addresses serialised in L2: 0.24 ms per round).
 constexpr int GROUP_TREES = 16;
@@ -862,10 +862,11 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
     // Difference path (sib_slot != NULL): base slots.  The FIRST run of a tree uses one of the game's SIB_WAYS slots (SIB_WAYS g + way), whose content is
     // reused while a tag names the run's parent (a leaf is its tree's expansion target for ~14 rounds); further runs of the tree in the same
     // round (rare) take a slot behind the games' and are always evaluated.  comp[] lists the (first request row, slot) pairs to evaluate.
-    __shared__ int l_cnt[3 + SIB_BINS + 2], l_base[3 + SIB_BINS + 2];
+    constexpr int NP0 = 225, LC = 3 + NP0 + 2; // runs, singles, rows in runs | children per net pixel of their stone (P0) | full evaluations, uncacheable runs
+    __shared__ int l_cnt[LC], l_base[LC];
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = blockIdx.x * GROUP_TREES + (tid >> 6);
-    if (tid < 3 + SIB_BINS + 2) l_cnt[tid] = 0;
+    if (tid < LC) l_cnt[tid] = 0;
     __syncthreads();
     int n = 0;
     TreeState ts{};
@@ -923,7 +924,7 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
                         way = __ffs((int)~used) - 1;
                     }
                     hit = SIB_WAYS - 1;
-                    mi = atomicAdd(&l_cnt[3 + SIB_BINS], 1);
+                    mi = atomicAdd(&l_cnt[3 + NP0], 1);
                 }
                 if (hit > 0 || mi >= 0) { // move to the front
 #pragma unroll
@@ -935,8 +936,8 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
                 }
                 bslot = SIB_WAYS * g + way;
             } else {
-                ex = atomicAdd(&l_cnt[3 + SIB_BINS + 1], 1);
-                mi = atomicAdd(&l_cnt[3 + SIB_BINS], 1);
+                ex = atomicAdd(&l_cnt[3 + NP0 + 1], 1);
+                mi = atomicAdd(&l_cnt[3 + NP0], 1);
             }
         }
     }
@@ -944,21 +945,21 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
     rbase = __shfl(rbase, rs, 64);
     if (in_run) {
         if (sib_slot) {
-            int wy0, wx0;
-            sib_window(bn, (int)(ta >> 8), wy0, wx0);
-            bin = wy0 * SIB_ORG + wx0;
+            // slots are handed out per net PIXEL of the child's stone (P0), not per window bin: a bin's rows are then ordered by P0, and an fc0 window tile
+            // only has to walk the window pixels its own rows can differ in (k_bin_prefix: the tile's rectangle)
+            bin = (2 * (int)(ta >> 8) + 1) / 3;
             rank = atomicAdd(&l_cnt[3 + bin], 1);
         }
     } else if (lane < n) sidx = atomicAdd(&l_cnt[1], 1);
     __syncthreads();
-    if (tid < 3 + SIB_BINS + 2 && l_cnt[tid] > 0 && (tid < 3 || sib_slot))
-        l_base[tid] = atomicAdd(&cnt[tid < 3 ? tid : (tid < 3 + SIB_BINS ? 8 + (tid - 3) : 96 + (tid - 3 - SIB_BINS))], l_cnt[tid]);
+    if (tid < LC && l_cnt[tid] > 0 && (tid < 3 || sib_slot))
+        l_base[tid] = atomicAdd(&cnt[tid < 3 ? tid : (tid < 3 + NP0 ? NET_GCNT_P0 + (tid - 3) : 96 + (tid - 3 - NP0))], l_cnt[tid]);
     __syncthreads();
     if (start && len >= SIB_MIN) {
         groups[l_base[0] + gslot] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)len);
         if (sib_slot) {
-            if (ex >= 0) bslot = SIB_WAYS * S.games + l_base[3 + SIB_BINS + 1] + ex;
-            if (mi >= 0) comp[l_base[3 + SIB_BINS] + mi] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)bslot);
+            if (ex >= 0) bslot = SIB_WAYS * S.games + l_base[3 + NP0 + 1] + ex;
+            if (mi >= 0) comp[l_base[3 + NP0] + mi] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)bslot);
         }
     }
     bslot = __shfl(bslot, rs, 64);
@@ -971,31 +972,64 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
 
 // Difference path: slots.  Every bin's rows get consecutive slots, bins padded to whole 128-sample fc0 tiles (a tile's super-steps are
 // its bin's window); the single rows are bin SIB_BINS (no window: their tiles only run the epilogue on their own full row).
-// Bins are laid out large to small (corner windows collect 16 board pixels each, edge windows 4, interior ones 1; singles last).
-// All tiles cost the same, so T tiles take ceil(T / CUs) rounds of workgroups: the tiles of the last, partial round are instead
+// Bins are laid out DEAREST FIRST (round 5): interior bins (one P0 each: the whole 7x7 window differs), edge bins (4 P0s, rectangles of 28 .. 49 pixels), corner bins
+// (16 P0s, 16 .. 49 pixels), then a tail of interior bins for the K-split set, the single rows last (sib_bin_at).  The whole-K launch deals its tiles in rounds of n_cu workgroups (position p = round * n_cu + xcd * n_cu / 8 + i, an
+// XCD's chunk of a round = consecutive tiles = a few bins' weight slices through one L2), so round 1 holds the full-price tiles and a CU's second tile is a cheap
+// one: the 18 % of window pixels the rectangles skip then shorten the launch (in the old corner-first order with an eighth of the tiles per XCD, the XCDs of the interior
+// bins ran two full-price tiles per CU and nothing was gained).  T tiles take ceil(T / CUs) rounds of workgroups: the tiles of the last, partial round are instead
 // split over K (cnt[6] ways, fp32 partials + k_win_finish), so that the round costs 1 / cnt[6] of a full one.  The split set is made of
 // WHOLE bins from the end of the layout (tiles >= cnt[5]): a row's bin -- unlike its slot -- is a function of the position alone, so
 // the summation order of a row never depends on the order in which k_group's atomics handed out the slots.
-__device__ inline int sib_bin_at(int pos) { // layout position -> bin
+__device__ inline int sib_bin_at(int pos, int bn) { // layout position -> bin: interior bins, edge bins, corner bins, a tail of interior bins, the single rows
     if (pos >= SIB_BINS) return SIB_BINS;
-    if (pos < 4) return (pos >> 1) * (SIB_ORG - 1) * SIB_ORG + (pos & 1) * (SIB_ORG - 1);            // corners
-    pos -= 4;
-    constexpr int E = SIB_ORG - 2; // 7 edge bins per side
+    constexpr int E = SIB_ORG - 2; // 7 edge bins per side, 7 x 7 interior bins
+    // the TAIL: small bins (one P0 each) at the end of the layout, so that the K-split set -- whole bins from the end, see below -- can be cut close to the partial round
+    // it covers (behind the corner bins it would start up to 55 tiles early).  N = 15: the interior bins of window rows 5..7; N = 9: its only interior bin
+    const int head = bn > 9 ? 4 * E : 0;
+    auto interior = [&](int i) { return (1 + i / E) * SIB_ORG + 1 + i % E; };
+    if (pos < head) return interior(pos);
+    pos -= head;
     if (pos < 4 * E) {
         const int sd = pos / E, i = 1 + pos % E;
         return sd == 0 ? i : sd == 1 ? (SIB_ORG - 1) * SIB_ORG + i : sd == 2 ? i * SIB_ORG : i * SIB_ORG + SIB_ORG - 1;
     }
     pos -= 4 * E;
-    return (1 + pos / E) * SIB_ORG + 1 + pos % E;                                                      // interior
+    if (pos < 4) return (pos >> 1) * (SIB_ORG - 1) * SIB_ORG + (pos & 1) * (SIB_ORG - 1);              // corners
+    return interior(head + pos - 4);
 }
-__global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, int32_t* __restrict__ bin_start, int32_t* __restrict__ tile_info,
-                                                    uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu, int max_fways,
-                                                    int max_wways, int part_w_rows, int facc_single_base, int part_f_rows, int nsup_full) {
-    __shared__ int tile0[SIB_BINS + 2], binc[SIB_BINS + 1], order[SIB_BINS + 1], start_at[SIB_BINS + 2];
+// Round 5: a bin's rows are ordered by the net pixel P0 of their stone (k_group hands out slots per P0), and a child's trunk output differs from its base's only within
+// P0 +- 3 CLIPPED TO THE BOARD -- for the 176 of 225 pixels near an edge that is less than the 7x7 window the bin shares (a corner bin collects 16 pixels whose
+// regions run from 4x4 to 7x7).  k_sib_children2 writes exact zeros outside a child's own region, so a tile may skip every window pixel outside the union of its rows'
+// regions: tile_info carries that rectangle (window coordinates), fc0 walks rect pixels only -- 19 % fewer window super-steps at N = 15, 31 % at N = 9.  Zero pixels
+// contribute exact zeros and the rectangle is walked row-major, so a row's sum does not depend on which rectangle its tile got (slots still come from atomics).
+// Tiles of the K-split set keep the full window (their split boundaries are positions in the 98 super-steps).
+__device__ inline void sib_p0_range(int bn, int o, int& lo, int& hi) { // net-pixel rows (columns) whose 7-wide window starts at origin o
+    lo = o == 0 ? 0 : o + SIB_WIN / 2;
+    hi = o == bn - SIB_WIN ? bn - 1 : o + SIB_WIN / 2;
+}
+constexpr int BP_THREADS = 256, BP_MAXT = 2048; // k_bin_prefix: threads, tiles of the whole-K launch it can order by cost (more: layout order)
+__global__ __launch_bounds__(BP_THREADS) void k_bin_prefix(int32_t* __restrict__ cnt, int32_t* __restrict__ bin_start, int32_t* __restrict__ tile_info,
+                                                           uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu, int max_fways,
+                                                           int max_wways, int part_w_rows, int facc_single_base, int part_f_rows, int nsup_full, int bn, int use_rects, int tile_cap) {
+    __shared__ unsigned char cost[BP_MAXT];
+    __shared__ int hist[64], bstart[64];
+    __shared__ int tile0[SIB_BINS + 2], binc[SIB_BINS + 1], bcnt[SIB_BINS + 1], order[SIB_BINS + 1], start_at[SIB_BINS + 2], p0c[225], p0o[225], s_split, s_ntiles;
     const int tid = threadIdx.x;
-    const int c = tid < SIB_BINS ? cnt[8 + tid] : (tid == SIB_BINS ? cnt[1] : 0);
-    if (tid <= SIB_BINS) { binc[tid] = (c + GT_BS - 1) / GT_BS; order[tid] = sib_bin_at(tid); } // (tiles per bin and the layout order in parallel:
-    __syncthreads();                                                                                    //  the serial part below only adds)
+    for (int i = tid; i < 225; i += blockDim.x) p0c[i] = i < bn * bn ? cnt[NET_GCNT_P0 + i] : 0;
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    int c = 0, oy = 0, ox = 0, ylo = 0, yhi = -1, xlo = 0, xhi = -1;
+    if (tid < SIB_BINS) {
+        oy = tid / SIB_ORG; ox = tid % SIB_ORG;
+        if (oy <= bn - SIB_WIN && ox <= bn - SIB_WIN) {
+            sib_p0_range(bn, oy, ylo, yhi);
+            sib_p0_range(bn, ox, xlo, xhi);
+        }
+        for (int y = ylo; y <= yhi; ++y)
+            for (int x = xlo; x <= xhi; ++x) { p0o[y * bn + x] = c; c += p0c[y * bn + x]; } // (offset of the P0's rows inside the bin: row-major P0 order)
+    } else if (tid == SIB_BINS) c = cnt[1];
+    if (tid <= SIB_BINS) { bcnt[tid] = c; binc[tid] = (c + GT_BS - 1) / GT_BS; order[tid] = sib_bin_at(tid, bn); } // (tiles per bin and the layout order in parallel:
+    __syncthreads();                                                                                                     //  the serial part below only adds)
     if (tid == 0) {
         int t = 0;
         for (int pos = 0; pos <= SIB_BINS; ++pos) { // (counts from LDS: 82 serial global loads were most of this kernel's 16 us)
@@ -1004,6 +1038,7 @@ __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, i
             start_at[pos] = t;
             t += binc[b];
         }
+        start_at[SIB_BINS + 1] = t;
         const int ntiles = t;
         int t_split = ntiles - (ntiles < n_cu ? ntiles : ntiles % n_cu); // first tile of the partial round ...
         int first = ntiles;
@@ -1032,11 +1067,87 @@ __global__ __launch_bounds__(128) void k_bin_prefix(int32_t* __restrict__ cnt, i
         cnt[4] = ntiles;
         cnt[5] = t_split;
         cnt[6] = ways;
+        s_split = t_split;
+        s_ntiles = ntiles;
     }
     __syncthreads();
-    if (tid <= SIB_BINS) {
-        bin_start[tid] = tile0[tid] * GT_BS;
-        for (int t = 0; t * GT_BS < c; ++t) tile_info[tile0[tid] + t] = tid | ((c - t * GT_BS < GT_BS ? c - t * GT_BS : GT_BS) << 8);
+    constexpr int FULL_RECT = (0 << 16) | ((SIB_WIN - 1) << 19) | (0 << 22) | ((SIB_WIN - 1) << 25);
+    if (tid < SIB_BINS) {
+        cnt[8 + tid] = c; // (the bin's total: diagnostics)
+        const int off = tile0[tid] * GT_BS;
+        for (int y = ylo; y <= yhi; ++y)
+            for (int x = xlo; x <= xhi; ++x) bin_start[y * bn + x] = off + p0o[y * bn + x]; // first slot of the P0's rows
+    }
+    // one thread per tile: its bin (layout position by a search over start_at), its live slots, its rectangle = union of the regions (P0 +- 3, clipped to the board) of
+    // the P0s with rows in the tile, in window coordinates; cost = the rectangle's pixels
+    const int ntiles = s_ntiles, t_split = s_split;
+    for (int T = tid; T < ntiles; T += blockDim.x) {
+        int pos = 0;
+        for (int step = 64; step > 0; step >>= 1)
+            if (pos + step <= SIB_BINS && start_at[pos + step] <= T) pos += step;
+        const int b = order[pos], t = T - tile0[b], cb = bcnt[b];
+        const int lo = t * GT_BS, hi = cb - lo < GT_BS ? cb : lo + GT_BS;
+        int rect = FULL_RECT, area = b < SIB_BINS ? SIB_WPX : 1;
+        if (use_rects && b < SIB_BINS && T < t_split) {
+            const int by = b / SIB_ORG, bx = b % SIB_ORG;
+            int y0, y1, x0, x1;
+            sib_p0_range(bn, by, y0, y1);
+            sib_p0_range(bn, bx, x0, x1);
+            int ry0 = SIB_WIN, ry1 = -1, rx0 = SIB_WIN, rx1 = -1;
+            for (int y = y0; y <= y1; ++y)
+                for (int x = x0; x <= x1; ++x) {
+                    const int n = p0c[y * bn + x], o = p0o[y * bn + x];
+                    if (n > 0 && o < hi && o + n > lo) {
+                        const int a0 = (y - 3 < 0 ? 0 : y - 3) - by, a1 = (y + 3 > bn - 1 ? bn - 1 : y + 3) - by;
+                        const int c0 = (x - 3 < 0 ? 0 : x - 3) - bx, c1 = (x + 3 > bn - 1 ? bn - 1 : x + 3) - bx;
+                        ry0 = a0 < ry0 ? a0 : ry0; ry1 = a1 > ry1 ? a1 : ry1;
+                        rx0 = c0 < rx0 ? c0 : rx0; rx1 = c1 > rx1 ? c1 : rx1;
+                    }
+                }
+            if (ry1 >= ry0 && rx1 >= rx0 && ry0 >= 0 && rx0 >= 0 && ry1 < SIB_WIN && rx1 < SIB_WIN) {
+                rect = (ry0 << 16) | (ry1 << 19) | (rx0 << 22) | (rx1 << 25);
+                area = (ry1 - ry0 + 1) * (rx1 - rx0 + 1);
+            }
+        }
+        tile_info[T] = b | ((hi - lo) << 8) | rect;
+        if (T < t_split && T < BP_MAXT) { cost[T] = (unsigned char)area; atomicAdd(&hist[area], 1); }
+    }
+    __syncthreads();
+    // Order of the whole-K launch (tiles below t_split).  With rectangles a tile costs 16 .. 49 window pixels, and a launch of two rounds of workgroups takes as long as
+    // its slowest CU's two tiles: in layout order the CUs of the interior bins ran two full-price tiles and the 18 % of skipped work bought nothing.  The tiles are
+    // sorted by cost, descending and STABLY (a bin's tiles stay together: the workgroups of one XCD stream its weight slice together) -- a counting sort, one wave
+    // matching equal costs with ballots chunk by chunk -- and the launch deals positions in rounds of 8 x 32 workgroups, XCD x taking chunk x of even rounds and chunk
+    // 7 - x of odd ones (k_fc0_*): the CU with a full-price tile gets a cheap second one.  Best case with two whole tiles per CU: 49 + 35 of 98.
+    {
+        int* tile_order = tile_info + tile_cap;
+        __syncthreads();
+        const int n = t_split <= BP_MAXT ? t_split : 0;
+        if (tid == 0) {
+            int run = 0;
+            for (int a = 63; a >= 0; --a) { bstart[a] = run; run += hist[a]; }
+            cnt[7] = tile_cap;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const unsigned long long lt = (1ULL << tid) - 1ULL;
+            for (int c0 = 0; c0 < n; c0 += 64) {
+                const int T = c0 + tid, cT = T < n ? (int)cost[T] : -1;
+                unsigned long long todo = __ballot(T < n);
+                int pos = 0;
+                while (todo) {
+                    const int lead = __ffsll((long long)todo) - 1, lc = __shfl(cT, lead, 64);
+                    const unsigned long long m = __ballot(cT == lc);
+                    const int base = bstart[lc];
+                    if (cT == lc) pos = base + __popcll(m & lt);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (tid == lead) bstart[lc] = base + __popcll(m);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    todo &= ~m;
+                }
+                if (T < n) tile_order[pos] = T;
+            }
+        }
+        for (int T = n + tid; T < t_split; T += blockDim.x) tile_order[T] = T; // (n = 0: more tiles than the table holds)
     }
     const int nsing = cnt[1], s0 = tile0[SIB_BINS] * GT_BS;
     for (int i = tid; i < nsing; i += blockDim.x) slot_desc[s0 + i] = make_uint2((uint32_t)singles[i], (uint32_t)(facc_single_base + i)); // (fp32 fc0 row index)
@@ -1053,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_win_finish(const float* __restrict__ pa
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // (local slot, mt 16, s 2, h 2)
     const size_t local = i >> 6;
     const int tile = t0 + (int)(local / GT_BS);
-    if (tile >= nt || (int)(local % GT_BS) >= (tile_info[tile] >> 8)) return;
+    if (tile >= nt || (int)(local % GT_BS) >= ((tile_info[tile] >> 8) & 0xFF)) return;
     const uint2 dsc = slot_desc[(size_t)t0 * GT_BS + local];
     const int piece = (int)(i & 63), mt = piece >> 2, sx = (piece >> 1) & 1, h = piece & 1;
     const int n0 = 32 * mt + 16 * sx + 4 * h; // j = 0..3 -> n0 + j ; j = 4..7 -> n0 + 8 + (j - 4)
@@ -1823,7 +1934,10 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
         }
     };
     // difference-row entries of a tile's pixels: k_sib_children's store_rows<DELTA> (staging rows = this wave's cells 0..31)
-    auto store_rows = [&](const f32x16 (&x)[4], uint4* row, bool lane_valid, const int (&rd_px)[4], const bool (&rd_ok)[4]) {
+    // `far`: this lane's pixel lies outside the child's own region (P0 +- 3, clipped to the board -- at an edge that is less than the 7x7 window its bin shares): there the child
+    // equals its base, and the lane stores EXACT zeros instead of the base row's quantisation remainder (~2^-22 of the activation), so that an fc0 window tile may skip the pixel
+    // or not (k_bin_prefix: the tile's rectangle) without changing a bit of the row's sum.
+    auto store_rows = [&](const f32x16 (&x)[4], uint4* row, bool lane_valid, const int (&rd_px)[4], const bool (&rd_ok)[4], bool far) {
         const int lq = OL();
         uint4* stage_w = (uint4*)(wgrid + (lq & 31) * GRID_STRIDE);
         int rd_gi[4];
@@ -1846,7 +1960,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
                 for (int part = 0; part < 2; ++part) {
                     if (lane_valid) {
 #pragma unroll
-                        for (int p4 = 0; p4 < 4; ++p4) stage_w[p4 * 2 + h] = __builtin_bit_cast(uint4, part ? lo8[p4] : hi8[p4]);
+                        for (int p4 = 0; p4 < 4; ++p4) stage_w[p4 * 2 + h] = far ? make_uint4(0u, 0u, 0u, 0u) : __builtin_bit_cast(uint4, part ? lo8[p4] : hi8[p4]);
                     }
                     WAVE_LDS_FENCE();
 #pragma unroll
@@ -1882,7 +1996,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
                         asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax_v) : "v"(v0), "v"(v1));
                         asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax_l) : "v"(l0), "v"(l1));
                     }
-                    if (lane_valid) stage_w[(mm * 2 + sx) * 2 + h] = H.v;
+                    if (lane_valid) stage_w[(mm * 2 + sx) * 2 + h] = far ? make_uint4(0u, 0u, 0u, 0u) : H.v;
                 }
             WAVE_LDS_FENCE();
             int eh = (int)((__float_as_uint(amax_v * MX6_AMAX_ADJ) >> 23) & 0xFFu) - 2, el = (int)((__float_as_uint(amax_l * MX6_AMAX_ADJ) >> 23) & 0xFFu) - 2;
@@ -1893,6 +2007,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ev[i] = res[2 * i]; od[i] = res[2 * i + 1]; }
             lo6[q] = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, __uint_as_float((uint32_t)el << 23));
+            if (far) lo6[q] = (u32x6){0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint4 v = *(const uint4*)(wgrid + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
@@ -2309,7 +2424,14 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
             else base_subtract(x);
             if (lane == 0) slot_desc[slot] = make_uint2((uint32_t)crow, ent.y);
             TP(6);
-            store_rows(x, crow_p, (OL() & 31) < V2_TPX, rd_px, rd_ok);
+            bool farA;
+            {
+                int bq = bpxA;
+                asm volatile("" : "+v"(bq));
+                const int yA = bq / N, xA = bq - yA * N;
+                farA = yA - py > 3 || py - yA > 3 || xA - pxx > 3 || pxx - xA > 3;
+            }
+            store_rows(x, crow_p, (OL() & 31) < V2_TPX, rd_px, rd_ok, farA);
             TP(7);
         }
         // ---- the ring: residual stream of the BASE in front of block 2 + this child's depthwise outputs ----
@@ -2348,7 +2470,14 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
             if constexpr (F16LO) base_sub_f16lo(x, frow, bpxB, cpxB);
             else base_subtract(x);
             TP(10);
-            store_rows(x, crow_p, (OL() & 31) < V2_RING, rd_px, rd_ok);
+            bool farB;
+            {
+                int bq = bpxB;
+                asm volatile("" : "+v"(bq));
+                const int yB = bq / N, xB = bq - yB * N;
+                farB = yB - py > 3 || py - yB > 3 || xB - pxx > 3 || pxx - xB > 3;
+            }
+            store_rows(x, crow_p, (OL() & 31) < V2_RING, rd_px, rd_ok, farB);
         }
         load_conv_w();
         ent_c = ent_n;
@@ -2481,6 +2610,13 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     auto ring = [&](int slot) -> uint4* { return slot == 0 ? ldsW0 : slot == 1 ? ldsW1 : slot == 2 ? ldsW2 : ldsW3; };
     int b0 = blockIdx.x * GT_BS;
     int count, win_oy = 0, win_ox = 0, ubeg = 0, part_row0 = 0, split_y = (int)blockIdx.y;
+    int wr_y0 = 0, wr_x0 = 0, wr_w = SIB_WIN, wr_n = 2 * SIB_WPX, wr_inv = 65536 / SIB_WIN + 1;
+    auto win_u = [&](int j) { // WIN: super-step j of the tile's rectangle -> super-step u = 2 w + q of the 7x7 window (steps past the end -- prefetches -- re-read the last)
+        j = j < wr_n ? j : wr_n - 1;
+        j = j < 0 ? 0 : j;
+        const int wl = j >> 1, ry = (wl * wr_inv) >> 16, rx = wl - ry * wr_w;
+        return 2 * ((wr_y0 + ry) * SIB_WIN + wr_x0 + rx) + (j & 1);
+    };
     if (WIN) { // EPI_SPLIT: the tiles below the K-split set, whole K; EPI_PARTIAL: tile d_count[5] + blockIdx.x, K split d_count[6] ways over blockIdx.y
         // Workgroups go to the 8 XCDs round-robin and every XCD has its own L2: XCD x takes a contiguous eighth of the tiles (tiles are
         // ordered by bin = by weight slice), so the workgroups that share an L2 stream the same 9 MB of weights in step instead of
@@ -2498,14 +2634,23 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
             tile = t_split + item / ways;
             part_row0 = t_split * GT_BS;
             out_row_u4 = (size_t)n_here * GT_BS; // partials: [split][slot inside the split set]
-        } else {
-            tile = ((int)blockIdx.x & 7) * eighth + ((int)blockIdx.x >> 3);
-            if (((int)blockIdx.x >> 3) >= eighth || tile >= n_here) return;
+        } else { // position p of the cost-sorted order (k_bin_prefix), dealt in rounds of 8 x 32 workgroups: XCD x = blockIdx & 7 takes chunk x of an even round and chunk
+                 // 7 - x of an odd one (the XCD with the dearest tiles of round 1 gets the cheapest of round 2)
+            (void)eighth;
+            const int per_x = (int)gridDim.x >> 3, cu_x = per_x < 32 ? per_x : 32, j = (int)blockIdx.x >> 3, r = j / cu_x; // (32 CUs per XCD)
+            const int xc = (int)blockIdx.x & 7, p = r * (8 * cu_x) + ((r & 1) ? 7 - xc : xc) * cu_x + j % cu_x;
+            if (p >= n_here) return;
+            tile = tile_info[d_count[7] + p];
         }
         b0 = tile * GT_BS;
         const int ti = tile_info[tile], bin = ti & 0xFF;
-        count = b0 + (ti >> 8);
-        const int nsup = bin < SIB_BINS ? 2 * SIB_WPX : 0, per = (nsup + ways - 1) / ways;
+        count = b0 + ((ti >> 8) & 0xFF);
+        // the tile's rectangle of window pixels (k_bin_prefix): rows wr_y0 .. y1, columns wr_x0 .. x1 of the 7x7 window; super-step j of the tile = pixel j / 2 of the rectangle in
+        // row-major order, channel half j & 1
+        wr_y0 = (ti >> 16) & 7; wr_x0 = (ti >> 22) & 7; wr_w = ((ti >> 25) & 7) - wr_x0 + 1;
+        wr_n = 2 * (((ti >> 19) & 7) - wr_y0 + 1) * wr_w;
+        wr_inv = 65536 / wr_w + 1; // (j / 2) / wr_w = ((j / 2) * wr_inv) >> 16 for j / 2 < 49
+        const int nsup = bin < SIB_BINS ? wr_n : 0, per = (nsup + ways - 1) / ways;
         ubeg = split_y * per;
         ksup = nsup - ubeg < per ? nsup - ubeg : per;
         if (ksup < 0) ksup = 0;
@@ -2549,7 +2694,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     const int h = lane >> 5;
 
     auto uoff = [&](int u) { // (block, pixel) of super-step u inside a sample row, packed as block * 32 + pixel
-        if (WIN) return u < 2 * SIB_WPX ? u : 2 * SIB_WPX - 1; // difference rows: super-step u = 2 w + q itself (prefetches past the end re-read the last)
+        if (WIN) return win_u(u); // difference rows: super-step u = 2 w + q of the window
         const int full = full_tiles * 64;
         int tile, q, pl;
         if (u < full) { tile = u >> 6; q = (u >> 5) & 1; pl = u & 31; }
@@ -2559,7 +2704,7 @@ __global__ __launch_bounds__(256) void k_fc0_mx(const uint4* __restrict__ wp, co
     // absolute super-step (= weight stage group) of this workgroup's local super-step ul
     auto ustep = [&](int ul) {
         if (!WIN) return ubeg + ul;
-        const int u = ubeg + ul < 2 * SIB_WPX ? ubeg + ul : 2 * SIB_WPX - 1;
+        const int u = win_u(ubeg + ul);
         const int w = u >> 1, qq = u & 1, wy = w / SIB_WIN, wx = w - wy * SIB_WIN;
         const int px = (win_oy + wy) * bn + win_ox + wx;
         return px < full_tiles * 32 ? (px >> 5) * 64 + qq * 32 + (px & 31) : full_tiles * 64 + qq * last_cnt + (px - full_tiles * 32);
@@ -2861,6 +3006,13 @@ __global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, co
     // ---- which tile, which part of K: exactly k_fc0_mx's mapping ----
     int b0 = blockIdx.x * GT_BS;
     int count, win_oy = 0, win_ox = 0, ubeg = 0, part_row0 = 0, split_y = (int)blockIdx.y;
+    int wr_y0 = 0, wr_x0 = 0, wr_w = SIB_WIN, wr_n = 2 * SIB_WPX, wr_inv = 65536 / SIB_WIN + 1;
+    auto win_u = [&](int j) { // WIN: super-step j of the tile's rectangle -> super-step u = 2 w + q of the 7x7 window (steps past the end -- prefetches -- re-read the last)
+        j = j < wr_n ? j : wr_n - 1;
+        j = j < 0 ? 0 : j;
+        const int wl = j >> 1, ry = (wl * wr_inv) >> 16, rx = wl - ry * wr_w;
+        return 2 * ((wr_y0 + ry) * SIB_WIN + wr_x0 + rx) + (j & 1);
+    };
     if (WIN) {
         const int nt = d_count[4], t_split = d_count[5];
         const int n_here = EPI == EPI_PARTIAL ? nt - t_split : t_split, eighth = (n_here + 7) >> 3;
@@ -2874,14 +3026,23 @@ __global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, co
             tile = t_split + item / ways;
             part_row0 = t_split * GT_BS;
             out_row_u4 = (size_t)n_here * GT_BS;
-        } else {
-            tile = ((int)blockIdx.x & 7) * eighth + ((int)blockIdx.x >> 3);
-            if (((int)blockIdx.x >> 3) >= eighth || tile >= n_here) return;
+        } else { // position p of the cost-sorted order (k_bin_prefix), dealt in rounds of 8 x 32 workgroups: XCD x = blockIdx & 7 takes chunk x of an even round and chunk
+                 // 7 - x of an odd one (the XCD with the dearest tiles of round 1 gets the cheapest of round 2)
+            (void)eighth;
+            const int per_x = (int)gridDim.x >> 3, cu_x = per_x < 32 ? per_x : 32, j = (int)blockIdx.x >> 3, r = j / cu_x; // (32 CUs per XCD)
+            const int xc = (int)blockIdx.x & 7, p = r * (8 * cu_x) + ((r & 1) ? 7 - xc : xc) * cu_x + j % cu_x;
+            if (p >= n_here) return;
+            tile = tile_info[d_count[7] + p];
         }
         b0 = tile * GT_BS;
         const int ti = tile_info[tile], bin = ti & 0xFF;
-        count = b0 + (ti >> 8);
-        const int nsup = bin < SIB_BINS ? 2 * SIB_WPX : 0, per = (nsup + ways - 1) / ways;
+        count = b0 + ((ti >> 8) & 0xFF);
+        // the tile's rectangle of window pixels (k_bin_prefix): rows wr_y0 .. y1, columns wr_x0 .. x1 of the 7x7 window; super-step j of the tile = pixel j / 2 of the rectangle in
+        // row-major order, channel half j & 1
+        wr_y0 = (ti >> 16) & 7; wr_x0 = (ti >> 22) & 7; wr_w = ((ti >> 25) & 7) - wr_x0 + 1;
+        wr_n = 2 * (((ti >> 19) & 7) - wr_y0 + 1) * wr_w;
+        wr_inv = 65536 / wr_w + 1; // (j / 2) / wr_w = ((j / 2) * wr_inv) >> 16 for j / 2 < 49
+        const int nsup = bin < SIB_BINS ? wr_n : 0, per = (nsup + ways - 1) / ways;
         ubeg = split_y * per;
         ksup = nsup - ubeg < per ? nsup - ubeg : per;
         if (ksup < 0) ksup = 0;
@@ -2931,7 +3092,7 @@ __global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, co
         vl = vl < 0 ? 0 : vl;
         const int u = ubeg + (vl >> 1), mm = vl & 1;
         if (WIN) {
-            const int uc = u < 2 * SIB_WPX ? u : 2 * SIB_WPX - 1;
+            const int uc = win_u(u);
             return ((uc & 1) * SIB_WPX + (uc >> 1)) * 8 + 4 * mm; // difference row: [q][w] parts, super-step u = 2 w + q
         }
         const int full = full_tiles * 64;
@@ -2947,7 +3108,7 @@ __global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, co
         int us;
         if (!WIN) us = ubeg + ul;
         else {
-            const int u = ubeg + ul < 2 * SIB_WPX ? ubeg + ul : 2 * SIB_WPX - 1;
+            const int u = win_u(ubeg + ul);
             const int w = u >> 1, qq = u & 1, wy = w / SIB_WIN, wx = w - wy * SIB_WIN;
             const int px = (win_oy + wy) * bn + win_ox + wx;
             us = px < full_tiles * 32 ? (px >> 5) * 64 + qq * 32 + (px & 31) : full_tiles * 64 + qq * last_cnt + (px - full_tiles * 32);
@@ -3507,8 +3668,8 @@ size_t net_alloc(Net& net) {
             // difference path: slots (bins padded to whole tiles), their difference rows
             net.d_slots = mb + (size_t)(SIB_BINS + 1) * GT_BS;
             ok = ok && A((void**)&net.d_sib_slot, sizeof(uint32_t) * mb);
-            ok = ok && A((void**)&net.d_bin_start, sizeof(int32_t) * 96);
-            ok = ok && A((void**)&net.d_tile_info, sizeof(int32_t) * (net.d_slots / GT_BS));
+            ok = ok && A((void**)&net.d_bin_start, sizeof(int32_t) * 256);
+            ok = ok && A((void**)&net.d_tile_info, sizeof(int32_t) * 2 * (net.d_slots / GT_BS)); // [tile] info, then [position] the whole-K launch's tile order
             ok = ok && A(&net.d_slot_desc, sizeof(uint2) * net.d_slots);
             ok = ok && A(&net.d_rows, net.d_slots * (size_t)SIBX_DROW_U4 * 16);
             ok = ok && A(&net.a_base, net.base_slots * row_u4 * 16);
@@ -3875,9 +4036,16 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
                                                              (const uint4*)net.d_sib_rows, net.d_gcnt, net.sib_h, nullptr, nullptr, nullptr, nullptr, nullptr);
         return;
     }
-    k_bin_prefix<<<1, 128, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu,
+    static const int tprof_mode = getenv("OMOK_SIB_PROF") ? atoi(getenv("OMOK_SIB_PROF")) : 0; // timing experiments only (N = 15, fp6 format): 1 = k_sib_children, 2 = k_sib_children2
+    const bool tprof = tprof_mode == 1;
+    const bool mixed = x16 && net.diff_fp6; // FC0_MIXED: full rows f16, difference rows fp6 (k_sib_children2 only)
+    const bool v2 = (net.sib_v2 && !tprof) || mixed;
+    // per-tile rectangles of window pixels (k_bin_prefix): only k_sib_children2 writes the exact zeros outside a child's own region that make a row's sum independent of its tile
+    static const bool rects_env = !(getenv("OMOK_SIB_RECTS") && atoi(getenv("OMOK_SIB_RECTS")) == 0); // (A-B runs)
+    const bool rects = v2 && rects_env && net.win_rects;
+    k_bin_prefix<<<1, BP_THREADS, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu,
                                     sib_max_fways(net, max_count), SIB_MAX_WWAYS, (int)std::min<size_t>(net.part_w_rows * 7, (size_t)1 << 30), (int)net.base_slots,
-                                    (int)std::min<size_t>(net.part_rows, (size_t)1 << 30), 2 * net.hw);
+                                    (int)std::min<size_t>(net.part_rows, (size_t)1 << 30), 2 * net.hw, net.n, rects ? 1 : 0, (int)(net.d_slots / GT_BS));
     static const bool stats = getenv("OMOK_SIB_STATS") && atoi(getenv("OMOK_SIB_STATS")); // diagnostics only: synchronises every round
     if (stats) {
         static long long acc[8] = {}, launches = 0;
@@ -3888,6 +4056,13 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         c[3] = c2[0]; // (runs evaluated in full: base-cache misses + uncacheable runs)
         c[7] = c2[2]; // (K split of the full-row fc0)
         for (int i = 0; i < 8; ++i) acc[i] += c[i];
+        if ((launches + 1) % 50 == 0) { // this round's window tiles: the work their rectangles leave
+            std::vector<int32_t> ti((size_t)(c[4] > 0 ? c[4] : 1));
+            hipMemcpy(ti.data(), net.d_tile_info, sizeof(int32_t) * ti.size(), hipMemcpyDeviceToHost);
+            long long tot = 0;
+            for (int t = 0; t < c[5] && t < c[4]; ++t) tot += (((ti[t] >> 19) & 7) - ((ti[t] >> 16) & 7) + 1) * (((ti[t] >> 25) & 7) - ((ti[t] >> 22) & 7) + 1);
+            fprintf(stderr, "[sib stats] whole-K window tiles: %d, rectangle pixels %lld = %.3f of full 7x7 windows\n", c[5], tot, (double)tot / (49.0 * (c[5] > 0 ? c[5] : 1)));
+        }
         if (++launches % 50 == 0) {
             fprintf(stderr, "[sib stats] rounds %lld: per round runs %.0f (evaluated in full %.0f) singles %.0f rows-in-runs %.0f (run length %.2f) window tiles %.1f (split set from %.1f, %.1f ways) full-row K split %.1f\n",
                     launches, acc[0] / 50.0, acc[3] / 50.0, acc[1] / 50.0, acc[2] / 50.0, acc[0] ? (double)acc[2] / acc[0] : 0.0, acc[4] / 50.0, acc[5] / 50.0, acc[6] / 50.0, acc[7] / 50.0);
@@ -3895,10 +4070,6 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         }
     }
     // runs without a cached base -> compact rows [0, misses) + their base slots; then the single rows -> compact rows [misses, misses + singles)
-    static const int tprof_mode = getenv("OMOK_SIB_PROF") ? atoi(getenv("OMOK_SIB_PROF")) : 0; // timing experiments only (N = 15, fp6 format): 1 = k_sib_children, 2 = k_sib_children2
-    const bool tprof = tprof_mode == 1;
-    const bool mixed = x16 && net.diff_fp6; // FC0_MIXED: full rows f16, difference rows fp6 (k_sib_children2 only)
-    const bool v2 = (net.sib_v2 && !tprof) || mixed;
     if (net.n == 9) launch_trunk_fmt<9, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1, v2);
     else launch_trunk_fmt<15, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1, v2);
     if (v2 && tprof_mode == 2 && !x16 && net.n == 15) {
@@ -3978,7 +4149,7 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
     if (net.fc0_fmt == FC0_F16 && !net.diff_fp6) {
         const int lc = (hw % 32) ? (hw % 32) : 1;
         const int wtiles_max = (tiles_max + SIB_BINS + 1 + 7) / 8 * 8 + 8;
-        k_fc0_x3<EPI_SPLIT, true><<<dim3(wtiles_max, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.d_rows, 0, (size_t)SIBX_DROW_U4, hw / 32, lc, bias_fc0, h0, 128,
+        k_fc0_x3<EPI_SPLIT, true><<<dim3((wtiles_max + 255) / 256 * 256, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.d_rows, 0, (size_t)SIBX_DROW_U4, hw / 32, lc, bias_fc0, h0, 128,
                                                                        nullptr, net.d_gcnt, max_count, net.d_tile_info, (const uint2*)net.d_slot_desc, net.facc, net.n);
         const int stiles = wtiles_max < n_cu + 8 ? wtiles_max : n_cu + 8;
         k_fc0_x3<EPI_PARTIAL, true><<<dim3(n_cu + 8, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.d_rows, 0, (size_t)SIBX_DROW_U4, hw / 32, lc, bias_fc0, nullptr,
@@ -3995,7 +4166,7 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
     }
     // window tiles: whole rounds of workgroups at full K, the tiles of the last partial round split over K (k_bin_prefix)
     const int wtiles_max = (tiles_max + SIB_BINS + 1 + 7) / 8 * 8 + 8; // (the XCD-aware tile mapping rounds an eighth of the tiles up)
-    k_fc0_mx<EPI_SPLIT, 0, true><<<dim3(wtiles_max, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
+    k_fc0_mx<EPI_SPLIT, 0, true><<<dim3((wtiles_max + 255) / 256 * 256, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
                                                                        (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr, net.d_gcnt, max_count,
                                                                        net.d_tile_info, (const uint2*)net.d_slot_desc, net.facc, net.n);
     const int stiles = wtiles_max < n_cu + 8 ? wtiles_max : n_cu + 8;

@@ -71,11 +71,12 @@ def test_execute_equals_stepwise_in_the_benchmark_regime(mode):
     assert full_nr >= 1 and depth >= 3
 
 
-def _packed_run(n, games, count, k, plies, seed, tensors, cache=True):
+def _packed_run(n, games, count, k, plies, seed, tensors, cache=True, rects=True):
     import torch
     eng = oa.Engine(board_size=n, games=games, max_nodes=4 * count + 256, max_tables=count + 64, max_batch_k=k, seed=seed)
     eng.load_weights(tensors)
     eng.set_base_cache(cache)
+    eng.set_window_rects(rects)
     sp = oa.SelfPlay(eng)
     sp.reset()
     sp.run(count, k, max_plies=plies)
@@ -93,7 +94,8 @@ def _packed_run(n, games, count, k, plies, seed, tensors, cache=True):
 def test_selfplay_run_on_the_difference_path_is_reproducible_and_cache_independent(n, games, count, k, plies):
     """(b) + (d): two runs of omok_selfplay_run with rounds on the difference path (N = 15: 4096 rows >= 3072; N = 9: 2048 rows >= 1024;
     k_group hands out slots with atomics) give the same packed replay bytes and trees; a third run with the base cache switched off
-    gives them too (a cached base evaluation == its recomputation, bit for bit)."""
+    gives them too (a cached base evaluation == its recomputation, bit for bit); so does a fourth whose fc0 window tiles walk the whole 7x7 window
+    instead of the rectangle their rows can differ in (round 5: the skipped window pixels hold exact zeros)."""
     tensors = oa.weights.init_random(n, seed=0)
     a = _packed_run(n, games, count, k, plies, 3, tensors)
     b = _packed_run(n, games, count, k, plies, 3, tensors)
@@ -103,6 +105,9 @@ def test_selfplay_run_on_the_difference_path_is_reproducible_and_cache_independe
     _same_dumps(a[2], b[2], "run vs run")
     assert a[0] == c[0] and np.array_equal(a[1], c[1]), "base cache on / off differ"
     _same_dumps(a[2], c[2], "cache on vs off")
+    d = _packed_run(n, games, count, k, plies, 3, tensors, rects=False)
+    assert a[0] == d[0] and np.array_equal(a[1], d[1]), "window rectangles on / off differ"
+    _same_dumps(a[2], d[2], "window rectangles on vs off")
 
 
 @pytest.mark.parametrize("n,games,k", [(15, 224, 16), (9, 160, 8)])  # 3584 rows per round >= 3072; 1280 >= 1024
