@@ -120,15 +120,26 @@ def cpu_baseline(args, mean_plies, budget_s):
     tensors = oa.weights.init_random(n, seed=0)
     net = T.Network(n, tensors, "cpu", allow_cpu=True)
 
-    def forward(x):
+    onet_c = O.Net(n, tensors)
+
+    def forward_torch(x, threads):
         with torch.no_grad():
             p, v = net(torch.from_numpy(np.ascontiguousarray(x)).reshape(-1, n, n, 3))
         return p.numpy().reshape(len(x), hw), v.numpy().reshape(-1)
 
+    def forward_c(x, threads):  # the oracle's own fp32 forward (oracle/net.c: plain loops, OpenMP over blocks of 8 rows)
+        return onet_c.forward(np.ascontiguousarray(x, dtype=np.float32).reshape(len(x), -1), threads=threads)
+
+    FORWARDS = {"torch-CPU (BLAS / oneDNN)": forward_torch, "oracle/net.c (OpenMP over rows)": forward_c}
+
     seen_rows = []  # request rows of the legs' real search rounds (for the oracle-vs-GPU check of the net outputs below)
 
-    def leg(games, sims, threads, seconds, max_plies):
+    def leg(games, sims, threads, seconds, max_plies, engine="torch-CPU (BLAS / oneDNN)"):
         torch.set_num_threads(threads)
+        fwd = FORWARDS[engine]
+
+        def forward(x):
+            return fwd(x, threads)
         root_p, _ = forward(O.Environment(n).encode_nn_input(0)[None])
         sp = O.SelfPlay(n, games, cap_nodes=min(16384, 4 * sims + 1024), cap_tables=max(256, sims + 256), seed=args.seed)
         sp.reset(root_p[0])
@@ -164,7 +175,7 @@ def cpu_baseline(args, mean_plies, budget_s):
             sp.advance(p)
             plies += 1
         dt = time.perf_counter() - t0
-        return {"games": games, "sims_per_move": rounds * k, "threads": threads, "seconds": dt, "plies_completed": plies,
+        return {"games": games, "sims_per_move": rounds * k, "threads": threads, "net_forward": engine, "seconds": dt, "plies_completed": plies,
                 "sims": n_sims, "sims_per_s": n_sims / dt, "nn_evals_per_s": n_evals / dt, "net_seconds": t_net,
                 "tree_seconds": dt - t_net, "finished": sp.alive_count == 0}
 
@@ -175,14 +186,16 @@ def cpu_baseline(args, mean_plies, budget_s):
     # Budget: 10 % thread calibration, 10 % per C1 leg, 50 % the C2' leg, 15 % the one-thread C2' leg.
     cand = sorted({t for t in (64, 128, cores) if t <= cores}) or [cores]
     g2, g1t = 256, 16
-    calib = {t: leg(g2, args.sims, t, max(1.0, 0.10 * budget_s / len(cand)), 1)["sims_per_s"] for t in cand}
-    best_t = max(calib, key=calib.get)
+    # two forwards compete at every thread count: torch-CPU and the oracle's own C forward (rows are independent: OpenMP over blocks of rows); on the GPU box's
+    # 2 x 64-core host torch-CPU reached 2.9 k rows/s at 4096-row batches whatever the thread count, so the row-parallel C loop is the fairer CPU path there
+    calib = {(e, t): leg(g2, args.sims, t, max(0.6, 0.12 * budget_s / (2 * len(cand))), 1, e)["sims_per_s"] for e in FORWARDS for t in cand}
+    best_e, best_t = max(calib, key=calib.get)
     share = 0.50 * budget_s
     legs = {
-        "c1_best_threads": leg(1, 100, best_t, 0.10 * budget_s, 10 ** 6),
-        "c1_one_thread": leg(1, 100, 1, 0.10 * budget_s, 10 ** 6),
-        "c2p_best_threads": leg(g2, args.sims, best_t, share, 4),
-        "c2p_one_thread": leg(g1t, args.sims, 1, 0.15 * budget_s, 2),
+        "c1_best_threads": leg(1, 100, best_t, 0.08 * budget_s, 10 ** 6, best_e),
+        "c1_one_thread": leg(1, 100, 1, 0.08 * budget_s, 10 ** 6),
+        "c2p_best_threads": leg(g2, args.sims, best_t, share, 4, best_e),
+        "c2p_one_thread": leg(g1t, args.sims, 1, 0.12 * budget_s, 2),
     }
     torch.set_num_threads(cores)
     best = legs["c2p_best_threads"]
@@ -201,7 +214,7 @@ def cpu_baseline(args, mean_plies, budget_s):
     if seen_rows:
         allr = np.concatenate(seen_rows)
         xr = np.ascontiguousarray(allr[:: max(1, len(allr) // 256)][:256])
-        onet = O.Net(n, tensors)
+        onet = onet_c
         t1 = time.perf_counter()
         po, vo, lgo, vpo = onet.forward_logits(xr, threads=best_t)
         dt_o = time.perf_counter() - t1
@@ -211,9 +224,10 @@ def cpu_baseline(args, mean_plies, budget_s):
                                     "threads": best_t, "what": "oracle/net.c fp32 forward (plain loops, OpenMP over blocks of 8 rows) on request rows of the legs' search rounds"}
                                    if net_check else None),
             "value": best["sims_per_s"] / (rounds_up * mean_plies), "unit": "games/s", "cores": best_t, "host_threads": cores, "kind": "port",
-            "thread_calibration_sims_per_s": {str(t): v for t, v in calib.items()},
+            "net_forward": best_e,
+            "thread_calibration_sims_per_s": {f"{e} @ {t} threads": v for (e, t), v in calib.items()},
             "sample": f"C2' = {g2} games x {rounds_up} sims/move ({g2 * k}-row forwards) x up to 4 plies (bounded to {share:.0f} s; {best['plies_completed']} plies completed) on {best_t} of {cores} "
-                      f"threads (fastest of {cand}): oracle C tree code + torch-CPU fp32 forward (BLAS); {best['sims_per_s']:.0f} sims/s, converted with {mean_plies:.1f} plies/game "
+                      f"threads (fastest of {cand} x two forwards): oracle C tree code + fp32 forward by {best_e}; {best['sims_per_s']:.0f} sims/s, converted with {mean_plies:.1f} plies/game "
                       f"from the GPU run.  Also C1 (1 game, 100->112 sims/move, whole game or {0.10 * budget_s:.0f} s) and, on 1 thread, C1 and {g1t} games of C2': see legs",
             "cpu_model": model, "sims_per_s": best["sims_per_s"],
             "one_thread_value": legs["c2p_one_thread"]["sims_per_s"] / (rounds_up * mean_plies),

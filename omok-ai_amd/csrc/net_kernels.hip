@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(BP_THREADS) void k_bin_prefix(int32_t* __restrict__
                                                            uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu, int max_fways,
                                                            int max_wways, int part_w_rows, int facc_single_base, int part_f_rows, int nsup_full, int bn, int use_rects, int tile_cap) {
     __shared__ unsigned char cost[BP_MAXT];
-    __shared__ int hist[64], bstart[64];
+    __shared__ int hist[64];
     __shared__ int tile0[SIB_BINS + 2], binc[SIB_BINS + 1], bcnt[SIB_BINS + 1], order[SIB_BINS + 1], start_at[SIB_BINS + 2], p0c[225], p0o[225], s_split, s_ntiles;
     const int tid = threadIdx.x;
     for (int i = tid; i < 225; i += blockDim.x) p0c[i] = i < bn * bn ? cnt[NET_GCNT_P0 + i] : 0;
@@ -1030,24 +1030,36 @@ __global__ __launch_bounds__(BP_THREADS) void k_bin_prefix(int32_t* __restrict__
     } else if (tid == SIB_BINS) c = cnt[1];
     if (tid <= SIB_BINS) { bcnt[tid] = c; binc[tid] = (c + GT_BS - 1) / GT_BS; order[tid] = sib_bin_at(tid, bn); } // (tiles per bin and the layout order in parallel:
     __syncthreads();                                                                                                     //  the serial part below only adds)
-    if (tid == 0) {
-        int t = 0;
-        for (int pos = 0; pos <= SIB_BINS; ++pos) { // (counts from LDS: 82 serial global loads were most of this kernel's 16 us)
-            const int b = order[pos];
-            tile0[b] = t;
-            start_at[pos] = t;
-            t += binc[b];
+    if (tid < 64) { // wave 0: exclusive scan of the bins' tile counts in layout order (82 positions = two passes of 64 lanes), then the split point
+        int carry = 0, ntiles = 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int pos = half * 64 + tid, b = pos <= SIB_BINS ? order[pos] : 0, v = pos <= SIB_BINS ? binc[b] : 0;
+            int incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += u;
+            }
+            if (pos <= SIB_BINS) { tile0[b] = carry + incl - v; start_at[pos] = carry + incl - v; }
+            carry += __shfl(incl, 63, 64);
         }
-        start_at[SIB_BINS + 1] = t;
-        const int ntiles = t;
+        ntiles = carry;
+        if (tid == 0) start_at[SIB_BINS + 1] = ntiles;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int t_split = ntiles - (ntiles < n_cu ? ntiles : ntiles % n_cu); // first tile of the partial round ...
-        int first = ntiles;
-        for (int pos = SIB_BINS; pos >= 0; --pos) {                     // ... moved down to the start of its bin
-            const int b0 = start_at[pos];
-            if (b0 < first) first = b0;
-            if (b0 <= t_split) break;
+        if (t_split < ntiles) {                                           // ... moved down to the start of its bin: the largest bin start <= t_split
+            int best = 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int pos = half * 64 + tid, st = pos <= SIB_BINS ? start_at[pos] : 0;
+                best = st <= t_split && st > best ? st : best;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(best, o, 64); best = u > best ? u : best; }
+            t_split = best;
         }
-        if (t_split < ntiles) t_split = first;
+      if (tid == 0) {
         int ways = ntiles > t_split ? n_cu / (ntiles - t_split) : 1;
         if (ways > max_wways) ways = max_wways;
         if (ntiles > t_split && ways > part_w_rows / ((ntiles - t_split) * GT_BS)) ways = part_w_rows / ((ntiles - t_split) * GT_BS); // (partials slab)
@@ -1069,6 +1081,7 @@ __global__ __launch_bounds__(BP_THREADS) void k_bin_prefix(int32_t* __restrict__
         cnt[6] = ways;
         s_split = t_split;
         s_ntiles = ntiles;
+      }
     }
     __syncthreads();
     constexpr int FULL_RECT = (0 << 16) | ((SIB_WIN - 1) << 19) | (0 << 22) | ((SIB_WIN - 1) << 25);
@@ -1122,26 +1135,28 @@ __global__ __launch_bounds__(BP_THREADS) void k_bin_prefix(int32_t* __restrict__
         int* tile_order = tile_info + tile_cap;
         __syncthreads();
         const int n = t_split <= BP_MAXT ? t_split : 0;
-        if (tid == 0) {
-            int run = 0;
-            for (int a = 63; a >= 0; --a) { bstart[a] = run; run += hist[a]; }
-            cnt[7] = tile_cap;
-        }
-        __syncthreads();
+        if (tid == 0) cnt[7] = tile_cap;
         if (tid < 64) {
+            // first position of every cost bucket, dearest first: lane a keeps bucket a's running start in a register
+            const int hv = hist[63 - tid];
+            int incl = hv;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += u;
+            }
+            int my_start = __shfl(incl - hv, 63 - tid, 64);
             const unsigned long long lt = (1ULL << tid) - 1ULL;
             for (int c0 = 0; c0 < n; c0 += 64) {
                 const int T = c0 + tid, cT = T < n ? (int)cost[T] : -1;
                 unsigned long long todo = __ballot(T < n);
                 int pos = 0;
-                while (todo) {
+                while (todo) { // one pass per distinct cost of the chunk (a few: neighbouring tiles have neighbouring P0s)
                     const int lead = __ffsll((long long)todo) - 1, lc = __shfl(cT, lead, 64);
                     const unsigned long long m = __ballot(cT == lc);
-                    const int base = bstart[lc];
+                    const int base = __shfl(my_start, lc, 64);
                     if (cT == lc) pos = base + __popcll(m & lt);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    if (tid == lead) bstart[lc] = base + __popcll(m);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (tid == lc) my_start += __popcll(m);
                     todo &= ~m;
                 }
                 if (T < n) tile_order[pos] = T;
