@@ -69,7 +69,7 @@ int orc_net_load(orc_net* net, int idx, const float* data, int64_t count) {
 static inline float lrelu(float x) { return x > 0.0f ? x : 0.2f * x; }
 
 /* trunk for one sample: in [3*HW] -> x [HW][128] */
-static void trunk(const orc_net* net, const float* in, float* x, float* h, float* d, float* g) {
+static inline __attribute__((always_inline)) void trunk(const orc_net* net, const float* in, float* x, float* h, float* d, float* g) {
     const int n = net->n, hw = net->hw;
     const float* cw = net->t[0];
     const float* cb = net->t[1];
@@ -136,7 +136,10 @@ static void trunk(const orc_net* net, const float* in, float* x, float* h, float
 #define SB 8 /* samples per weight pass */
 
 /* lg / vpre (optional): the policy head's output in front of the softmax (network.rs:227-247) and the value head's in front of tanh */
-static void forward_impl(const orc_net* net, const float* in, int B, float* p, float* v, float* lg, float* vpre, int threads) {
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+void orc_net_forward_impl_(const orc_net* net, const float* in, int B, float* p, float* v, float* lg, float* vpre, int threads) {
     const int hw = net->hw;
     const int64_t K0 = (int64_t)C * hw;
     if (threads < 1) threads = 1;
@@ -202,7 +205,7 @@ static void forward_impl(const orc_net* net, const float* in, int B, float* p, f
     }
 }
 
-void orc_net_forward(const orc_net* net, const float* in, int B, float* p, float* v, int threads) { forward_impl(net, in, B, p, v, NULL, NULL, threads); }
+void orc_net_forward(const orc_net* net, const float* in, int B, float* p, float* v, int threads) { orc_net_forward_impl_(net, in, B, p, v, NULL, NULL, threads); }
 void orc_net_forward_logits(const orc_net* net, const float* in, int B, float* p, float* v, float* logits, float* vpre, int threads) {
-    forward_impl(net, in, B, p, v, logits, vpre, threads);
+    orc_net_forward_impl_(net, in, B, p, v, logits, vpre, threads);
 }
