@@ -2444,7 +2444,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
                 int bq = bpxA;
                 asm volatile("" : "+v"(bq));
                 const int yA = bq / N, xA = bq - yA * N;
-                farA = yA - py > 3 || py - yA > 3 || xA - pxx > 3 || pxx - xA > 3;
+                farA = (yA - py > 3 || py - yA > 3 || xA - pxx > 3 || pxx - xA > 3) && SIB2_EXP != 15; // (timing experiment 15: no exact zeros -- only valid with the rectangles off)
             }
             store_rows(x, crow_p, (OL() & 31) < V2_TPX, rd_px, rd_ok, farA);
             TP(7);
@@ -2490,7 +2490,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
                 int bq = bpxB;
                 asm volatile("" : "+v"(bq));
                 const int yB = bq / N, xB = bq - yB * N;
-                farB = yB - py > 3 || py - yB > 3 || xB - pxx > 3 || pxx - xB > 3;
+                farB = (yB - py > 3 || py - yB > 3 || xB - pxx > 3 || pxx - xB > 3) && SIB2_EXP != 15;
             }
             store_rows(x, crow_p, (OL() & 31) < V2_RING, rd_px, rd_ok, farB);
         }
