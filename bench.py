@@ -59,7 +59,7 @@ def parse(argv=None):
                          "(f16 meets north_star's 1e-3 on the LOGITS too); f32: the fp32 VALU kernels")
     ap.add_argument("--f16-leg", type=int, default=1, help="extra legs: one more whole episode each with fc0 forced into the f16 / the fp6 operand format -> value_f16_format, value_fp6_format (0 = skip)")
     ap.add_argument("--gather", action="store_true", help="RCCL all-gather-v of replay tuples at episode end")
-    ap.add_argument("--cpu-seconds", type=float, default=70.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=80.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=20, help="training steps timed after the episode (0 = skip; batch 128)")
     ap.add_argument("--slots-multiple", type=int, default=3, help="extra leg (outside the timed region): slots mode, this many x games played on the "
                     "engine's game slots with finished slots restarted (omok_selfplay_run_slots); 0 = skip")
