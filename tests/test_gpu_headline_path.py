@@ -297,3 +297,51 @@ def test_whole_episodes_at_scale_are_deterministic():
         assert st["finished"] == games and st["children2_launches"] > 0
         eng.close()
     assert digests[0] == digests[1], digests
+
+
+def test_full_size_rounds_first_games_against_the_oracle():
+    """Tree parity AT THE TIMED SIZE (BASELINE configs[1]: 4096 games, 15x15, 800 simulations per move, K = 16): every round is a 65536-row forward on the difference path
+    -- multi-tile window bins, cost-ordered window tiles with rectangles, the K-split set -- and the first 32 games are played in step on the ORACLE, which consumes the GPU's
+    p / v rows of those games (the dense request list is in tree order: the first rows of every round).  Request boards (sampled rounds), moves, mirror inputs and the canonical
+    dumps of both trees of the 32 games must be bit-identical after one whole ply (50 rounds: fully expanded nodes) and after ten rounds of the second.
+    Reference: alpha-zero/src/parallel_mcts_executor.rs:26-270, agent.rs:83-232, src/trainer.rs:95-205."""
+    from test_gpu_parity import _compare_trees
+    n, games, g0, count, k = 15, 4096, 32, 800, 16
+    tensors = oa.weights.init_random(n, seed=0)
+    eng = oa.Engine(board_size=n, games=games, max_nodes=4 * count + 1024, max_tables=1056, max_batch_k=k, seed=0)
+    eng.load_weights(tensors)
+    sp = oa.SelfPlay(eng)
+    sp.reset()
+    root_p = eng.evaluate_p(O.Environment(n).encode_nn_input(0)[None]).reshape(-1)
+    osp = O.SelfPlay(n, g0, cap_nodes=4 * count + 1024, cap_tables=1056, seed=0, game_offset=0)
+    osp.reset(root_p)
+    eng.reset_stats()
+    shape = [0, 0]
+    for ply, rounds in ((0, count // k), (1, 10)):
+        for rnd in range(rounds):
+            nreq = sp.round_generate(rnd, k, 0.25, 0.03)
+            oin = osp.round_generate(rnd, k, 0.25, 0.03)
+            assert nreq == games * k  # (no terminal position this early: every simulation asks for an evaluation)
+            if rnd in (0, 1, 17, rounds - 1):
+                assert np.array_equal(sp.round_inputs()[: len(oin)], oin), f"ply {ply} round {rnd}: request boards of the first {g0} games"
+            p, v = sp.round_eval()
+            sp.round_scatter()
+            osp.round_scatter(p[: len(oin)], v[: len(oin)])
+        _compare_trees(sp, osp, g0, f"ply {ply} after {rounds} full-size rounds")
+        for g in range(g0):
+            full, full_nr, depth = tree_shape(osp.tree_dump(g, ply & 1)[0])
+            shape = [max(shape[0], full_nr), max(shape[1], depth)]
+        if ply == 0:
+            a = sp.sample_actions(1.0, 30)
+            assert np.array_equal(a[:g0], osp.sample(1.0, 30)), "moves of the first games"
+            nm = sp.mirror_generate()
+            om = osp.mirror_generate()
+            assert nm == games and np.array_equal(sp.mirror_inputs()[: len(om)], om)
+            pm = sp.mirror_eval()
+            sp.mirror_apply()
+            osp.advance(pm[: len(om)])
+            _compare_trees(sp, osp, g0, "after the first advance")
+    st = eng.stats()
+    print(f"full-size rounds: {int(st['children2_launches'])} on the difference path, fully expanded non-root nodes {shape[0]}, depth {shape[1]}")
+    assert st["children2_launches"] >= 60 and shape[0] >= 1 and shape[1] >= 2
+    eng.close()
