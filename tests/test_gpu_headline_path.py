@@ -317,6 +317,7 @@ def test_full_size_rounds_first_games_against_the_oracle(n, games, count, k, max
     root_p = eng.evaluate_p(O.Environment(n).encode_nn_input(0)[None]).reshape(-1)
     osp = O.SelfPlay(n, g0, cap_nodes=4 * count + 1024, cap_tables=max_tables, seed=0, game_offset=0)
     osp.reset(root_p)
+    onet = O.Net(n, tensors)
     eng.reset_stats()
     shape = [0, 0]
     for ply, rounds in ((0, count // k), (1, 10)):  # (a whole ply: 50 / 25 rounds; then ten rounds of the second)
@@ -324,9 +325,18 @@ def test_full_size_rounds_first_games_against_the_oracle(n, games, count, k, max
             nreq = sp.round_generate(rnd, k, 0.25, 0.03)
             oin = osp.round_generate(rnd, k, 0.25, 0.03)
             assert nreq == games * k  # (no terminal position this early: every simulation asks for an evaluation)
+            xin = None
             if rnd in (0, 1, 17, rounds - 1):
-                assert np.array_equal(sp.round_inputs()[: len(oin)], oin), f"ply {ply} round {rnd}: request boards of the first {g0} games"
+                xin = sp.round_inputs()
+                assert np.array_equal(xin[: len(oin)], oin), f"ply {ply} round {rnd}: request boards of the first {g0} games"
             p, v = sp.round_eval()
+            if xin is not None and rnd == 17:  # the net's outputs of a full-size round, rows from all over the batch, against the oracle's forward (north_star: 1e-3, logits included)
+                pick = np.random.default_rng(5).choice(nreq, size=384, replace=False)
+                lg, vp = sp.round_logits()
+                pc, vc, lgc, vpc = onet.forward_logits(xin[pick], threads=8)
+                worst = (float(np.abs(p[pick] - pc).max()), float(np.abs(v[pick] - vc).max()), float(np.abs(lg[pick] - lgc).max()), float(np.abs(vp[pick] - vpc).max()))
+                print(f"n={n}: full-size round {rnd}, {len(pick)} of {nreq} rows against the oracle: |dp| {worst[0]:.2e} |dv| {worst[1]:.2e} |dlogit| {worst[2]:.2e} |dvpre| {worst[3]:.2e}")
+                assert max(worst) < TOL, worst
             sp.round_scatter()
             osp.round_scatter(p[: len(oin)], v[: len(oin)])
         _compare_trees(sp, osp, g0, f"ply {ply} after {rounds} full-size rounds")
