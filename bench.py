@@ -680,7 +680,7 @@ def main():
             chk = out["cpu_baseline"].pop("_net_check", None)
             if chk is not None and use_cuda:
                 # The GPU's outputs against the ORACLE (oracle/net.c), not against the GPU's own fp32 kernels.
-                #  (1) difference_path: request rows of REAL search rounds of an engine whose rounds take the path the headline is timed on (>= 4096 rows per round:
+                #  (1) difference_path: request rows of REAL search rounds of an engine of the timed engine's size, whose rounds take the path the headline is timed on (65536 rows per round at configs[1]:
                 #      sibling base + 7x7-window difference rows, the operand format this engine's commit probe chose) -- inputs from omok_round_inputs, outputs from
                 #      omok_round_outputs / omok_round_logits of those very rounds, >= 512 of the rows through the oracle's forward.  Round 4's line called the plain-row
                 #      figure below "headline_mode"; a 64-game engine never takes the difference path, so that was a statement about plain rows only.
@@ -691,7 +691,7 @@ def main():
                     mode_h = {"f16x3": B.NET_F16X3, "fp6": B.NET_F16X3_FP6, "mixed": B.NET_F16X3_MIXED, "f16": B.NET_F16X3_F16, "f32": B.NET_F32}[args.net_mode]
                     tensors0 = oa.weights.init_random(n, seed=0)
                     vs = {"reference": "oracle/net.c (fp32 restatement of network.rs, the checker of the -m gpu tests)"}
-                    g_dp = max(PR.difference_path_games(n, k), -(-4096 // k))
+                    g_dp = max(PR.difference_path_games(n, k), -(-4096 // k), games)  # (the timed engine's own size: 65536-row rounds at configs[1])
                     rr = PR.search_round_rows(tensors0, n, games=g_dp, batch_k=k, warm_plies=3, warm_sims=64, rounds=2, device=gpu, seed=args.seed + 5, net_mode=mode_h)
                     sel = np.arange(0, len(rr["x"]), max(1, len(rr["x"]) // 768))[:768]
                     onet = O.Net(n, tensors0)
