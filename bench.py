@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 F16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: bf16/f16 MFMA dense
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec
+BOOST_SCLK_MHZ = 2400.0          # the shader clock the dense peak is quoted at (and what rocm-smi shows on an idle, awake part)
 # HBM bytes per net row from the committed rocprofv3 --pmc passes (profiles/README.md): (FETCH_SIZE x 2 [gfx950 128-B
 # request correction] + WRITE_SIZE) KiB / rows of the profiled launch.  {board: {kernel: bytes per row}}
 PMC_HBM_BYTES_PER_ROW = {15: {"k_trunk": None, "k_fc0_mx": (3.873e6 * 1024 * 2 - 65536 * 28800.0 + 1.347e5 * 1024) / 65536}}
@@ -75,6 +76,74 @@ def parse(argv=None):
 
 def elapsed():
     return time.perf_counter() - T_PROCESS_START
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# clock / power samples of the timed region (rank 0): a child process started BEFORE this process touches the GPU runs `rocm-smi` about twice a second and appends
+# "unix time, sclk MHz, W" (of the busiest GPU) to a scratch file; the lines between the two barriers of the timed region are summarised into the JSON line.
+# Every kernel of the search rounds runs against the package power limit on this part (profiles/r05_power_by_kernel.txt), so the clock the peak is quoted at is not the clock the run gets.
+# ------------------------------------------------------------------------------------------------------------------
+CLOCK_SAMPLER = r"""
+import re, subprocess, sys, time
+out = open(sys.argv[1], "a", buffering=1)
+while True:
+    try:
+        txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+    except Exception:
+        break
+    sclk, watt = {}, {}
+    for line in txt.splitlines():
+        m = re.match(r"GPU\[(\d+)\]\s*:\s*sclk clock level.*\((\d+)Mhz\)", line)
+        if m: sclk[m.group(1)] = int(m.group(2))
+        m = re.match(r"GPU\[(\d+)\]\s*:.*Power \(W\):\s*([0-9.]+)", line)
+        if m: watt[m.group(1)] = float(m.group(2))
+    if not sclk or not watt:
+        break
+    g = max(watt, key=watt.get)
+    out.write(f"{time.time():.3f} {sclk.get(g, 0)} {watt[g]:.0f}\n")
+    time.sleep(0.25)
+"""
+
+
+def start_clock_sampler():
+    import shutil
+    import tempfile
+    if os.environ.get("OMOK_BENCH_CLOCKS", "1") == "0" or not shutil.which("rocm-smi"):
+        return None
+    try:
+        path = os.path.join(tempfile.gettempdir(), f"omok_bench_clocks_{os.getpid()}.txt")
+        open(path, "w").close()
+        return subprocess.Popen([sys.executable, "-c", CLOCK_SAMPLER, path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), path
+    except Exception:
+        return None
+
+
+def stop_clock_sampler(sampler, t_begin, t_end):
+    if not sampler:
+        return None
+    proc, path = sampler
+    try:
+        proc.terminate()  # (this exact child)
+        proc.wait(timeout=15)
+    except Exception:
+        pass
+    try:
+        rows = [[float(x) for x in l.split()] for l in open(path) if len(l.split()) == 3]
+        os.remove(path)
+    except Exception:
+        return None
+    rows = [r for r in rows if t_begin <= r[0] <= t_end]
+    if len(rows) < 4:
+        return None
+    import numpy as np
+    sclk, watt = np.array([r[1] for r in rows]), np.array([r[2] for r in rows])
+    busy = watt >= 0.85 * np.percentile(watt, 90)  # (samples inside well-filled rounds: the thin tail of an episode draws a fraction of the power and runs at the boost clock)
+    return {"method": "rocm-smi (--showclocks --showpower) from a child process, ~2 samples per second between the barriers of the timed region",
+            "samples": len(rows), "sclk_mhz_median": float(np.median(sclk)), "sclk_mhz_p10": float(np.percentile(sclk, 10)), "sclk_mhz_max": float(sclk.max()),
+            "power_w_median": float(np.median(watt)), "power_w_max": float(watt.max()),
+            "busy_samples": int(busy.sum()), "sclk_mhz_busy_median": float(np.median(sclk[busy])), "power_w_busy_median": float(np.median(watt[busy])),
+            "note": "busy = samples at >= 0.85 x the 90th percentile of the power readings, i.e. inside the well-filled rounds: there the package sits at its power limit and the shader "
+                    "clock below the boost clock the peaks are quoted at (profiles/r05_power_by_kernel.txt: each kernel of a round alone runs at the limit too)"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -292,6 +361,8 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: using the launcher's world size", file=sys.stderr)
 
+    sampler = start_clock_sampler() if rank == 0 else None  # (a child process: started before anything here initialises the GPU)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -359,11 +430,12 @@ def main():
     for key in ("records", "bytes", "seconds"):
         gathered[key] = 0
     barrier()
-    t0 = time.perf_counter()
+    t0, wall0 = time.perf_counter(), time.time()
     for _ in range(args.steps):
         episode(args.max_plies)
     barrier()
     dt = time.perf_counter() - t0
+    clocks = stop_clock_sampler(sampler, wall0, time.time())
     st = eng.stats()
     alive, status, plies = sp.game_info()
 
@@ -537,8 +609,15 @@ def main():
         "game_length_percentiles": {str(q): float(np.percentile(plies, q)) for q in (0, 10, 25, 50, 75, 90, 99, 100)},
         "arena": {"max_nodes": max_nodes, "max_tables": max_tables, "peak_nodes": st["peak_nodes"], "peak_tables": st["peak_tables"]},
         "cpu_baseline": None,
+        "clocks": clocks,
         "seconds_since_process_start": elapsed(),
     }
+    if clocks and clocks["sclk_mhz_busy_median"] > 0:
+        # `peak` is quoted at the boost clock (2400 MHz); the well-filled rounds run at the package power limit, below it: the same fraction against the peak at the clock they got
+        scale = BOOST_SCLK_MHZ / clocks["sclk_mhz_busy_median"]
+        for key in ("roofline", "roofline_trunk", "roofline_fc0", "roofline_net"):
+            out[key]["frac_at_sustained_clock"] = out[key]["frac"] * scale
+        clocks["boost_sclk_mhz"] = BOOST_SCLK_MHZ
     if args.gather:
         out["replay_gather"] = {"records_per_episode": gathered["records"] / max(args.steps, 1), "bytes_per_episode": gathered["bytes"] / max(args.steps, 1),
                                 "seconds_per_episode": gathered["seconds"] / max(args.steps, 1), "inside_timed_region": True,

@@ -4018,6 +4018,16 @@ static sib2_kernel_t sib2_kernel(bool x16, int n, bool mixed = false) { // k_sib
     if (n == 9) return x16 ? k_sib_children2<true, 9> : k_sib_children2<false, 9>;
     return x16 ? k_sib_children2<true, 15> : k_sib_children2<false, 15>;
 }
+// A-B builds only (tools/power_by_kernel.sh): OMOK_REPEAT_<WHICH>=n launches one (idempotent) kernel n times in a row, so that a sampled clock / power reading is that kernel's own
+static int repeat_env(const char* name) {
+#ifdef OMOK_EXPERIMENT
+    const char* v = getenv(name);
+    const int n = v ? atoi(v) : 1;
+    return n > 0 ? n : 1;
+#else
+    return 1;
+#endif
+}
 static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_count, hipStream_t st, bool delta) {
     constexpr int LDS = TR_WBYTES + 4 * SIB_CGRID_BYTES + TR_SIDE_FLOATS * 4;
     static_assert(LDS + 32 <= 160 * 1024, "k_sib_children LDS (+ the static pair-barrier flags)");
@@ -4112,6 +4122,8 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
     }
     net.children_launches[v2 ? 0 : 1] += 1.0;
     if (v2) {
+        static const int rep = repeat_env("OMOK_REPEAT_CHILDREN");
+        for (int r = 0; r < rep; ++r)
         sib2_kernel(x16, net.n, mixed)<<<256, 512, V2_LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_base, net.row_u4, (const uint4*)net.d_sib_rows,
                                                           net.d_gcnt, (const uint4*)net.sib_h, net.d_sib_slot, net.d_bin_start, (uint4*)net.d_rows, (uint2*)net.d_slot_desc, nullptr);
         return;
@@ -4181,6 +4193,8 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
     }
     // window tiles: whole rounds of workgroups at full K, the tiles of the last partial round split over K (k_bin_prefix)
     const int wtiles_max = (tiles_max + SIB_BINS + 1 + 7) / 8 * 8 + 8; // (the XCD-aware tile mapping rounds an eighth of the tiles up)
+    static const int rep_win = repeat_env("OMOK_REPEAT_WIN");
+    for (int r = 0; r < rep_win; ++r)
     k_fc0_mx<EPI_SPLIT, 0, true><<<dim3((wtiles_max + 255) / 256 * 256, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.d_rows, 0, (size_t)SIB_DROW_U4, hw / 32,
                                                                        (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, h0, 128, nullptr, net.d_gcnt, max_count,
                                                                        net.d_tile_info, (const uint2*)net.d_slot_desc, net.facc, net.n);
@@ -4345,7 +4359,11 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     const size_t cap_t = (size_t)tiles_t * GT_BS;
     const size_t fin_threads = (size_t)max_count * 64;
     if (tsplit == 1) {
+        static const int rep_fc1 = repeat_env("OMOK_REPEAT_FC1"), rep_heads = repeat_env("OMOK_REPEAT_HEADS");
+        for (int r = 0; r < rep_fc1; ++r)
         launch_gemm<16, EPI_SPLIT, 1, FC1_NST, TAIL_PRIO>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st, net.device);
+        for (int r = 1; r < rep_heads; ++r)
+            if (MT == 8) launch_gemm<8, EPI_LOGITS, 2, HEADS_NST, TAIL_PRIO>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
         if (MT == 8) launch_gemm<8, EPI_LOGITS, 2, HEADS_NST, TAIL_PRIO>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
         else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
     } else {
