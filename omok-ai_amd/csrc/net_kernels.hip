@@ -943,6 +943,24 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
     }
     gslot = __shfl(gslot, rs, 64);
     rbase = __shfl(rbase, rs, 64);
+    // Difference path: a run's rows are listed by the COLUMN of their stone's net pixel (then row, then request order) instead of request order.  k_sib_children2's
+    // eight waves take eight consecutive entries, and what they read of the run's base slot is the union of their windows: neighbours in this order overlap, so a pass
+    // pulls ~28 KB per child through L2 instead of ~35 (the stone's pixel lies in rows 0..9, columns 0..14: the column separates more).  Which wave evaluates a
+    // row changes nothing in the row.
+    int pos_in_run = lane - rs;
+#ifndef GROUP_SORT
+#define GROUP_SORT 1 // (A-B builds: 0 = request order, same results)
+#endif
+    if (sib_slot && GROUP_SORT) {
+        const int pc = (2 * (int)(ta >> 8) + 1) / 3;
+        const int key = in_run ? (((pc % 15) * 16 + pc / 15) << 6) | lane : 0x7FFFFFFF;
+        int rank_in_run = 0;
+        for (int j = 0; j < n; ++j) { // (n = the tree's requests of this round, wave-uniform; a run is at most that long)
+            const int other = __shfl(key, (rs + j) & 63, 64);
+            rank_in_run += (j < len && other < key) ? 1 : 0;
+        }
+        if (in_run) pos_in_run = rank_in_run;
+    }
     if (in_run) {
         if (sib_slot) {
             // slots are handed out per net PIXEL of the child's stone (P0), not per window bin: a bin's rows are then ordered by P0, and an fc0 window tile
@@ -964,7 +982,7 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
     }
     bslot = __shfl(bslot, rs, 64);
     if (in_run) {
-        const int ri = l_base[2] + rbase + (lane - rs);
+        const int ri = l_base[2] + rbase + pos_in_run;
         sib_rows[ri] = make_uint4(ts.req_base + (uint32_t)lane, sib_slot ? (uint32_t)bslot : (uint32_t)(l_base[0] + gslot), tn, ta);
         if (sib_slot) sib_slot[ri] = ((uint32_t)bin << 24) | (uint32_t)(l_base[3 + bin] + rank);
     } else if (lane < n) singles[l_base[1] + sidx] = (int32_t)(ts.req_base + (uint32_t)lane);
