@@ -3,7 +3,7 @@
 # --kernel-trace only) over `bench.py --max-plies 2 <args>`, summarised per kernel, and the per-row / per-simulation HBM bytes merged into
 # OUTDIR/pmc_bytes.json under the board's key.
 out=$1; board=$2; shift 2; R=$PWD; mkdir -p $R/$out
-cd /tmp; export TMPDIR=/tmp
+cd /tmp; export TMPDIR=/tmp OMOK_BENCH_CLOCKS=0 # (bench.py starts no child process under the profiler)
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS" \
