@@ -112,7 +112,7 @@ def start_clock_sampler():
         return None
     # Under a profiler the GPU is already initialised when this program starts (rocprofv3 --pmc preloads its tool library, which opens the device), and a process that has
     # initialised the GPU must not start a program: no sampler then.
-    if os.environ.get("LD_PRELOAD") or any(k.startswith(("ROCP", "ROCPROF", "ROCTRACER", "HSA_TOOLS")) for k in os.environ):
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCP_", "ROCPROF", "ROCTRACER", "HSA_TOOLS_LIB")) for k in os.environ):
         return None
     try:
         path = os.path.join(tempfile.gettempdir(), f"omok_bench_clocks_{os.getpid()}.txt")
