@@ -84,9 +84,10 @@ def elapsed():
 # Every kernel of the search rounds runs against the package power limit on this part (profiles/r05_power_by_kernel.txt), so the clock the peak is quoted at is not the clock the run gets.
 # ------------------------------------------------------------------------------------------------------------------
 CLOCK_SAMPLER = r"""
-import re, subprocess, sys, time
+import os, re, subprocess, sys, time
 out = open(sys.argv[1], "a", buffering=1)
-while True:
+parent, t_end = int(sys.argv[2]), time.time() + 3600.0
+while os.getppid() == parent and time.time() < t_end:  # (never outlives the bench process that started it)
     try:
         txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
     except Exception:
@@ -117,7 +118,7 @@ def start_clock_sampler():
     try:
         path = os.path.join(tempfile.gettempdir(), f"omok_bench_clocks_{os.getpid()}.txt")
         open(path, "w").close()
-        return subprocess.Popen([sys.executable, "-c", CLOCK_SAMPLER, path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), path
+        return subprocess.Popen([sys.executable, "-c", CLOCK_SAMPLER, path, str(os.getpid())], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL), path
     except Exception:
         return None
 
