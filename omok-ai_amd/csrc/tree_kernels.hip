@@ -203,6 +203,16 @@ __device__ inline float seq_sum_regs(const float (&x)[Geo<N>::IT]) {
 // ---------------------------------------------------------------------------------------------
 // per-tree view
 // ---------------------------------------------------------------------------------------------
+#ifdef KROUND_PROF // diagnostic build: per launch and tree, shader-clock cycles per phase of k_round
+__device__ unsigned long long g_kprof[64][8192][8];
+__device__ unsigned int g_klaunch;
+#define KP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); kp[i] += now_ - kp_last; kp_last = now_; } while (0)
+#else
+#define KP(i) do { } while (0)
+#endif
+#ifndef PARALLEL_PICKS
+#define PARALLEL_PICKS 1 // (A-B builds: 0 = run_sims picks its cells and checks its children one at a time, as in round 4; same results)
+#endif
 template <int N>
 struct Tree {
     using G = Geo<N>;
@@ -243,6 +253,9 @@ struct Regs { // wave-uniform running state of a tree
     uint32_t memo_n = 0;
     unsigned long long memo_bytes = 0;
     bool dirty = false; // this wave has stores in flight that a later load of its own may depend on (see LeafCache)
+#ifdef KROUND_PROF
+    unsigned long long kp[8] = {}, kp_last = 0;
+#endif
 };
 
 // The memoised leaf in registers.  Consecutive simulations of a round expand the SAME leaf (see memo_node): after the first one the wave
@@ -433,14 +446,29 @@ __device__ inline void select_leaf(const Tree<N>& T, NodeHdr& h, int& node, uint
         const size_t tb = (size_t)h.table * ROWP;
         const float ph = __fdiv_rn(1.0f, (float)h.legal); // placeholder prior of a not-yet-evaluated node
         unsigned long long best = 0ULL;
+        // every load of the level goes out before the first use: rows are ROWP long (pad cells: rank NONE8; (n, w, p) of a cell without child are read and not used).
+        // (Loaded under `if (ord != NONE8)` the scan was a chain of 2 x IT dependent round trips per level: k_round's slowest trees spent 3/4 of their time here.)
+        uint8_t ordv[G::IT];
+        uint32_t nv[G::IT];
+        uint16_t civ[G::IT];
+        float wv[G::IT], pv[G::IT];
 #pragma unroll
         for (int j = 0; j < G::IT; ++j) {
             const int a = j * 64 + lane;
-            const uint8_t ord = T.corder[tb + a];
+            ordv[j] = T.corder[tb + a];
+            nv[j] = T.cn[tb + a];
+            wv[j] = T.cw[tb + a];
+            pv[j] = h.has_policy ? T.pol[(size_t)node * ROWP + a] : ph;
+            civ[j] = T.cidx[tb + a];
+        }
+#pragma unroll
+        for (int j = 0; j < G::IT; ++j) {
+            const int a = j * 64 + lane;
+            const uint8_t ord = ordv[j];
             if (ord != NONE8) {
-                const uint32_t n = T.cn[tb + a];
-                const float w = T.cw[tb + a];
-                const float p = h.has_policy ? T.pol[(size_t)node * ROWP + a] : ph;
+                const uint32_t n = nv[j];
+                const float w = wv[j];
+                const float p = pv[j];
                 const float q = __fdiv_rn(w, (float)n + F32_EPS);
                 const float bias = __fdiv_rn(sq, (float)(1u + n));
                 const float score = q + (1.0f * p) * bias;
@@ -452,10 +480,55 @@ __device__ inline void select_leaf(const Tree<N>& T, NodeHdr& h, int& node, uint
         best = wave_max_u64(best);
         const int a_best = (int)(best & 0xFFFFu);
         path_bytes += 12ull * h.nch;
-        node_n = T.cn[tb + a_best];
-        node = (int)T.cidx[tb + a_best];
+        { // the chosen child's n and index are in the registers of the lane that scanned it
+            uint32_t n_sel = nv[0], c_sel = civ[0];
+#pragma unroll
+            for (int j = 1; j < G::IT; ++j) {
+                n_sel = (a_best >> 6) == j ? nv[j] : n_sel;
+                c_sel = (a_best >> 6) == j ? (uint32_t)civ[j] : c_sel;
+            }
+            node_n = (uint32_t)__shfl((int)n_sel, a_best & 63, 64);
+            node = __shfl((int)c_sel, a_best & 63, 64);
+        }
         h = T.hdr[node];
     }
+}
+
+// Does a stone at cell `a` make exactly five with the `own` stones along direction pair `pr` (0: horizontal, 1: vertical, 2: (-1,-1)/(1,1), 3: (-1,1)/(1,-1))?
+// The reference's run counts (environment/src/lib.rs:112-145, 179-190: consecutive own stones from the new one outwards, at most 5 per ray) for ONE pair of opposite rays,
+// per lane: `a` and `pr` may differ between lanes, `own` is the mover's bitboard WITHOUT the new stone (the rays start next to it).  exactly_five() is the OR over pr.
+template <int N>
+__device__ inline bool five_in_pair(const uint64_t* own, int a, int pr) {
+    constexpr int NW = Geo<N>::NW;
+    const int dx = pr == 1 ? 0 : -1, dy = pr == 0 ? 0 : (pr == 3 ? 1 : -1);
+    const int x0 = a % N, y0 = a / N;
+    int run_a = 0, run_b = 0;
+    bool on_a = true, on_b = true;
+#pragma unroll
+    for (int k = 1; k <= 5; ++k) {
+        const int xa = x0 + dx * k, ya = y0 + dy * k, xb = x0 - dx * k, yb = y0 - dy * k;
+        const bool in_a = xa >= 0 && xa < N && ya >= 0 && ya < N, in_b = xb >= 0 && xb < N && yb >= 0 && yb < N;
+        on_a = on_a && in_a && get_bit<NW>(own, in_a ? ya * N + xa : 0) != 0;
+        on_b = on_b && in_b && get_bit<NW>(own, in_b ? yb * N + xb : 0) != 0;
+        run_a += on_a ? 1 : 0;
+        run_b += on_b ? 1 : 0;
+    }
+    return 1 + run_a + run_b == 5;
+}
+// index of the r-th (0-based) set bit of w, r < popcount(w); per lane (w and r may differ between lanes)
+__device__ inline int nth_set_bit_lane(uint64_t w, int r) {
+    uint64_t cur = w;
+    int base = 0;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        const uint64_t low = cur & ((1ULL << sh) - 1ULL);
+        const int c = __popcll(low);
+        const bool up = r >= c;
+        r -= up ? c : 0;
+        base += up ? sh : 0;
+        cur = up ? (cur >> sh) : low;
+    }
+    return base;
 }
 
 template <int N>
@@ -566,6 +639,10 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
     constexpr int ROWP = G::ROWP, NW = G::NW;
     const int lane = LANE;
     int done = 0;
+#ifdef KROUND_PROF
+    unsigned long long (&kp)[8] = R.kp;
+    unsigned long long& kp_last = R.kp_last;
+#endif
     while (done < count) {
         // ---- the leaf (run_sim's head) ----
         int node = 0;
@@ -581,6 +658,7 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
         else { fence_own_stores(R); h = T.hdr[node]; }
         if (h.nch == h.legal && h.nch != 0) { fence_own_stores(R); C.node = -1; }
         select_leaf<N>(T, h, node, node_n, path_bytes);
+        KP(2); // descents (+ header loads)
         R.memo_node = node;
         R.memo_n = node_n;
         R.memo_bytes = path_bytes;
@@ -592,6 +670,7 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
             C.node = -1;
             __syncthreads();
             done += 1;
+            KP(3); // terminal-leaf backups
             continue;
         }
         // ---- the leaf's board and untried cells (cached, or loaded once) ----
@@ -622,6 +701,7 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
             for (int j = 0; j < G::IT; ++j) C.cand[j] = cand[j];
             C.h = h;
         }
+        KP(4); // leaf board / untried cells
         const unsigned long long sim_bytes = path_bytes + 2 * (G::HW / 8);
         if (total == 0) { R.bytes += sim_bytes; done += 1; continue; } // "There's no action for now": this simulation is consumed
         // ---- how many simulations this leaf can take: the rest of the round, its untried cells, the room in the arenas ----
@@ -640,6 +720,39 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
         uint32_t my_x = 0u;
         if (lane < m) my_x = philox(A.seed, first_sim + (uint32_t)(done + lane), (uint32_t)A.ply, tree_global, RNG_EXPAND).x;
         int my_action = 0, my_status = ST_IN_PROGRESS;
+#if PARALLEL_PICKS
+        {
+            // Simulation i draws r_i = floor(x_i (total - i) / 2^32) and takes the r_i-th of the cells the earlier ones left.  In RANK space (rank = position among the leaf's
+            // untried cells as they are now): with the ranks taken so far sorted, s_0 < s_1 < ..., the r-th remaining rank is r + #{j : s_j - j <= r}.  The sorted list lives across
+            // the lanes (lane j: s_j), so a pick is one ballot and one shuffle; the ranks turn into cells for all simulations at once.  The same cells as picking one by one
+            // (the loop this replaces: ~1100 cycles per pick, a quarter of the kernel for the average tree).
+            const int my_r = lane < m ? (int)__umulhi(my_x, (uint32_t)(total - lane)) : 0;
+            int sorted = 0x7FFFFFFF, my_q = 0; // lane j: the j-th smallest rank taken so far
+            for (int i = 0; i < m; ++i) {
+                const int r = __builtin_amdgcn_readlane(my_r, i);
+                const int k = __popcll(__ballot(lane < i && sorted - lane <= r));
+                const int q = r + k;
+                const int up = __shfl_up(sorted, 1, 64);
+                sorted = lane < k ? sorted : (lane == k ? q : up);
+                if (lane == i) my_q = q;
+            }
+            // rank -> cell: the my_q-th set bit of the untried mask
+            int cum = 0, wj = 0, rr = my_q;
+            uint64_t wsel = cand[0];
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) {
+                const int c = __popcll(cand[j]);
+                if (my_q >= cum && my_q < cum + c) { wj = j; rr = my_q - cum; wsel = cand[j]; }
+                cum += c;
+            }
+            if (lane < m) my_action = wj * 64 + nth_set_bit_lane(wsel, rr);
+            for (int i = 0; i < m; ++i) { // the picked cells are no longer untried
+                const int a = __builtin_amdgcn_readlane(my_action, i);
+#pragma unroll
+                for (int j = 0; j < G::IT; ++j) cand[j] &= ~((a >> 6) == j ? (1ULL << (a & 63)) : 0ULL);
+            }
+        }
+#else
         {
             int tot = total;
             for (int i = 0; i < m; ++i) {
@@ -661,8 +774,37 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
                 tot -= 1;
             }
         }
+#endif
+        KP(5); // picks
         // ---- place the stones (pme.rs:128-135): win check per child, up to the first terminal one ----
         int n_commit = m, term_status = ST_IN_PROGRESS;
+#if PARALLEL_PICKS
+        {
+            // lane 4 c + p checks direction pair p of child c (16 children at a time); a child is a win if any of its four pairs makes exactly five, a draw if it took the
+            // leaf's last cell; the first terminal child ends the batch (the loop this replaces checked one child at a time with 40 lanes: ~1300 cycles each)
+            uint64_t own[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) own[w] = h.turn == 0 ? bb[w] : bb[NW + w];
+            int first = -1;
+            bool first_five = false;
+            for (int c0 = 0; c0 < m && first < 0; c0 += 16) {
+                const int c = c0 + (lane >> 2);
+                const int a = __shfl(my_action, c < m ? c : 0, 64);
+                const bool five = c < m && five_in_pair<N>(own, a, lane & 3);
+                unsigned long long fm = __ballot(five);
+                fm |= fm >> 1;
+                fm |= fm >> 2; // bit 4 k: child c0 + k has a five
+                fm &= 0x1111111111111111ULL;
+                if (fm) { first = c0 + ((__ffsll((long long)fm) - 1) >> 2); first_five = true; }
+            }
+            if (h.legal == 1) { first_five = first == 0; first = 0; } // (m == 1: the child fills the board)
+            if (first >= 0) {
+                n_commit = first + 1;
+                term_status = first_five ? (h.turn == 0 ? ST_BLACK_WIN : ST_WHITE_WIN) : ST_DRAW;
+                if (lane == first) my_status = term_status;
+            }
+        }
+#else
         for (int i = 0; i < m; ++i) {
             const int a = __builtin_amdgcn_readlane(my_action, i);
             uint64_t mine[NW];
@@ -674,6 +816,8 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
             if (lane == i) my_status = st;
             if (st != ST_IN_PROGRESS) { n_commit = i + 1; term_status = st; break; }
         }
+#endif
+        KP(6); // win checks
         // ---- expand (node.rs:61-81), n_commit children in one pass ----
         int tab = h.table;
         if (tab == NONE16) {
@@ -734,10 +878,14 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
 #pragma unroll
             for (int j = 0; j < G::IT; ++j) C.cand[j] = cand[j];
         }
+        KP(7); // expansion stores (+ a terminal child's backup)
         done += n_commit;
     }
 }
 
+#ifndef SCATTER_SEGMENTS
+#define SCATTER_SEGMENTS 1 // (A-B builds: 0 = rounds with several request parents back up one request at a time, as in round 4; same results)
+#endif
 #ifndef KROUND_BATCH
 #define KROUND_BATCH 1 // 0: one simulation at a time (run_sim; A-B builds and the reference point of the batched form)
 #endif
@@ -755,6 +903,11 @@ __global__ __launch_bounds__(64, KROUND_WPS) void k_round(Store S, RoundArgs A) 
     const Tree<N> T(S, t);
     const TreeState ts = *T.ts;
     Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
+#ifdef KROUND_PROF
+    unsigned long long (&kp)[8] = R.kp;
+    unsigned long long& kp_last = R.kp_last;
+    kp_last = __builtin_readcyclecounter();
+#endif
 #ifndef KROUND_EXP
 #define KROUND_EXP 0 // timing-only A-B builds: 1 = no deferred backups, 2 = no simulations
 #endif
@@ -769,7 +922,9 @@ __global__ __launch_bounds__(64, KROUND_WPS) void k_round(Store S, RoundArgs A) 
     // two coincide; in slots mode a slot's later games have their own ids and start their plies at 0
     A.ply = gs0.plies;
     const uint32_t tree_global = (uint32_t)((A.game_offset + gs0.gid) * 2 + A.side);
+    KP(0); // state loads + the previous round's backups
     if (A.round == 0) apply_noise<N>(T, A, tree_global, s_row);
+    KP(1); // noise
     LeafCache<N> C;
     if (KROUND_EXP == 2) { /* timing only */ }
     else if (KROUND_BATCH) run_sims<N>(S, T, R, C, A, (uint32_t)(A.round * A.K), A.K, tree_global);
@@ -780,8 +935,21 @@ __global__ __launch_bounds__(64, KROUND_WPS) void k_round(Store S, RoundArgs A) 
         o.error = R.error; o.n_req = R.n_req;
         *T.ts = o;
         atomicAdd(S.d_bytes, R.bytes);
+#ifdef KROUND_PROF
+        const unsigned int L = (unsigned int)A.round & 63u;
+        if (t < 8192)
+            for (int i = 0; i < 8; ++i) g_kprof[L][t][i] = kp[i];
+#endif
     }
 }
+#ifdef KROUND_PROF
+extern "C" void omok_debug_kround_prof(unsigned long long* out /* [64][8192][8] */) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kprof), sizeof(unsigned long long) * 64 * 8192 * 8);
+    static unsigned long long zero[1] = {0};
+    (void)zero;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // ONE TREE SEARCHED BY MANY WAVES: MCTSExecutor::run (alpha-zero/src/mcts_executor.rs:29-255), the executor of the GUI and of
@@ -1244,13 +1412,19 @@ __global__ __launch_bounds__(64) void k_softmax_scatter_policy(Store S, const fl
 // backup of a terminal node between them moved the descent) take the plain per-request walk.
 // (device function: k_scatter proper, and the head of k_round when the run loop defers a round's backups into the next round's kernel --
 //  the backups then warm the very nodes the descent reads, and the round needs one launch less)
+// The backups of a round's requests (node.rs:83-99, in request order).  A tree's requests are children of ONE leaf in ~95 % of its rounds; in the others the leaf filled up
+// (or a terminal child sent the next simulation elsewhere) in mid-round and they fall into two or three SEGMENTS of consecutive requests with one parent each.  A segment's
+// requests share the path above their parent, so its backups are taken together: lane i holds the path's level i, the values are added level by level in request order
+// (the same additions in the same order as one backup after the other), one store per slot.  Segments follow each other in request order with the earlier one's stores landed
+// first (their paths share the slots near the root).  Round 5: before, any round with a second parent took all K backups one by one, a walk of dependent loads and a store
+// fence each -- 4-7 % of the trees in EVERY round from ply 0 on (a leaf fills up every 14 rounds), and with every tree's wave resident at once those were k_round's time.
 template <int N>
 __device__ inline void scatter_tree(const Store& S, const Tree<N>& T, const TreeState& ts, Regs& R, const float* __restrict__ V) {
     using G = Geo<N>;
     constexpr int ROWP = G::ROWP;
     const int lane = LANE, nreq = (int)ts.n_req;
     // every request's node, its parent and action (one lane per request; n_req <= KMAX = 64)
-    int x = 0, par = -1, act = 0;
+    int x = 0, par = -1 - lane, act = 0;
     float val = 0.0f;
     if (lane < nreq) {
         x = (int)T.req[lane];
@@ -1259,54 +1433,71 @@ __device__ inline void scatter_tree(const Store& S, const Tree<N>& T, const Tree
         act = (int)hx.action;
         val = V[(size_t)ts.req_base + lane];
     }
-    const int leaf = __shfl(par, 0, 64);
-    const bool same = __ballot(lane < nreq && par != leaf) == 0ULL;
-    // the path above the leaf: level 0 = the leaf's slot in its parent's table, ... up to the child of the root
-    int depth = 0;
-    size_t my_slot = 0;
-    uint32_t my_n = 0;
-    float my_w = 0.0f;
-    bool fits = same;
-    if (same) {
-        int y = leaf;
-        while (y != 0) {
-            const NodeHdr h = T.hdr[y];
-            const size_t slot = (size_t)T.hdr[h.parent].table * ROWP + h.action;
-            const uint32_t n = T.cn[slot];
-            const float w = T.cw[slot];
-            if (lane == depth) { my_slot = slot; my_n = n; my_w = w; }
-            y = h.parent;
-            depth += 1;
-            if (depth >= 64) { fits = y == 0; break; }
-        }
-    }
-    if (fits) {
-        const size_t tab_leaf = (size_t)T.hdr[leaf].table * ROWP;
-        // own slots: n += 1, w += -v (the first step of propagate), one lane per request
-        if (lane < nreq) {
-            const size_t slot = tab_leaf + act;
-            const uint32_t n = T.cn[slot] + 1u;
-            const float w = T.cw[slot] + (-val);
-            T.cn[slot] = n;
-            T.cw[slot] = w;
-        }
-        // levels and root: the value alternates its sign with the distance; level i (distance i + 1 from the request) gets +v for even i
-        float root_w = R.root_w;
-        const float sgn_root = (depth & 1) ? -1.0f : 1.0f;
-        for (int r = 0; r < nreq; ++r) {
-            const float v = __shfl(val, r, 64);
-            if (lane < depth) { my_n += 1u; my_w += (lane & 1) ? -v : v; }
-            root_w += sgn_root * v; // (+-v exactly: a multiplication by +-1)
-        }
-        if (lane < depth) { T.cn[my_slot] = my_n; T.cw[my_slot] = my_w; }
-        R.root_n += (uint32_t)nreq;
-        R.root_w = root_w;
-        R.bytes += (unsigned long long)nreq * (16ull * (unsigned long long)(depth + 1) + 16ull + 8ull * G::HW + 4ull);
-    } else {
+    const int prev_par = __shfl_up(par, 1, 64);
+    unsigned long long rem = __ballot(lane < nreq && (lane == 0 || par != prev_par)); // segment starts
+#if SCATTER_SEGMENTS == 0
+    if (__popcll(rem) > 1) { // (A-B builds: the round-4 form -- a second parent sends every backup of the round through the walk)
         for (uint32_t r = 0; r < ts.n_req; ++r) {
             backup<N>(T, R, T.req[r], -V[(size_t)ts.req_base + r]);
             __syncthreads();
             R.bytes += 8ull * G::HW + 4;
+        }
+        return;
+    }
+#endif
+    while (rem) {
+        const int s0 = __ffsll((long long)rem) - 1;
+        rem &= rem - 1ULL;
+        const int s1 = rem ? __ffsll((long long)rem) - 1 : nreq; // the segment = requests [s0, s1)
+        const int leaf = __shfl(par, s0, 64);
+        // the path above the leaf: level 0 = the leaf's slot in its parent's table, ... up to the child of the root
+        int depth = 0;
+        size_t my_slot = 0;
+        uint32_t my_n = 0;
+        float my_w = 0.0f;
+        bool fits = true;
+        {
+            int y = leaf;
+            while (y != 0) {
+                const NodeHdr h = T.hdr[y];
+                const size_t slot = (size_t)T.hdr[h.parent].table * ROWP + h.action;
+                const uint32_t n = T.cn[slot];
+                const float w = T.cw[slot];
+                if (lane == depth) { my_slot = slot; my_n = n; my_w = w; }
+                y = h.parent;
+                depth += 1;
+                if (depth >= 64) { fits = y == 0; break; }
+            }
+        }
+        if (fits) {
+            const size_t tab_leaf = (size_t)T.hdr[leaf].table * ROWP;
+            // own slots: n += 1, w += -v (the first step of propagate), one lane per request
+            if (lane >= s0 && lane < s1) {
+                const size_t slot = tab_leaf + act;
+                const uint32_t n = T.cn[slot] + 1u;
+                const float w = T.cw[slot] + (-val);
+                T.cn[slot] = n;
+                T.cw[slot] = w;
+            }
+            // levels and root: the value alternates its sign with the distance; level i (distance i + 1 from the request) gets +v for even i
+            float root_w = R.root_w;
+            const float sgn_root = (depth & 1) ? -1.0f : 1.0f;
+            for (int r = s0; r < s1; ++r) {
+                const float v = __shfl(val, r, 64);
+                if (lane < depth) { my_n += 1u; my_w += (lane & 1) ? -v : v; }
+                root_w += sgn_root * v; // (+-v exactly: a multiplication by +-1)
+            }
+            if (lane < depth) { T.cn[my_slot] = my_n; T.cw[my_slot] = my_w; }
+            R.root_n += (uint32_t)(s1 - s0);
+            R.root_w = root_w;
+            R.bytes += (unsigned long long)(s1 - s0) * (16ull * (unsigned long long)(depth + 1) + 16ull + 8ull * G::HW + 4ull);
+            if (rem) __syncthreads(); // the next segment's path shares slots with this one: its loads come after these stores
+        } else {
+            for (int r = s0; r < s1; ++r) {
+                backup<N>(T, R, (int)T.req[r], -V[(size_t)ts.req_base + (uint32_t)r]);
+                __syncthreads();
+                R.bytes += 8ull * G::HW + 4;
+            }
         }
     }
 }

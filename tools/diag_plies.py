@@ -1,0 +1,16 @@
+import os, sys
+sys.path.insert(0, "/root/repo")
+import omok_ai_amd as oa
+eng = oa.Engine(board_size=15, games=4096, max_nodes=4224, max_tables=1056, max_batch_k=16, seed=0)
+eng.load_random_weights(0)
+sp = oa.SelfPlay(eng)
+sp.set_episode(1); sp.reset()
+ply = 0
+while sp.alive_count > 0:
+    a = sp.alive_count
+    eng.reset_stats()
+    sp.run(800, 16, max_plies=1)
+    sys.stderr.write(f"ply {ply} alive {a} ")
+    sys.stderr.flush()
+    eng.stats()
+    ply += 1
