@@ -433,13 +433,31 @@ __device__ void apply_noise(const Tree<N>& T, const RoundArgs& A, uint32_t tree_
     __syncthreads();
 }
 
+// What a descent FROM THE ROOT passed, level by level (wave-uniform, scalar registers): the table slot it took and that slot's (n, w) as the scan read them.  A simulation
+// that ends on a terminal leaf is backed up along exactly these slots, and nothing writes them between the scan and the backup: the backup needs no walk and no load
+// (k_round's slowest trees -- those that spend a round on root -> terminal descents -- spent a fifth of their time in that walk).
+constexpr int PR_LEVELS = 3;
+struct PathRec {
+    int tab[PR_LEVELS], act[PR_LEVELS];
+    uint32_t n[PR_LEVELS];
+    float w[PR_LEVELS];
+    int depth; // levels recorded by the last descent; < 0: it did not start at the root, > PR_LEVELS: deeper than the record
+};
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline NodeHdr uni(const NodeHdr& h) {
+    uint4 q = __builtin_bit_cast(uint4, h);
+    q.x = (uint32_t)uni((int)q.x); q.y = (uint32_t)uni((int)q.y); q.z = (uint32_t)uni((int)q.z); q.w = (uint32_t)uni((int)q.w);
+    return __builtin_bit_cast(NodeHdr, q);
+}
+
 // select_leaf (node.rs:43-58) with the PUCT selector (pme.rs:81-90): from (node, h) down while the node is fully expanded; the last maximal child in
 // insertion order wins (max_by).  Updates node, its header, its visit count as stored in its parent's table, and the algorithmic bytes of the path.
-template <int N>
-__device__ inline void select_leaf(const Tree<N>& T, NodeHdr& h, int& node, uint32_t& node_n, unsigned long long& path_bytes) {
+template <int N, bool REC>
+__device__ inline void select_leaf_impl(const Tree<N>& T, NodeHdr& h, int& node, uint32_t& node_n, unsigned long long& path_bytes, PathRec& rec) {
     using G = Geo<N>;
     constexpr int ROWP = G::ROWP;
     const int lane = LANE;
+    int lev = 0;
     while (h.nch == h.legal && h.nch != 0) {
         const uint32_t pn = node_n > 1u ? node_n : 1u;
         const float sq = __fsqrt_rn((float)pn);
@@ -480,18 +498,38 @@ __device__ inline void select_leaf(const Tree<N>& T, NodeHdr& h, int& node, uint
         best = wave_max_u64(best);
         const int a_best = (int)(best & 0xFFFFu);
         path_bytes += 12ull * h.nch;
-        { // the chosen child's n and index are in the registers of the lane that scanned it
+        { // the chosen child's n, w and index are in the registers of the lane that scanned it
             uint32_t n_sel = nv[0], c_sel = civ[0];
+            float w_sel = wv[0];
 #pragma unroll
             for (int j = 1; j < G::IT; ++j) {
                 n_sel = (a_best >> 6) == j ? nv[j] : n_sel;
                 c_sel = (a_best >> 6) == j ? (uint32_t)civ[j] : c_sel;
+                w_sel = (a_best >> 6) == j ? wv[j] : w_sel;
             }
             node_n = (uint32_t)__shfl((int)n_sel, a_best & 63, 64);
             node = __shfl((int)c_sel, a_best & 63, 64);
+            if (REC) {
+                const float w_best = __shfl(w_sel, a_best & 63, 64);
+#pragma unroll
+                for (int l = 0; l < PR_LEVELS; ++l)
+                    if (l == lev) {
+                        rec.tab[l] = uni((int)h.table);
+                        rec.act[l] = uni(a_best);
+                        rec.n[l] = (uint32_t)uni((int)node_n);
+                        rec.w[l] = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, w_best)));
+                    }
+            }
         }
         h = T.hdr[node];
+        lev += 1;
     }
+    if (REC) rec.depth = lev;
+}
+template <int N>
+__device__ inline void select_leaf(const Tree<N>& T, NodeHdr& h, int& node, uint32_t& node_n, unsigned long long& path_bytes) {
+    PathRec none;
+    select_leaf_impl<N, false>(T, h, node, node_n, path_bytes, none);
 }
 
 // Does a stone at cell `a` make exactly five with the `own` stones along direction pair `pr` (0: horizontal, 1: vertical, 2: (-1,-1)/(1,1), 3: (-1,1)/(1,-1))?
@@ -643,6 +681,10 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
     unsigned long long (&kp)[8] = R.kp;
     unsigned long long& kp_last = R.kp_last;
 #endif
+    PathRec rec;
+    rec.depth = -1;
+    NodeHdr root_h; // the root's header while nothing is added under the root (a round of terminal simulations starts at the root K times)
+    bool root_ok = false;
     while (done < count) {
         // ---- the leaf (run_sim's head) ----
         int node = 0;
@@ -654,21 +696,50 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
             path_bytes = R.memo_bytes;
         } else C.node = -1;
         NodeHdr h;
+        const bool from_root = R.memo_node < 0; // (node == 0)
         if (C.node == node) h = C.h;
-        else { fence_own_stores(R); h = T.hdr[node]; }
+        else if (from_root && root_ok) h = root_h;
+        else {
+            fence_own_stores(R);
+            h = T.hdr[node];
+            if (from_root) { root_h = uni(h); root_ok = true; }
+        }
         if (h.nch == h.legal && h.nch != 0) { fence_own_stores(R); C.node = -1; }
-        select_leaf<N>(T, h, node, node_n, path_bytes);
+        if (from_root) select_leaf_impl<N, true>(T, h, node, node_n, path_bytes, rec);
+        else {
+            select_leaf<N>(T, h, node, node_n, path_bytes);
+            rec.depth = -1;
+        }
         KP(2); // descents (+ header loads)
         R.memo_node = node;
         R.memo_n = node_n;
         R.memo_bytes = path_bytes;
         if (h.status != ST_IN_PROGRESS) { // terminal leaf (pme.rs:92-97): one simulation
             R.bytes += path_bytes;
-            fence_own_stores(R);
-            backup<N>(T, R, node, h.status >= ST_BLACK_WIN ? 1.0f : 0.0f);
+            if (rec.depth >= 0 && rec.depth <= PR_LEVELS) { // node.rs:83-99 along the recorded slots: the same additions, leaf's slot first, the sign alternating upwards
+                float v = h.status >= ST_BLACK_WIN ? 1.0f : 0.0f;
+#pragma unroll
+                for (int l = PR_LEVELS - 1; l >= 0; --l)
+                    if (l < rec.depth) {
+                        if (lane == 0) {
+                            const size_t slot = (size_t)rec.tab[l] * ROWP + rec.act[l];
+                            T.cn[slot] = rec.n[l] + 1u;
+                            T.cw[slot] = rec.w[l] + v;
+                        }
+                        v = -v;
+                        R.bytes += 16;
+                    }
+                R.root_n += 1u;
+                R.root_w += v;
+                R.bytes += 16;
+                R.dirty = true; // (the next descent reads these slots: it waits for the stores first)
+            } else {
+                fence_own_stores(R);
+                backup<N>(T, R, node, h.status >= ST_BLACK_WIN ? 1.0f : 0.0f);
+                __syncthreads();
+            }
             R.memo_node = -1;
             C.node = -1;
-            __syncthreads();
             done += 1;
             KP(3); // terminal-leaf backups
             continue;
@@ -867,6 +938,7 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
         R.dirty = true;
         h.table = (uint16_t)tab;
         h.nch = (uint16_t)(h.nch + n_commit);
+        if (node == 0) root_ok = false; // (the root's stored header has changed)
         if (term_status != ST_IN_PROGRESS) { // pme.rs:177-181: the terminal child's reward goes up the path now; the next simulation starts at the root again
             fence_own_stores(R);
             backup<N>(T, R, idx0 + n_commit - 1, term_status == ST_DRAW ? 0.0f : 1.0f);
