@@ -757,11 +757,13 @@ __device__ void run_sims(const Store& S, const Tree<N>& T, Regs& R, LeafCache<N>
             fence_own_stores(R);
 #pragma unroll
             for (int i = 0; i < 2 * NW; ++i) bb[i] = T.board[(size_t)node * (2 * NW) + i];
+            uint8_t ordc[G::IT]; // (the insertion ranks go out with the board words, not behind them)
+#pragma unroll
+            for (int j = 0; j < G::IT; ++j) ordc[j] = h.table != NONE16 ? T.corder[(size_t)h.table * ROWP + j * 64 + lane] : NONE8;
 #pragma unroll
             for (int j = 0; j < G::IT; ++j) {
                 const int a = j * 64 + lane;
-                bool c = a < G::HW && !(((bb[j] | bb[NW + j]) >> lane) & 1ULL);
-                if (c && h.table != NONE16) c = T.corder[(size_t)h.table * ROWP + a] == NONE8;
+                const bool c = a < G::HW && !(((bb[j] | bb[NW + j]) >> lane) & 1ULL) && ordc[j] == NONE8;
                 cand[j] = __ballot(c);
                 total += __popcll(cand[j]);
             }
@@ -969,11 +971,11 @@ __global__ __launch_bounds__(64, KROUND_WPS) void k_round(Store S, RoundArgs A) 
     using G = Geo<N>;
     __shared__ float s_row[G::ROWP];
     const int g = blockIdx.x;
-    const GameState gs0 = S.gs[g];
-    if (!gs0.alive) return;
     const int t = A.side * S.games + g;
     const Tree<N> T(S, t);
-    const TreeState ts = *T.ts;
+    const GameState gs0 = S.gs[g];
+    const TreeState ts = *T.ts; // (issued with the game's state, not behind it)
+    if (!gs0.alive) return;
     Regs R{ts.n_nodes, ts.n_tables, ts.root_n, 0u, ts.error, ts.root_w, 0ull};
 #ifdef KROUND_PROF
     unsigned long long (&kp)[8] = R.kp;
