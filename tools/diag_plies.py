@@ -1,3 +1,7 @@
+"""Per-ply counters of k_round (root descents, terminal simulations, multi-parent rounds) on a DIAGNOSTIC build of the library: apply
+docs/experiments/r05_lds_staged_path.diff's -DKROUND_COUNT hunks (tree_kernels.hip, engine.cpp), build it as tools/ab/libomok_cnt.so and run
+   OMOK_MI355X_LIB=tools/ab/libomok_cnt.so python3 tools/diag_plies.py
+The product library prints nothing here (the counters do not exist in it)."""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import omok_ai_amd as oa
