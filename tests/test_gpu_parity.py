@@ -322,6 +322,8 @@ def _drive_selfplay_vs_oracle(n, games, count, k, max_plies, mode, threshold=6, 
     (9, 6, 48, 8, 0, B.NET_F16X3),     # whole games to the end on the reference's board size
     (9, 3, 40, 16, 12, B.NET_F32),     # count not a multiple of K (rounds up), fp32 net path
     (15, 3, 64, 16, 6, B.NET_F16X3),   # the benchmark board, shallow
+    (9, 3, 64, 32, 0, B.NET_F16X3),    # K = 32: batches of more than 16 children (two passes of the 16-at-a-time win checks), whole games
+    (9, 2, 128, 64, 0, B.NET_F16X3),   # K = KMAX = 64: a batch as wide as the wave (the sorted ranks of the picks fill every lane)
 ])
 def test_selfplay_bit_exact_vs_oracle(n, games, count, k, max_plies, mode):
     _drive_selfplay_vs_oracle(n, games, count, k, max_plies, mode)
