@@ -1804,7 +1804,7 @@ __global__ __launch_bounds__(512) void k_sib_children(const uint64_t* __restrict
 // depthwise) and need not be bit-identical -- on the rows the tests compare they are, every layer boundary re-quantising to ~22 bits -- so the difference path
 // is tolerance-checked; the copy path (rows bit-identical to a full evaluation by construction) keeps k_sib_children.
 #ifndef SIB2_EXP
-#define SIB2_EXP 0 // A-B builds (tools/build_variant.sh): 1 = every child reads base slot 0 (timing only), 3 = a workgroup barrier per pass, 6 = per 4 passes, 4 = plain stores, 7 = no stores (timing only), 8 = contiguous shares per wave (round 3), 9 / 10 = no conv_in / block 0 (timing only)
+#define SIB2_EXP 0 // A-B builds (tools/build_variant.sh): 1 = every child reads base slot 0 (timing only), 3 = a workgroup barrier per pass, 6 = per 4 passes, 4 = plain stores, 7 = no stores (timing only), 8 = contiguous shares per wave (round 3), 9 / 10 = no conv_in / block 0 (timing only), 17 = every wave's cycles per launch -> stderr (diagnostic, results unchanged)
 #endif
 #if SIB2_EXP != 0 && !defined(OMOK_EXPERIMENT)
 #error "SIB2_EXP builds are timing experiments, most with wrong results: build them with -DOMOK_EXPERIMENT (tools/build_variant.sh does), never as the product"
@@ -1861,6 +1861,9 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
     for (int i = tid; i < 8 * V2_WAVE_FLOATS; i += blockDim.x) ((float*)(smem + TR_WBYTES + TR_SIDE_FLOATS * 4))[i] = 0.0f;
     __syncthreads(); // (the only workgroup barrier: from here on a wave touches read-only LDS and its own cells)
     for (int i = 0; i < (wv >> 2); ++i) __builtin_amdgcn_s_sleep(120); // the two waves of a SIMD (w, w + 4) start about half a pass apart
+#if SIB2_EXP == 17 // (diagnostic, results unchanged: every wave's cycles from here to its end -> tprof[workgroup * 8 + wave], summed over the launches)
+    const unsigned long long wt0 = __builtin_readcyclecounter();
+#endif
     const int nsib = d_cnt[2];
     const bool st_on = SIB2_EXP != 7 || nsib < 0; // (timing experiment 7: no difference-row stores; a run-time condition, so that nothing is dead code)
     const half8* convW = (const half8*)(wt + TR_WBYTES / 16);
@@ -2522,6 +2525,9 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
     }
     if (TPROF && lane == 0 && (wv == 0 || wv == 5))
         for (int i = 0; i < 12; ++i) atomicAdd(&tprof[(wv ? 16 : 0) + i], tp_acc[i]);
+#if SIB2_EXP == 17
+    if (lane == 0 && tprof) atomicAdd(&tprof[blockIdx.x * 8 + wv], __builtin_readcyclecounter() - wt0);
+#endif
 }
 
 #undef OL
@@ -4141,9 +4147,39 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
     net.children_launches[v2 ? 0 : 1] += 1.0;
     if (v2) {
         static const int rep = repeat_env("OMOK_REPEAT_CHILDREN");
+        unsigned long long* wave_times = nullptr;
+#if SIB2_EXP == 17
+        static unsigned long long* d_wt = nullptr;
+        static int wt_launches = 0;
+        if (!d_wt) { hipMalloc(&d_wt, 2048 * 8); hipMemset(d_wt, 0, 2048 * 8); }
+        wave_times = d_wt;
+#endif
         for (int r = 0; r < rep; ++r)
         sib2_kernel(x16, net.n, mixed)<<<256, 512, V2_LDS, st>>>(S.board, (const uint4*)net.wt_trunk, net.wt_first, (uint4*)net.a_base, net.row_u4, (const uint4*)net.d_sib_rows,
-                                                          net.d_gcnt, (const uint4*)net.sib_h, net.d_sib_slot, net.d_bin_start, (uint4*)net.d_rows, (uint2*)net.d_slot_desc, nullptr);
+                                                          net.d_gcnt, (const uint4*)net.sib_h, net.d_sib_slot, net.d_bin_start, (uint4*)net.d_rows, (uint2*)net.d_slot_desc, wave_times);
+#if SIB2_EXP == 17
+        if (++wt_launches % 150 == 0) {
+            static unsigned long long h[2048];
+            hipStreamSynchronize(st);
+            hipMemcpy(h, d_wt, sizeof(h), hipMemcpyDeviceToHost);
+            hipMemset(d_wt, 0, sizeof(h));
+            double sum = 0, mx = 0, mn = 1e30, wgmax = 0, wgsum = 0, xcd[8] = {}, early = 0, late = 0;
+            for (int b = 0; b < 256; ++b) {
+                double wm = 0;
+                for (int w = 0; w < 8; ++w) {
+                    const double v = (double)h[b * 8 + w] / 150.0;
+                    sum += v; mx = v > mx ? v : mx; mn = v < mn ? v : mn; wm = v > wm ? v : wm;
+                    (w < 4 ? early : late) += v;
+                }
+                wgsum += wm; wgmax = wm > wgmax ? wm : wgmax;
+                xcd[b & 7] += wm;
+            }
+            fprintf(stderr, "[sib2 wave times] cycles per launch: wave mean %.0f min %.0f max %.0f | slowest wave of a workgroup: mean %.0f max %.0f (max / mean %.3f) | waves 0-3 mean %.0f, 4-7 mean %.0f | per XCD:",
+                    sum / 2048, mn, mx, wgsum / 256, wgmax, wgmax / (wgsum / 256), early / 1024, late / 1024);
+            for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f", xcd[x] / 32);
+            fprintf(stderr, "\n");
+        }
+#endif
         return;
     }
     if (tprof && !x16 && net.n == 15) {
