@@ -2016,15 +2016,34 @@ __device__ int transition(const Store& S, const Tree<N>& T, int action, uint8_t*
             for (int q = 0; q < 2 * NW; ++q) T.board[(size_t)dst * (2 * NW) + q] = bw[q];
         }
         unsigned long long m = __ballot(a && h.has_policy && dst != i);
-        while (m) { // policy rows, one node at a time, whole wave copies
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int src = base + l, d = s_nmap[src];
-            float v[G::IT];
+        while (m) { // policy rows: the whole wave copies a row; four rows' loads go out before their stores (one row at a time was a dependent round trip per surviving
+                    // node, most of this kernel's time).  Ascending with dst <= src: a store never reaches a row that is still to be read (src' > src >= dst).
+            constexpr int PB = 4;
+            int srcs[PB], dsts[PB];
+            float v[PB][G::IT];
 #pragma unroll
-            for (int j = 0; j < G::IT; ++j) v[j] = T.pol[(size_t)src * ROWP + j * 64 + lane];
+            for (int q = 0; q < PB; ++q) {
+                srcs[q] = -1;
+                dsts[q] = 0;
+                if (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    srcs[q] = base + l;
+                    dsts[q] = s_nmap[base + l];
+                }
+            }
 #pragma unroll
-            for (int j = 0; j < G::IT; ++j) T.pol[(size_t)d * ROWP + j * 64 + lane] = v[j];
+            for (int q = 0; q < PB; ++q)
+                if (srcs[q] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < G::IT; ++j) v[q][j] = T.pol[(size_t)srcs[q] * ROWP + j * 64 + lane];
+                }
+#pragma unroll
+            for (int q = 0; q < PB; ++q)
+                if (srcs[q] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < G::IT; ++j) T.pol[(size_t)dsts[q] * ROWP + j * 64 + lane] = v[q][j];
+                }
         }
         __syncthreads();
     }
