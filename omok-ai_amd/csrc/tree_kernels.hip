@@ -17,6 +17,7 @@
 // computed uniformly by all lanes and stored by lane 0.  A __syncthreads() (single-wave
 // workgroup: a fence + waitcnt) separates global stores from later cross-lane loads.
 #include "common.h"
+#include <type_traits>
 
 namespace omok {
 
@@ -134,13 +135,39 @@ __device__ float gamma_draw(float alpha_f, uint64_t seed, uint32_t cell, uint32_
 // ---------------------------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------------------------
+#ifndef WAVE_MAX_DPP
+#define WAVE_MAX_DPP 1 // (A-B builds: 0 = the butterfly of 64-bit shuffles, 12 ds_bpermute in a dependent chain; same result)
+#endif
+// unsigned maximum over the 64 lanes by data-parallel-primitive moves (no LDS crossbar): inclusive max-scan inside each row of 16 lanes (row_shr 1, 2, 4, 8; lanes without
+// a source keep the identity 0), lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast15), lane 31 into rows 2 and 3 (row_bcast31): lane 63 holds the wave's maximum.
+__device__ inline uint32_t wave_max_u32_dpp(uint32_t x) {
+    auto step = [](uint32_t v, auto ctrl, auto row_mask) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
+        return o > v ? o : v;
+    };
+    x = step(x, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+    x = step(x, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
 __device__ inline unsigned long long wave_max_u64(unsigned long long v) {
+#if WAVE_MAX_DPP
+    // lexicographic: the maximum of the high words, then the maximum of the low words among the lanes that hold it (a lane with v = 0 never wins against a candidate)
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t H = wave_max_u32_dpp(hi);
+    const uint32_t L = wave_max_u32_dpp(hi == H ? lo : 0u);
+    return ((unsigned long long)H << 32) | (unsigned long long)L;
+#else
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long x = __shfl_xor(v, o, 64);
         v = x > v ? x : v;
     }
     return v;
+#endif
 }
 __device__ inline uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
