@@ -42,6 +42,110 @@ except Exception:
     PMC_FILE = {}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# The result line.  The driver parses ONE line of at most a few KB: numbers and short identifiers only.  What every field means is in
+# profiles/bench_line_notes.md (keyed by field name); the verbose record of the same run (every probe figure, every leg, the prose) goes to the sidecar file
+# gpurun_out/bench_full.json (OMOK_BENCH_FULL overrides the path).  (Round 5's final line had grown to 24 KB and fell out of the driver's record.)
+# ------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 8000
+
+
+def _r(x, sig=5):
+    """numbers of the line carry `sig` significant digits"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    try:
+        return _r(float(x), sig)
+    except Exception:
+        return str(x)[:80]
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and d.get(k) is not None}
+
+
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "executed_flops", "frac_executed", "executed_over_algorithmic", "avg_launch_ms", "rows_per_launch",
+             "needed_bytes_per_row", "traffic_over_needed", "mfma_busy_pmc", "valu_busy_pmc", "share_of_kernel_time", "frac_at_sustained_clock",
+             "algorithmic_bytes_per_sim", "hbm_bytes_per_sim_pmc", "on_chip_fraction")
+
+
+def compact_line(full):
+    """the driver's line from the verbose record: required keys first, then the measured extras as numbers"""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    line["vs_baseline"] = full.get("vs_baseline")
+    line.update(_pick(full, ("dtype", "data", "config", "mcts_sims_per_s", "nn_evals_per_s", "plies_per_s", "mean_plies_per_game", "games_finished")))
+    for key in ("roofline", "roofline_fc0", "roofline_net", "roofline_tree"):
+        if isinstance(full.get(key), dict):
+            line[key] = _pick(full[key], ROOF_KEYS)
+    if isinstance(full.get("roofline"), dict) and "traffic" not in line["roofline"]:
+        line["roofline"]["traffic"] = None
+    cb = full.get("cpu_baseline")
+    line["cpu_baseline"] = None  # (the contract's key: null on multi-GPU runs and when the leg was switched off; the early line drops nulls)
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "host_threads", "cpu_model", "sims_per_s", "nn_evals_per_s", "net_tflops",
+                                          "tree_threads", "net_forward", "one_thread_value", "c1_games_per_s", "error", "skipped"))
+    fmt = full.get("fc0_format")
+    if isinstance(fmt, dict):
+        line["fc0_format"] = {"in_use": fmt.get("in_use_short"), "probe_verdict": (fmt.get("probe_verdict") or {}).get("code")}
+    pr = full.get("precision")
+    if isinstance(pr, dict):
+        cp = _pick(pr, ("within_contract", "error"))
+        vs = pr.get("vs_oracle")
+        if isinstance(vs, dict):
+            num = ("fc0_format", "rows_per_round", "difference_path_rounds", "rows_compared", "rows", "max_dp", "max_dv", "max_dlogit", "max_dvpre", "logit_abs_max")
+            cv = _pick(vs, ("error",))
+            if isinstance(vs.get("difference_path"), dict):
+                cv["difference_path"] = _pick(vs["difference_path"], num)
+            if isinstance(vs.get("plain_rows"), dict):
+                cv["plain_rows"] = _pick(vs["plain_rows"].get("headline_mode") or {}, num)
+            if "north_star_logits_1e-3" in vs:
+                cv["north_star_logits_1e-3"] = vs["north_star_logits_1e-3"]
+            cp["vs_oracle"] = cv
+        for key in ("search_rounds", "search_rounds_timed_size"):
+            if isinstance(pr.get(key), dict):
+                cp[key] = _pick(pr[key], ("rows", "max_dp", "max_dv", "max_dlogit", "max_dvpre", "within_contract", "children2_launches"))
+        line["precision"] = cp
+    line.update(_pick(full, ("value_f16_format", "value_fp6_format")))
+    for key, keys in (("window_first_plies", ("plies", "ms_per_full_round", "games_per_s_at_mean_length", "mcts_sims_per_s", "error")),
+                      ("slots_mode", ("games", "games_per_s", "error")), ("replay_postprocess", ("records", "ms", "achieved", "frac")),
+                      ("train_phase", ("steps", "batch", "steps_per_s")), ("replay_gather", ("records_per_episode", "bytes_per_episode", "seconds_per_episode", "last_counts", "last_ids")),
+                      ("clocks", ("samples", "sclk_mhz_busy_median", "power_w_busy_median", "sclk_mhz_median", "sclk_mhz_max")),
+                      ("children_kernel_launches", ("k_sib_children2", "k_sib_children")), ("rank0_kernel_ms", ("ms_round", "ms_tree", "ms_trunk", "ms_fc0", "ms_tail", "ms_ply"))):
+        if isinstance(full.get(key), dict):
+            line[key] = _pick(full[key], keys)
+    line.update(_pick(full, ("rank0_timed_region_ms", "seconds_since_process_start")))
+    line["notes"] = "profiles/bench_line_notes.md"
+    line = _r(line)
+    if len(json.dumps(line)) > LINE_LIMIT:  # never let an extra cost the record: drop the optional objects, last first
+        for key in ("rank0_kernel_ms", "children_kernel_launches", "train_phase", "replay_postprocess", "slots_mode", "window_first_plies", "roofline_tree", "roofline_net", "roofline_fc0", "clocks"):
+            line.pop(key, None)
+            if len(json.dumps(line)) <= LINE_LIMIT:
+                break
+    return line
+
+
+def emit(full, final):
+    """print the driver's line (flush) and leave the verbose record beside it"""
+    line = compact_line(full)
+    if not final:  # the early safety line: a measured line exists from here on whatever happens to the extra legs; it carries no null placeholders
+        line = {k: v for k, v in line.items() if v is not None or k == "vs_baseline"}
+    path = os.environ.get("OMOK_BENCH_FULL") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, default=lambda o: float(o) if hasattr(o, "__float__") else str(o))
+    except OSError:
+        pass
+    print(json.dumps(line), flush=True)
+
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,7 +268,7 @@ def self_launch(args):
         msg = f"--gpus {args.gpus}: {args.gpus} GPUs needed, {have} visible on this host; nothing was run"
         print(json.dumps({"error": msg, "n_gpus": args.gpus, "gpus_visible": have, "value": None}), flush=True)
         print(msg, file=sys.stderr)
-        return 0
+        return 3  # (nothing was measured: not a success)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -196,6 +300,53 @@ def cpu_baseline(args, mean_plies, budget_s):
 
     onet_c = O.Net(n, tensors)
 
+    class MMForward:
+        """The same fp32 forward as matrix products (network.rs:51-247): every 1x1 convolution is `rows*HW x Cin @ Cin x Cout` (torch.addmm -> MKL sgemm), the depthwise
+        3x3 nine shifted multiply-adds on the NHWC grid, fc0 one [rows, 128 HW] x [128 HW, 512] product -- the shape a CPU BLAS is good at (VERDICT round 5, item 8:
+        the conv2d graph of train.py reached 2.9 k rows/s whatever the thread count).  Rows in chunks of `cs` (chosen by the calibration below: small chunks keep the
+        115 KB-per-row activations in cache, large ones give MKL more rows per product)."""
+        cs = 256
+
+        def __init__(self):
+            sh = oa.weights.tensor_shapes(n)
+            t = [torch.as_tensor(np.asarray(x, dtype=np.float32).reshape(s_)) for x, s_ in zip(tensors, sh)]
+            self.w_in, self.b_in = t[0].reshape(3, 128).contiguous(), t[1]
+            self.blocks = []
+            for i in range(3):
+                w0, b0, dw, pw, b1, w2, b2 = t[2 + 7 * i: 9 + 7 * i]
+                self.blocks.append((w0.reshape(128, 32).contiguous(), b0, dw.reshape(9, 32).contiguous(), pw.reshape(32, 32).contiguous(), b1, w2.reshape(32, 128).contiguous(), b2))
+            self.fc = t[23:31]
+
+        def chunk(self, x):
+            import torch.nn.functional as F
+            b = x.shape[0]
+            a = F.leaky_relu_(torch.addmm(self.b_in, x.reshape(b * hw, 3), self.w_in), 0.2)
+            for w0, b0, dw, pw, b1, w2, b2 in self.blocks:
+                h = F.leaky_relu_(torch.addmm(b0, a, w0), 0.2)
+                hp = F.pad(h.view(b, n, n, 32), (0, 0, 1, 1, 1, 1))
+                d = hp[:, 0:n, 0:n, :] * dw[0]
+                for tap in range(1, 9):  # taps in (dy, dx) order like the reference's depthwise (network-utils/src/lib.rs:172-262)
+                    d.addcmul_(hp[:, tap // 3: tap // 3 + n, tap % 3: tap % 3 + n, :], dw[tap])
+                g = F.leaky_relu_(torch.addmm(b1, d.reshape(b * hw, 32), pw), 0.2)
+                a = F.leaky_relu_(torch.addmm(b2, g, w2).add_(a), 0.2)  # add before the activation (network.rs:108-111)
+            w_fc0, b_fc0, w_fc1, b_fc1, w_v, b_v, w_p, b_p = self.fc
+            h0 = F.leaky_relu_(torch.addmm(b_fc0, a.view(b, hw * 128), w_fc0), 0.2)
+            h1 = F.leaky_relu_(torch.addmm(b_fc1, h0, w_fc1), 0.2)
+            return torch.softmax(torch.addmm(b_p, h1, w_p), dim=1), torch.tanh(torch.addmm(b_v, h1, w_v))
+
+        def __call__(self, x, threads):
+            xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).reshape(len(x), hw * 3)
+            ps, vs = [], []
+            with torch.no_grad():
+                for i in range(0, len(xt), self.cs):
+                    p, v = self.chunk(xt[i:i + self.cs])
+                    ps.append(p)
+                    vs.append(v)
+            return torch.cat(ps).numpy(), torch.cat(vs).numpy().reshape(-1)
+
+    mm_net = MMForward()
+
+
     def forward_torch(x, threads):
         with torch.no_grad():
             p, v = net(torch.from_numpy(np.ascontiguousarray(x)).reshape(-1, n, n, 3))
@@ -204,11 +355,11 @@ def cpu_baseline(args, mean_plies, budget_s):
     def forward_c(x, threads):  # the oracle's own fp32 forward (oracle/net.c: plain loops, OpenMP over blocks of 8 rows)
         return onet_c.forward(np.ascontiguousarray(x, dtype=np.float32).reshape(len(x), -1), threads=threads)
 
-    FORWARDS = {"torch-CPU (BLAS / oneDNN)": forward_torch, "oracle/net.c (OpenMP over rows)": forward_c}
+    FORWARDS = {"torch-CPU mm (MKL sgemm)": mm_net, "torch-CPU (conv2d graph)": forward_torch, "oracle/net.c (OpenMP over rows)": forward_c}
 
     seen_rows = []  # request rows of the legs' real search rounds (for the oracle-vs-GPU check of the net outputs below)
 
-    def leg(games, sims, threads, seconds, max_plies, engine="torch-CPU (BLAS / oneDNN)"):
+    def leg(games, sims, threads, seconds, max_plies, engine="torch-CPU mm (MKL sgemm)"):
         torch.set_num_threads(threads)
         fwd = FORWARDS[engine]
 
@@ -216,6 +367,7 @@ def cpu_baseline(args, mean_plies, budget_s):
             return fwd(x, threads)
         root_p, _ = forward(O.Environment(n).encode_nn_input(0)[None])
         sp = O.SelfPlay(n, games, cap_nodes=min(16384, 4 * sims + 1024), cap_tables=max(256, sims + 256), seed=args.seed)
+        sp.set_threads(min(threads, games))  # the tree loops over the games under OpenMP (the reference: rayon par_iter, parallel_mcts_executor.rs:200-205)
         sp.reset(root_p[0])
         rounds = (sims + k - 1) // k
         t0 = time.perf_counter()
@@ -250,26 +402,54 @@ def cpu_baseline(args, mean_plies, budget_s):
             plies += 1
         dt = time.perf_counter() - t0
         return {"games": games, "sims_per_move": rounds * k, "threads": threads, "net_forward": engine, "seconds": dt, "plies_completed": plies,
-                "sims": n_sims, "sims_per_s": n_sims / dt, "nn_evals_per_s": n_evals / dt, "net_seconds": t_net,
+                "sims": n_sims, "sims_per_s": n_sims / dt, "nn_evals": n_evals, "nn_evals_per_s": n_evals / dt, "net_seconds": t_net,
                 "tree_seconds": dt - t_net, "finished": sp.alive_count == 0}
 
-    # C2' (VERDICT round 4, weak 9): 256 games -> 4096-row forwards per round, the batch shape at which a BLAS-backed CPU forward is efficient, on at least
-    # 64 of the host's threads (the fastest of {64, 128, all}; a host with fewer threads uses all of them), at least two plies.  (Round 4 timed 16 games on 16 threads:
-    # 256-row forwards are latency-bound on a 256-thread host, which made the CPU path look ~10x slower than it is.)  The tree part is the oracle's C loop over the
-    # games, single-threaded (the reference's is a rayon pool: on this split the net is > 95 % of the time either way).  The one-thread legs keep 16 games.
-    # Budget: 10 % thread calibration, 10 % per C1 leg, 50 % the C2' leg, 15 % the one-thread C2' leg.
+    # C2' (SURVEY 8d): 256 games -> 4096-row forwards per round, the batch shape at which a BLAS-backed CPU forward is efficient, on at least 64 of the host's threads
+    # (the fastest of {64, 128, all}; a host with fewer threads uses all of them).  Three forwards compete at every thread count: the matrix-product formulation on MKL
+    # (VERDICT round 5, item 8), train.py's conv2d graph (2.9 k rows/s on the GPU box's 2 x 64-core host whatever the thread count: it does not use the machine) and the
+    # oracle's own row-parallel C loops.  The tree part is the oracle's C code with the loops over the games under OpenMP on the same threads (the reference: a rayon pool).
+    # The one-thread legs keep 16 games.  Budget: 15 % calibration, 8 % per C1 leg, 50 % the C2' leg, 12 % the one-thread C2' leg.
     cand = sorted({t for t in (64, 128, cores) if t <= cores}) or [cores]
     g2, g1t = 256, 16
-    # two forwards compete at every thread count: torch-CPU and the oracle's own C forward (rows are independent: OpenMP over blocks of rows); on the GPU box's
-    # 2 x 64-core host torch-CPU reached 2.9 k rows/s at 4096-row batches whatever the thread count, so the row-parallel C loop is the fairer CPU path there
-    calib = {(e, t): leg(g2, args.sims, t, max(0.6, 0.12 * budget_s / (2 * len(cand))), 1, e)["sims_per_s"] for e in FORWARDS for t in cand}
+    flop_eval = 2.0 * (3 * 128 * hw + 3 * hw * (128 * 32 + 9 * 32 + 32 * 32 + 32 * 128) + 128 * hw * 512 + 512 * 512 + 512 + 512 * hw)
+    # does MKL use the machine?  fc0's product alone ([1024, 128 HW] x [128 HW, 512]) at 1 thread and at every candidate count, ~1 s in all: TFLOP/s must scale
+    mm_cal = {}
+    xa, wb = torch.randn(1024, 128 * hw), torch.randn(128 * hw, 512)
+    for t in [1] + cand:
+        torch.set_num_threads(t)
+        t_all, best_call, calls = time.perf_counter(), 1e9, 0
+        while calls < 3 or time.perf_counter() - t_all < (1.2 if t > 1 else 0.4):  # (the best single call: a new thread team's first ~0.5 s of products run at a fraction of its rate)
+            t1 = time.perf_counter()
+            torch.mm(xa, wb)
+            best_call = min(best_call, time.perf_counter() - t1)
+            calls += 1
+        mm_cal[str(t)] = 2.0 * 1024 * 128 * hw * 512 / best_call / 1e12
+    del xa, wb
+    # chunk size of the matrix-product forward: one 4096-row forward per candidate at the largest thread count
+    xv = (np.random.RandomState(1).rand(4096, 3 * hw) < 0.2).astype(np.float32)
+    mm_chunks = {}
+    for cs in (256, 1024, 4096):
+        mm_net.cs = cs
+        mm_net(xv[:max(cs, 1024)], cand[-1])
+        t1 = time.perf_counter()
+        mm_net(xv, cand[-1])
+        mm_chunks[cs] = 4096 / (time.perf_counter() - t1)
+    mm_net.cs = max(mm_chunks, key=mm_chunks.get)
+    # the matrix-product forward against the oracle's own (the checker of the -m gpu tests) on 64 deterministic rows
+    xv = (np.random.RandomState(0).rand(64, 3 * hw) < 0.2).astype(np.float32)
+    pm, vm = mm_net(xv, cand[-1])
+    pc, vc = forward_c(xv, min(8, cores))
+    mm_check = {"rows": 64, "max_dp": float(np.abs(pm - pc).max()), "max_dv": float(np.abs(vm - vc).max())}
+    calib_legs = {(e, t): leg(g2, args.sims, t, max(0.6, 0.15 * budget_s / (len(FORWARDS) * len(cand))), 1, e) for e in FORWARDS for t in cand}
+    calib = {kk: v["sims_per_s"] for kk, v in calib_legs.items()}
     best_e, best_t = max(calib, key=calib.get)
     share = 0.50 * budget_s
     legs = {
         "c1_best_threads": leg(1, 100, best_t, 0.08 * budget_s, 10 ** 6, best_e),
-        "c1_one_thread": leg(1, 100, 1, 0.08 * budget_s, 10 ** 6),
+        "c1_one_thread": leg(1, 100, 1, 0.08 * budget_s, 10 ** 6, best_e),
         "c2p_best_threads": leg(g2, args.sims, best_t, share, 4, best_e),
-        "c2p_one_thread": leg(g1t, args.sims, 1, 0.12 * budget_s, 2),
+        "c2p_one_thread": leg(g1t, args.sims, 1, 0.12 * budget_s, 2, best_e),
     }
     torch.set_num_threads(cores)
     best = legs["c2p_best_threads"]
@@ -298,11 +478,15 @@ def cpu_baseline(args, mean_plies, budget_s):
                                     "threads": best_t, "what": "oracle/net.c fp32 forward (plain loops, OpenMP over blocks of 8 rows) on request rows of the legs' search rounds"}
                                    if net_check else None),
             "value": best["sims_per_s"] / (rounds_up * mean_plies), "unit": "games/s", "cores": best_t, "host_threads": cores, "kind": "port",
-            "net_forward": best_e,
+            "net_forward": best_e, "tree_threads": min(best_t, g2),
+            "net_tflops": best["nn_evals"] * flop_eval / max(best["net_seconds"], 1e-9) / 1e12,  # the forward alone: evaluations x 2*MAC flops / time inside the forward
+            "net_share_of_time": best["net_seconds"] / max(best["seconds"], 1e-9), "nn_evals_per_s": best["nn_evals_per_s"],
+            "mm_calibration_tflops_by_threads": mm_cal, "mm_forward_rows_per_s_by_chunk": mm_chunks, "mm_forward_vs_oracle": mm_check,
             "thread_calibration_sims_per_s": {f"{e} @ {t} threads": v for (e, t), v in calib.items()},
-            "sample": f"C2' = {g2} games x {rounds_up} sims/move ({g2 * k}-row forwards) x up to 4 plies (bounded to {share:.0f} s; {best['plies_completed']} plies completed) on {best_t} of {cores} "
-                      f"threads (fastest of {cand} x two forwards): oracle C tree code + fp32 forward by {best_e}; {best['sims_per_s']:.0f} sims/s, converted with {mean_plies:.1f} plies/game "
-                      f"from the GPU run.  Also C1 (1 game, 100->112 sims/move, whole game or {0.10 * budget_s:.0f} s) and, on 1 thread, C1 and {g1t} games of C2': see legs",
+            "sample": f"C2': {g2} games x {rounds_up} sims x {best['plies_completed']} plies ({best['seconds']:.0f} s), {best_t} of {cores} threads",
+            "sample_long": f"C2' = {g2} games x {rounds_up} sims/move ({g2 * k}-row forwards) x up to 4 plies (bounded to {share:.0f} s; {best['plies_completed']} plies completed) on {best_t} of {cores} "
+                           f"threads (fastest of {cand} x three forwards): oracle C tree code (games under OpenMP) + fp32 forward by {best_e}; {best['sims_per_s']:.0f} sims/s, converted with {mean_plies:.1f} plies/game "
+                           f"from the GPU run.  Also C1 (1 game, 100->112 sims/move, whole game or {0.08 * budget_s:.0f} s) and, on 1 thread, C1 and {g1t} games of C2': see legs",
             "cpu_model": model, "sims_per_s": best["sims_per_s"],
             "one_thread_value": legs["c2p_one_thread"]["sims_per_s"] / (rounds_up * mean_plies),
             "c1_games_per_s": {kk: (1.0 / v["seconds"] if v["finished"] else v["sims_per_s"] / (112 * mean_plies)) for kk, v in legs.items() if kk.startswith("c1")},
@@ -472,6 +656,43 @@ def main():
     dominant = max(("k_trunk", "k_fc0_mx"), key=lambda kk: k_ms[kk])
     pmc = PMC_FILE.get(str(n), {})
 
+    # ---- executed matrix work: MFMA instructions counted from the kernels' structure (tools/isa_hist.py --mfma confirms the per-pass counts in the
+    #      code object) x the engine's device-side work counters (OMOK_STAT_WORK_*), beside the algorithmic credit.  Every MFMA of this library -- v_mfma_f32_32x32x16_f16
+    #      (32768 flop) and the block-scaled fp6 v_mfma_scale_f32_32x32x64_f8f6f4 (131072 flop) -- occupies a SIMD's matrix pipe for 32 cycles (MI355X_MICROARCH.md), so
+    #      frac_executed = MFMAs x 32 cycles / (time x 1024 SIMDs x 2.4 GHz): the pipe-busy fraction at the boost clock, comparable with mfma_busy_pmc.
+    tiles_row = (hw + 31) // 32                      # 32-pixel MFMA tiles of a full trunk row (k_trunk: one wave per tile)
+    M_TRUNK_TILE, M_CHILD2, M_CHILD1 = 170, 200, 340  # MFMAs: k_trunk per tile (conv_in 8 + 3 blocks x (24 + 6 + 24)); k_sib_children2 per child; k_sib_children per child (2 tiles)
+    M_MX_STEP, M_X3_HALF = 4 * 96, 4 * 96             # per 512 x 128 fc0 tile (4 waves): k_fc0_mx super-step K = 64 (64 f16 + 32 fp6 per wave); k_fc0_x3 half-step K = 32 (96 f16 per wave)
+    F_MX_STEP, F_X3_HALF = 4 * (64 * 32768 + 32 * 131072), 4 * 96 * 32768
+    M_FC1_TILE = 32 * 24 * 8                         # k_gemm_t<16>: 32 k-steps x 24 MFMAs per wave x 8 waves per 128-row tile
+    heads_mt = 8 if n == 15 else 4                   # k_gemm_t<MT>: output features / 32 (226 -> 256 at N = 15, 82 -> 128 at N = 9)
+    M_HEADS_TILE = 32 * (heads_mt * 4 * 3 // 8) * 8  # 32 k-steps x (MT x 4 accumulator tiles x 3 terms / 8 waves) x 8 waves
+    wk = {kk: float(st.get(kk, 0.0) or 0.0) for kk in ("work_diff_runs", "work_diff_singles", "work_diff_children", "work_copy_runs", "work_copy_singles", "work_copy_children",
+                                                       "work_diff_full_runs", "work_win_pixels", "work_win_tiles", "work_full_tiles")}
+    have_work = "work_diff_children" in st
+    fcode_all = int(st.get("fc0_format", 0))
+    plain_rows = max(0.0, rows - wk["work_diff_children"] - wk["work_diff_singles"] - wk["work_copy_children"] - wk["work_copy_singles"])
+    full_trunk_rows = wk["work_diff_full_runs"] + wk["work_diff_singles"] + wk["work_copy_runs"] + wk["work_copy_singles"] + plain_rows
+    mfma_trunk = M_CHILD2 * wk["work_diff_children"] + M_CHILD1 * wk["work_copy_children"] + M_TRUNK_TILE * tiles_row * full_trunk_rows
+    dense_tiles = (rows - wk["work_diff_children"] - wk["work_diff_singles"]) / 128.0   # rows of the copy path and of plain forwards go through the dense fc0
+    if fcode_all == 0:    # fp6 rows: k_fc0_mx everywhere
+        m_full, f_full = 2 * hw * M_MX_STEP, 2 * hw * F_MX_STEP
+    else:                 # f16 full rows (f16 and mixed formats): k_fc0_x3
+        m_full, f_full = 4 * hw * M_X3_HALF, 4 * hw * F_X3_HALF
+    m_win, f_win = (2 * M_X3_HALF * 2, 2 * F_X3_HALF * 2) if fcode_all == 1 else (2 * M_MX_STEP, 2 * F_MX_STEP)  # per window pixel and tile (two super-steps; f16 format: four half-steps)
+    mfma_fc0 = wk["work_win_pixels"] * m_win + (wk["work_full_tiles"] + dense_tiles) * m_full
+    flop_exec_fc0 = wk["work_win_pixels"] * f_win + (wk["work_full_tiles"] + dense_tiles) * f_full
+    mfma_tail = rows / 128.0 * (M_FC1_TILE + M_HEADS_TILE)
+    executed = {"k_trunk": (mfma_trunk, mfma_trunk * 32768.0), "k_fc0_mx": (mfma_fc0, flop_exec_fc0), "tail": (mfma_tail, mfma_tail * 32768.0)} if have_work else {}
+    SIMD_CYCLES_PER_S = 256 * 4 * BOOST_SCLK_MHZ * 1e6
+
+    def executed_fields(kernel, sec, flop_row):
+        if kernel not in executed or sec <= 0:
+            return {}
+        m, f = executed[kernel]
+        return {"executed_flops": f / launches, "executed_mfma": m / launches, "frac_executed": 32.0 * m / (sec * SIMD_CYCLES_PER_S),
+                "executed_over_algorithmic": f / max(rows * flop_row, 1.0)}
+
     def mfma_roofline(kernel, flop_row, note):
         sec = k_ms[kernel] * 1e-3
         ach = rows * flop_row / sec / 1e12 if sec > 0 else 0.0
@@ -514,7 +735,7 @@ def main():
         # base's operand row once; fc0: that difference row read + per run the base row's share.  traffic / needed = the re-reads and layout overhead the counters see.
         needed_row = {"k_trunk": drow + ppx * hw / run, "k_fc0_mx": drow + miss * ppx * hw / run}[kernel] if n == 15 else ppx * hw
         return {"bound": bound, "kernel": kernel, "kernel_members": members, "achieved": sides[bound]["achieved"], "peak": sides[bound]["peak"], "unit": sides[bound]["unit"],
-                "frac": sides[bound]["frac"],
+                "frac": sides[bound]["frac"], **executed_fields(kernel, sec, flop_row),
                 "algorithmic_credit": "achieved = request rows x the 2*MAC flops of a FULL evaluation of this stage (SURVEY 8d) / HIP-event time of the group: at N = 15 sibling requests "
                                       "are evaluated as one base position + per-child window differences, so ~0.2-0.3x of those flops are executed (as 3 split-operand MFMAs per product); "
                                       "mfma_busy_pmc is the matrix pipes' measured busy fraction",
@@ -554,6 +775,7 @@ def main():
                 "child's difference row, i.e. ~0.28x (N = 15) / ~0.65x (N = 9) of the algorithmic work is EXECUTED: `achieved` counts useful work and can exceed "
                 "what a dense kernel could reach")
     fc0_fmt = {0: "block-scaled fp6 (e2m3)", 1: "f16", 2: "mixed: f16 on full operand rows, block-scaled fp6 on the difference rows of sibling rounds"}.get(int(st.get("fc0_format", 0)), "f32")
+    fc0_short = {0: "fp6", 1: "f16", 2: "mixed f16/fp6"}.get(int(st.get("fc0_format", 0)), "f32")
     net_s = (st["ms_trunk"] + st["ms_fc0"] + st["ms_tail"]) * 1e-3
     tree_s = st["ms_tree"] * 1e-3
     tree_traffic = pmc.get("tree_hbm_bytes_per_sim")
@@ -561,9 +783,10 @@ def main():
         "metric": "self-play games/sec (15x15, 800 sims/move); MCTS nodes/sec",
         "value": games_per_s, "unit": "games/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": (f"f16 (split hi+lo MFMA operands: f16 main term + two correction terms, fp32 accumulate; fc0's correction terms in {fc0_fmt}, "
-                  + ("chosen by omok_net_commit's probe)" if args.net_mode == "f16x3" else "forced by --net-mode)")) if args.net_mode != "f32" else "f32",
-        "fc0_format": {"in_use": fc0_fmt, "probe_rows": st.get("probe_rows"), "probe_limit": st.get("probe_limit"),
+        "dtype": f"f16x3 split MFMA, fp32 acc; fc0 corrections {fc0_short}" if args.net_mode != "f32" else "f32",
+        "dtype_long": (f"f16 (split hi+lo MFMA operands: f16 main term + two correction terms, fp32 accumulate; fc0's correction terms in {fc0_fmt}, "
+                       + ("chosen by omok_net_commit's probe)" if args.net_mode == "f16x3" else "forced by --net-mode)")) if args.net_mode != "f32" else "f32",
+        "fc0_format": {"in_use": fc0_fmt, "in_use_short": fc0_short, "probe_rows": st.get("probe_rows"), "probe_limit": st.get("probe_limit"),
                        "fp6_max_dp_dv": [st.get("probe_dp_fp6"), st.get("probe_dv_fp6")], "f16_max_dp_dv": [st.get("probe_dp_f16"), st.get("probe_dv_f16")],
                        "probe_logit_abs_max": st.get("probe_logit_max"),
                        "plain_rows_max_dlogit": {"fp6": st.get("probe_dlogit_fp6"), "f16": st.get("probe_dlogit_f16")}, "probe_logit_limit": st.get("probe_logit_limit"),
@@ -582,12 +805,12 @@ def main():
         "children_kernel_launches": {"k_sib_children2": st.get("children2_launches"), "k_sib_children": st.get("children1_launches"),
                                      "note": "sibling rounds of the timed region by the kernel that evaluated the runs' children: k_sib_children2 on the difference path "
                                              "(rounds of >= 2048 rows at N = 15 in the mixed operand format, >= 3072 in the fp6 / f16 formats, >= 1024 at N = 9), k_sib_children on the copy path (smaller rounds)"},
-        "data": "synthetic (games from the empty board, random-init net seed 0, one RNG stream per step)",
+        "data": "synthetic (empty boards, random-init net seed 0)",
         "config": {"workload": f"{games} concurrent {n}x{n} games per GPU, {args.sims} sims/move, K={k}, two trees per game"
                                + ("" if complete else f", first {args.max_plies} plies only (games/s extrapolated)"),
                    "games_per_gpu": games, "board": n, "sims_per_move": args.sims, "batch_k": k,
                    "warmup_step": f"episode cut after {args.warmup_plies} plies" if args.warmup_plies else "whole episode",
-                   "parallelism": f"games sharded x{world}, no hot-path collective" + (", RCCL all-gather-v of replay tuples per episode" if args.gather else "")},
+                   "parallelism": f"games sharded x{world}, no hot-path collective" + (f", {'RCCL' if backend == 'nccl' else backend} all-gather-v of replay tuples per episode" if args.gather else "")},
         "mcts_sims_per_s": sims / dt, "nn_evals_per_s": evals / dt, "plies_per_s": ply_games / dt,
         "mean_plies_per_game": mean_plies, "games_finished": finished,
         "roofline": mfma_roofline(dominant, flop_trunk if dominant == "k_trunk" else flop_fc0, note_trunk if dominant == "k_trunk" else note_fc0),
@@ -595,6 +818,8 @@ def main():
         "roofline_fc0": mfma_roofline("k_fc0_mx", flop_fc0, note_fc0),
         "roofline_net": {"bound": "mfma", "achieved": rows * flop_eval / net_s / 1e12 if net_s > 0 else 0.0, "peak": F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (rows * flop_eval / net_s / 1e12 / F16_DENSE_PEAK_TFLOPS) if net_s > 0 else 0.0,
+                         **({"executed_flops": sum(v[1] for v in executed.values()) / launches, "executed_mfma": sum(v[0] for v in executed.values()) / launches,
+                             "frac_executed": 32.0 * sum(v[0] for v in executed.values()) / (net_s * SIMD_CYCLES_PER_S)} if executed and net_s > 0 else {}),
                          "note": "whole forward per SURVEY 8d: evals x 43.25 MFLOP / (trunk + fc0 + tail time)"},
         "roofline_tree": {"bound": "hbm", "kernel": "k_round+k_scan+k_scatter", "achieved": st["tree_bytes"] / tree_s / 1e9 if tree_s > 0 else 0.0,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (st["tree_bytes"] / tree_s / 1e9 / HBM_PEAK_GBS) if tree_s > 0 else 0.0,
@@ -621,14 +846,17 @@ def main():
         # `peak` is quoted at the boost clock (2400 MHz); the well-filled rounds run at the package power limit, below it: the same fraction against the peak at the clock they got
         scale = BOOST_SCLK_MHZ / clocks["sclk_mhz_busy_median"]
         for key in ("roofline", "roofline_trunk", "roofline_fc0", "roofline_net"):
-            out[key]["frac_at_sustained_clock"] = out[key]["frac"] * scale
+            if out[key]["frac"] * scale < 1.0:  # (an algorithmic-credit figure above 1 is not a fraction of anything: fc0's executes ~0.25x of its credit)
+                out[key]["frac_at_sustained_clock"] = out[key]["frac"] * scale
+            if out[key].get("frac_executed") is not None:
+                out[key]["frac_executed_at_sustained_clock"] = out[key]["frac_executed"] * scale
         clocks["boost_sclk_mhz"] = BOOST_SCLK_MHZ
     if args.gather:
         out["replay_gather"] = {"records_per_episode": gathered["records"] / max(args.steps, 1), "bytes_per_episode": gathered["bytes"] / max(args.steps, 1),
                                 "seconds_per_episode": gathered["seconds"] / max(args.steps, 1), "inside_timed_region": True,
-                                "method": "8 x int64 counts all-gather, then exact-size grouped send/recv (all-gather-v)",
+                                "method": "8 x int64 counts all-gather, then exact-size grouped send/recv (all-gather-v)", "backend": "RCCL" if backend == "nccl" else backend,
                                 "last_counts": gathered.get("last_counts"), "last_ids": gathered.get("last_ids")}
-    print(json.dumps(out), flush=True)  # the measured line exists from here on, whatever happens to the extra legs
+    emit(out, final=False)  # the measured line exists from here on, whatever happens to the extra legs
 
     # ---- extra legs, outside the timed region, only while the wall-clock budget has room ----------------------------
     extras = False
@@ -810,9 +1038,8 @@ def main():
         else:
             out["cpu_baseline"] = {"skipped": f"no room in the {args.budget_seconds:.0f} s budget ({elapsed():.0f} s used)"}
         extras = True
-    if extras:
-        out["seconds_since_process_start"] = elapsed()
-        print(json.dumps(out), flush=True)
+    out["seconds_since_process_start"] = elapsed()
+    emit(out, final=True)  # the LAST line is the complete one (also when no extra leg ran: it then differs from the first only by the keys that are null)
 
 
 if __name__ == "__main__":

@@ -88,7 +88,17 @@ pub const OMOK_STAT_PROBE_ROUND_MIXED: i32 = 32;
 pub const OMOK_STAT_PROBE_ROUND_F16: i32 = 35;
 pub const OMOK_STAT_PROBE_LOGIT_LIMIT: i32 = 38;
 pub const OMOK_STAT_PROBE_OUTSIDE: i32 = 39;
-pub const OMOK_STAT_COUNT: i32 = 40;
+pub const OMOK_STAT_WORK_DIFF_RUNS: i32 = 40;
+pub const OMOK_STAT_WORK_DIFF_SINGLES: i32 = 41;
+pub const OMOK_STAT_WORK_DIFF_CHILDREN: i32 = 42;
+pub const OMOK_STAT_WORK_COPY_RUNS: i32 = 43;
+pub const OMOK_STAT_WORK_COPY_SINGLES: i32 = 44;
+pub const OMOK_STAT_WORK_COPY_CHILDREN: i32 = 45;
+pub const OMOK_STAT_WORK_DIFF_FULL_RUNS: i32 = 46;
+pub const OMOK_STAT_WORK_WIN_PIXELS: i32 = 47;
+pub const OMOK_STAT_WORK_WIN_TILES: i32 = 48;
+pub const OMOK_STAT_WORK_FULL_TILES: i32 = 49;
+pub const OMOK_STAT_COUNT: i32 = 50;
 
 /// The raw C ABI: every entry point of include/omok_mi355x.h (generated; do not edit by hand).
 pub mod ffi {

@@ -303,7 +303,18 @@ int omok_debug_set_window_rects(omok_engine* e, int32_t enabled);
                                       inside north_star's 1e-3 -- committed, one line on stderr; 2 = it is outside 1e-3: the engine evaluates this net with the plain fp32
                                       kernels (OMOK_STAT_FC0_FORMAT = -1, the arithmetic of agent_model.rs:116-134; slow) until the next omok_net_commit.  A forced format
                                       (OMOK_NET_F16X3_FP6 / _F16 / _MIXED) is never probed: 0 */
-#define OMOK_STAT_COUNT 40
+/* [40..49] executed work of the search rounds on the sibling paths since omok_reset_stats (bench.py's executed_flops): */
+#define OMOK_STAT_WORK_DIFF_RUNS 40    /* difference path: runs of sibling requests ... */
+#define OMOK_STAT_WORK_DIFF_SINGLES 41 /* ... request rows outside runs (evaluated in full) ... */
+#define OMOK_STAT_WORK_DIFF_CHILDREN 42 /* ... request rows inside runs (k_sib_children2: a 5x5 / 7x7 window each) */
+#define OMOK_STAT_WORK_COPY_RUNS 43    /* the same three on the copy path (k_trunk<BASE> per run, k_sib_children per row) */
+#define OMOK_STAT_WORK_COPY_SINGLES 44
+#define OMOK_STAT_WORK_COPY_CHILDREN 45
+#define OMOK_STAT_WORK_DIFF_FULL_RUNS 46 /* runs of the difference path whose base was evaluated in full (base-cache misses + uncacheable runs) */
+#define OMOK_STAT_WORK_WIN_PIXELS 47   /* window pixels walked by the fc0 window tiles (sum over tiles of their rectangles; K-split tiles: 49) */
+#define OMOK_STAT_WORK_WIN_TILES 48    /* fc0 window tiles (128 slots each) */
+#define OMOK_STAT_WORK_FULL_TILES 49   /* 128-row tiles of the difference path's full-row fc0 */
+#define OMOK_STAT_COUNT 50
 int omok_get_stats(omok_engine* e, double* stats /* [OMOK_STAT_COUNT] */);
 int omok_reset_stats(omok_engine* e);
 /* Per-category HIP-event timing of the kernels on the engine's stream (off by default).  enabled = 1: every launch; enabled = N > 1:

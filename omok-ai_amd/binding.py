@@ -19,7 +19,9 @@ STAT_NAMES = ["sims", "evals", "ply_games", "finished", "ms_tree", "ms_trunk", "
               "fc0_format", "probe_rows", "probe_dp_fp6", "probe_dv_fp6", "probe_dp_f16", "probe_dv_f16", "probe_limit", "probe_logit_max",
               "children2_launches", "children1_launches", "probe_dlogit_fp6", "probe_dlogit_f16", "probe_round_rows",
               "probe_round_dp_fp6", "probe_round_dv_fp6", "probe_round_dlogit_fp6", "probe_round_dp_mixed", "probe_round_dv_mixed", "probe_round_dlogit_mixed",
-              "probe_round_dp_f16", "probe_round_dv_f16", "probe_round_dlogit_f16", "probe_logit_limit", "probe_outside"]
+              "probe_round_dp_f16", "probe_round_dv_f16", "probe_round_dlogit_f16", "probe_logit_limit", "probe_outside",
+              "work_diff_runs", "work_diff_singles", "work_diff_children", "work_copy_runs", "work_copy_singles", "work_copy_children", "work_diff_full_runs",
+              "work_win_pixels", "work_win_tiles", "work_full_tiles"]
 
 # every symbol include/omok_mi355x.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

@@ -1436,6 +1436,11 @@ extern "C" int omok_get_stats(omok_engine* e, double* stats) {
     for (int i = 0; i < 9; ++i) stats[OMOK_STAT_PROBE_ROUND_FP6 + i] = e->net.probe[10 + i];
     stats[OMOK_STAT_PROBE_LOGIT_LIMIT] = NET_PROBE_LOGIT_LIMIT;
     stats[OMOK_STAT_PROBE_OUTSIDE] = (double)e->net.probe_outside;
+    if (e->net.d_work) { // executed-work counters of the sibling rounds (device side: k_group, k_bin_prefix)
+        unsigned long long w[NET_WORK_COUNT];
+        if (hipMemcpy(w, e->net.d_work, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return OMOK_ERR_HIP;
+        for (int i = 0; i < 10; ++i) stats[OMOK_STAT_WORK_DIFF_RUNS + i] = (double)w[i];
+    }
     return OMOK_OK;
 }
 
@@ -1450,6 +1455,7 @@ extern "C" int omok_reset_stats(omok_engine* e) {
     e->net.children_launches[0] = e->net.children_launches[1] = 0.0;
     hipMemset(e->d_evals, 0, 16);
     hipMemset(e->S.d_bytes, 0, 16);
+    if (e->net.d_work) hipMemset(e->net.d_work, 0, sizeof(unsigned long long) * NET_WORK_COUNT);
     return OMOK_OK;
 }
 

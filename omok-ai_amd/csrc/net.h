@@ -60,6 +60,7 @@ struct Net {
     void* d_sib_rows = nullptr; // (request row, run) of the rows inside runs
     int32_t* d_gcnt = nullptr;  // [0] runs, [1] rows outside runs, [2] rows inside runs, [3] full rows (runs + singles), [4] fc0 window tiles,
                                 // [8 + b] children whose window is bin b (SIB_CNT_INTS in all)
+    unsigned long long* d_work = nullptr; // [NET_WORK_COUNT] executed-work counters summed over the rounds since omok_reset_stats (k_group, k_bin_prefix add; only omok_get_stats reads)
     float* sib_h = nullptr;     // [run][3 blocks][225][32] the base passes' depthwise inputs
     // difference path: a child's fc0 input = its run's base row + a 7x7-window difference row
     uint32_t* d_sib_slot = nullptr;  // per row inside a run: window bin << 24 | rank inside the bin
@@ -137,6 +138,10 @@ bool net_logits_cover_batch(const Net& net, int max_count);
 bool net_round_takes_sibling_path(const Net& net, int max_count);
 constexpr int NET_GCNT_P0 = 8 + 81 + 7 + 16;   // Net::d_gcnt[NET_GCNT_P0 + pixel]: children whose stone lands in net pixel `pixel` (their rows take consecutive slots inside the window bin)
 constexpr int NET_GCNT_INTS = NET_GCNT_P0 + 225; // ints of Net::d_gcnt
+// Net::d_work: [DIFF + 0..2] runs, single rows, rows in runs of the rounds on the difference path, [COPY + 0..2] the same on the copy path, [DIFF_FULL] runs of the difference
+// path whose base was evaluated in full (base-cache misses + uncacheable runs), [WIN_PIXELS] window pixels the fc0 window tiles walked (tiles x their rectangles),
+// [WIN_TILES] window tiles, [FULL_TILES] 128-row tiles of the full-row fc0
+constexpr int NET_WORK_DIFF = 0, NET_WORK_COPY = 3, NET_WORK_DIFF_FULL = 6, NET_WORK_WIN_PIXELS = 7, NET_WORK_WIN_TILES = 8, NET_WORK_FULL_TILES = 9, NET_WORK_COUNT = 16;
 // skip_softmax (split-precision modes only): stop behind the heads; the caller turns net_logits() into p / v itself (launch_softmax_scatter).
 void net_forward_requests(Net& net, const Store& S, int max_count, hipStream_t st, struct Prof* prof, int sibling_side = -1, bool skip_softmax = false);
 // Forward of explicit f32 inputs already in net.in_f32 ([count][3HW]); count is a host value

@@ -858,7 +858,8 @@ __device__ inline void sib_window(int n, int action, int& wy0, int& wx0) { // th
 constexpr int GROUP_TREES = 16;
 __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, uint2* __restrict__ groups, int32_t* __restrict__ singles,
                                                              uint4* __restrict__ sib_rows, int32_t* __restrict__ cnt, uint32_t* __restrict__ sib_slot,
-                                                             int32_t* __restrict__ tags, uint2* __restrict__ comp, int bn, int do_fill) {
+                                                             int32_t* __restrict__ tags, uint2* __restrict__ comp, int bn, int do_fill,
+                                                             unsigned long long* __restrict__ work) {
     // Difference path (sib_slot != NULL): base slots.  The FIRST run of a tree uses one of the game's SIB_WAYS slots (SIB_WAYS g + way), whose content is
     // reused while a tag names the run's parent (a leaf is its tree's expansion target for ~14 rounds); further runs of the tree in the same
     // round (rare) take a slot behind the games' and are always evaluated.  comp[] lists the (first request row, slot) pairs to evaluate.
@@ -972,6 +973,9 @@ __global__ __launch_bounds__(64 * GROUP_TREES) void k_group(Store S, int side, u
     __syncthreads();
     if (tid < LC && l_cnt[tid] > 0 && (tid < 3 || sib_slot))
         l_base[tid] = atomicAdd(&cnt[tid < 3 ? tid : (tid < 3 + NP0 ? NET_GCNT_P0 + (tid - 3) : 96 + (tid - 3 - NP0))], l_cnt[tid]);
+    // executed-work counters of the stats (Net::d_work: never read by a kernel): runs, single rows, rows in runs per path; the runs evaluated in full
+    if (tid < 3 && l_cnt[tid] > 0) atomicAdd(&work[(sib_slot ? NET_WORK_DIFF : NET_WORK_COPY) + tid], (unsigned long long)l_cnt[tid]);
+    if (tid == 3 + NP0 && sib_slot && l_cnt[tid] > 0) atomicAdd(&work[NET_WORK_DIFF_FULL], (unsigned long long)l_cnt[tid]);
     __syncthreads();
     if (start && len >= SIB_MIN) {
         groups[l_base[0] + gslot] = make_uint2(ts.req_base + (uint32_t)lane, (uint32_t)len);
@@ -1028,13 +1032,15 @@ __device__ inline void sib_p0_range(int bn, int o, int& lo, int& hi) { // net-pi
 constexpr int BP_THREADS = 256, BP_MAXT = 2048; // k_bin_prefix: threads, tiles of the whole-K launch it can order by cost (more: layout order)
 __global__ __launch_bounds__(BP_THREADS) void k_bin_prefix(int32_t* __restrict__ cnt, int32_t* __restrict__ bin_start, int32_t* __restrict__ tile_info,
                                                            uint2* __restrict__ slot_desc, const int32_t* __restrict__ singles, int n_cu, int max_fways,
-                                                           int max_wways, int part_w_rows, int facc_single_base, int part_f_rows, int nsup_full, int bn, int use_rects, int tile_cap) {
+                                                           int max_wways, int part_w_rows, int facc_single_base, int part_f_rows, int nsup_full, int bn, int use_rects, int tile_cap,
+                                                           unsigned long long* __restrict__ work) {
     __shared__ unsigned char cost[BP_MAXT];
-    __shared__ int hist[64];
+    __shared__ int hist[64], s_area;
     __shared__ int tile0[SIB_BINS + 2], binc[SIB_BINS + 1], bcnt[SIB_BINS + 1], order[SIB_BINS + 1], start_at[SIB_BINS + 2], p0c[225], p0o[225], s_split, s_ntiles;
     const int tid = threadIdx.x;
     for (int i = tid; i < 225; i += blockDim.x) p0c[i] = i < bn * bn ? cnt[NET_GCNT_P0 + i] : 0;
     if (tid < 64) hist[tid] = 0;
+    if (tid == 0) s_area = 0;
     __syncthreads();
     int c = 0, oy = 0, ox = 0, ylo = 0, yhi = -1, xlo = 0, xhi = -1;
     if (tid < SIB_BINS) {
@@ -1142,8 +1148,14 @@ __global__ __launch_bounds__(BP_THREADS) void k_bin_prefix(int32_t* __restrict__
         }
         tile_info[T] = b | ((hi - lo) << 8) | rect;
         if (T < t_split && T < BP_MAXT) { cost[T] = (unsigned char)area; atomicAdd(&hist[area], 1); }
+        if (b < SIB_BINS) atomicAdd(&s_area, area); // (window pixels this round's tiles walk: the stats' executed-work count)
     }
     __syncthreads();
+    if (tid == 0) {
+        atomicAdd(&work[NET_WORK_WIN_PIXELS], (unsigned long long)s_area);
+        atomicAdd(&work[NET_WORK_WIN_TILES], (unsigned long long)(ntiles - binc[SIB_BINS]));
+        atomicAdd(&work[NET_WORK_FULL_TILES], (unsigned long long)((cnt[3] + GT_BS - 1) / GT_BS));
+    }
     // Order of the whole-K launch (tiles below t_split).  With rectangles a tile costs 16 .. 49 window pixels, and a launch of two rounds of workgroups takes as long as
     // its slowest CU's two tiles: in layout order the CUs of the interior bins ran two full-price tiles and the 18 % of skipped work bought nothing.  The tiles are
     // sorted by cost, descending and STABLY (a bin's tiles stay together: the workgroups of one XCD stream its weight slice together) -- a counting sort, one wave
@@ -3697,6 +3709,8 @@ size_t net_alloc(Net& net) {
             ok = ok && A((void**)&net.d_groups, sizeof(uint2) * (mb / SIB_MIN + 1));
             ok = ok && A((void**)&net.d_singles, sizeof(int32_t) * mb);
             ok = ok && A((void**)&net.d_gcnt, sizeof(int32_t) * SIB_CNT_INTS);
+            ok = ok && A((void**)&net.d_work, sizeof(unsigned long long) * NET_WORK_COUNT);
+            if (ok) hipMemset(net.d_work, 0, sizeof(unsigned long long) * NET_WORK_COUNT);
             ok = ok && A((void**)&net.d_sib_rows, sizeof(uint4) * mb);
             net.base_slots = (size_t)SIB_WAYS * net.games + mb / SIB_MIN + 1; // SIB_WAYS slots per game + the other runs a round can hold
             { // V2 children (default; OMOK_SIB_V2=0 or omok_debug_set_children_kernel(1): k_sib_children on the difference path too): a base slot holds 1280 B per pixel instead of 3 h grids
@@ -3742,7 +3756,7 @@ void net_free(Net& net) {
     void** ptrs[] = {(void**)&net.p, (void**)&net.v, (void**)&net.vpre, (void**)&net.in_f32, (void**)&net.sx, (void**)&net.sh, (void**)&net.sd,
                      (void**)&net.sg, (void**)&net.s0, (void**)&net.s1, &net.wt_trunk, (void**)&net.wt_first, &net.wt_fc0,
                      &net.wt_fc0x, &net.wt_fc1, &net.wt_heads, &net.a_fc0, &net.h0, (void**)&net.part, (void**)&net.d_chunk, (void**)&net.d_groups,
-                     (void**)&net.d_singles, (void**)&net.d_gcnt, (void**)&net.sib_h, (void**)&net.d_sib_rows, (void**)&net.d_sib_slot,
+                     (void**)&net.d_singles, (void**)&net.d_gcnt, (void**)&net.d_work, (void**)&net.sib_h, (void**)&net.d_sib_rows, (void**)&net.d_sib_slot,
                      (void**)&net.d_bin_start, (void**)&net.d_tile_info, &net.d_slot_desc, &net.d_rows, (void**)&net.part_w, &net.a_base, (void**)&net.facc, (void**)&net.d_tags, &net.d_comp};
     for (void** p : ptrs) { if (*p) hipFree(*p); *p = nullptr; }
     for (int i = 0; i < NET_TENSORS; ++i) { if (net.w[i]) hipFree(net.w[i]); net.w[i] = nullptr; }
@@ -4073,7 +4087,7 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
         net.sib_cache_valid = true;
     }
     k_group<<<(S.games + GROUP_TREES - 1) / GROUP_TREES, 64 * GROUP_TREES, 0, st>>>(S, side, (uint2*)net.d_groups, net.d_singles, (uint4*)net.d_sib_rows, net.d_gcnt,
-                                                                                     delta ? net.d_sib_slot : nullptr, net.d_tags, (uint2*)net.d_comp, net.n, do_fill);
+                                                                                     delta ? net.d_sib_slot : nullptr, net.d_tags, (uint2*)net.d_comp, net.n, do_fill, net.d_work);
     if (!delta) {
         // (the copy path keeps the runs' h grids in sib_h[run index]: the slots the difference path caches bases in -- cached bases are void)
         net.sib_cache_valid = false;
@@ -4094,7 +4108,7 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
     const bool rects = v2 && rects_env && net.win_rects;
     k_bin_prefix<<<1, BP_THREADS, 0, st>>>(net.d_gcnt, net.d_bin_start, net.d_tile_info, (uint2*)net.d_slot_desc, net.d_singles, net.n_cu,
                                     sib_max_fways(net, max_count), SIB_MAX_WWAYS, (int)std::min<size_t>(net.part_w_rows * 7, (size_t)1 << 30), (int)net.base_slots,
-                                    (int)std::min<size_t>(net.part_rows, (size_t)1 << 30), 2 * net.hw, net.n, rects ? 1 : 0, (int)(net.d_slots / GT_BS));
+                                    (int)std::min<size_t>(net.part_rows, (size_t)1 << 30), 2 * net.hw, net.n, rects ? 1 : 0, (int)(net.d_slots / GT_BS), net.d_work);
     static const bool stats = getenv("OMOK_SIB_STATS") && atoi(getenv("OMOK_SIB_STATS")); // diagnostics only: synchronises every round
     if (stats) {
         static long long acc[8] = {}, launches = 0;

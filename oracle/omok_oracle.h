@@ -95,6 +95,8 @@ void orc_sp_destroy(orc_sp* sp);
  * reset after create is episode 0); orc_sp_set_episode sets the index the NEXT reset will use (resume). */
 void orc_sp_reset(orc_sp* sp, const float* root_policy /*HW*/);
 void orc_sp_set_episode(orc_sp* sp, uint64_t episode);
+/* threads > 1: round_generate / round_scatter loop over the games under OpenMP (the reference's rayon par_iter, pme.rs:200-205); same results as threads = 1 */
+void orc_sp_set_threads(orc_sp* sp, int threads);
 int orc_sp_ply(const orc_sp* sp);
 int orc_sp_alive_count(const orc_sp* sp);
 int orc_sp_game_alive(const orc_sp* sp, int game);

@@ -72,6 +72,7 @@ def lib():
     L.orc_sp_destroy.argtypes = [C.c_void_p]
     L.orc_sp_reset.argtypes = [C.c_void_p, fp]
     L.orc_sp_set_episode.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_sp_set_threads.argtypes = [C.c_void_p, C.c_int]
     L.orc_sp_set_actions.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.orc_sp_compute_policy.argtypes = [C.c_void_p, C.c_int, fp]
     L.orc_sp_compute_policy.restype = C.c_int
@@ -236,6 +237,10 @@ class SelfPlay:
     def set_episode(self, episode):
         """index of the RNG stream the NEXT reset uses (every reset = one trainer iteration advances it)"""
         lib().orc_sp_set_episode(self.h, int(episode))
+
+    def set_threads(self, threads):
+        """threads > 1: the per-game loops of round_generate / round_scatter run under OpenMP (same results)"""
+        lib().orc_sp_set_threads(self.h, int(threads))
 
     def set_actions(self, actions):
         """externally chosen moves for every alive game: replaces sample(); mirror_generate() / advance() follow"""

@@ -71,6 +71,10 @@ struct orc_sp {
     int ply;
     int error;
     int external; /* the pending moves came from orc_sp_set_actions */
+    int threads;  /* orc_sp_set_threads: > 1 = the loops over games of round_generate / round_scatter run under OpenMP (bench.py's CPU baseline: the reference's
+                     rayon par_iter over agents, pme.rs:200-205); every game then pushes its requests into its own segment [64 g, 64 g + 64) and the segments are
+                     packed in game order afterwards, so the request list -- and everything else -- is the serial loop's (tests/test_oracle_selfplay.py) */
+    int32_t* mt_cnt; /* [games] requests in the game's segment (threads > 1 only) */
     tree_t* trees[2];
     orc_env* envs;
     uint8_t* alive;
@@ -252,6 +256,14 @@ static void run_sim(orc_sp* sp, tree_t* t, int game, uint32_t sim_index, uint32_
     if (child < 0) return;
     if (status != ORC_IN_PROGRESS) { /* pme.rs:177-181 */
         backup(t, child, status == ORC_DRAW ? 0.0f : 1.0f);
+    } else if (sp->threads > 1) { /* this game's own segment of the request list */
+        if (sp->mt_cnt[game] < 64) {
+            sp->req_game[64 * game + sp->mt_cnt[game]] = game;
+            sp->req_node[64 * game + sp->mt_cnt[game]] = child;
+            sp->mt_cnt[game]++;
+        } else {
+            sp->error = 2;
+        }
     } else if (sp->n_req < sp->cap_req) {
         sp->req_game[sp->n_req] = game;
         sp->req_node[sp->n_req] = child;
@@ -373,6 +385,8 @@ orc_sp* orc_sp_create(int n, int games, int cap_nodes, int cap_tables, uint64_t 
     sp->alive_mark = (uint8_t*)malloc((size_t)cap_nodes);
     sp->node_map = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)cap_nodes);
     sp->table_map = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)cap_tables);
+    sp->threads = 1;
+    sp->mt_cnt = (int32_t*)calloc((size_t)games, sizeof(int32_t));
     return sp;
 }
 
@@ -390,11 +404,12 @@ void orc_sp_destroy(orc_sp* sp) {
     }
     free(sp->envs); free(sp->alive); free(sp->status); free(sp->plies); free(sp->last_action);
     free(sp->replay); free(sp->req_game); free(sp->req_node); free(sp->alive_mark);
-    free(sp->node_map); free(sp->table_map);
+    free(sp->node_map); free(sp->table_map); free(sp->mt_cnt);
     free(sp);
 }
 
 void orc_sp_set_episode(orc_sp* sp, uint64_t episode) { sp->episode = episode; }
+void orc_sp_set_threads(orc_sp* sp, int threads) { sp->threads = threads > 1 ? threads : 1; }
 
 void orc_sp_reset(orc_sp* sp, const float* root_policy) {
     sp->key = orc_stream_key(sp->seed, sp->episode);
@@ -431,6 +446,28 @@ int orc_sp_round_generate(orc_sp* sp, int round, int batch_size, float epsilon, 
                           float* inputs, int max_req) {
     const int side = sp->ply & 1;
     sp->n_req = 0;
+    if (sp->threads > 1 && batch_size <= 64) { /* games are independent (pme.rs:200-205): one game per task, requests packed in game order afterwards */
+        int64_t sims = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(sp->threads) reduction(+ : sims)
+        for (int g = 0; g < sp->games; ++g) {
+            sp->mt_cnt[g] = 0;
+            if (!sp->alive[g]) continue;
+            tree_t* t = &sp->trees[side][g];
+            const uint32_t tree_global = (uint32_t)((sp->game_offset + g) * 2 + side);
+            if (round == 0) apply_noise(sp, t, epsilon, alpha, tree_global);
+            for (int i = 0; i < batch_size; ++i) {
+                run_sim(sp, t, g, (uint32_t)(round * batch_size + i), tree_global);
+                sims += 1;
+            }
+        }
+        sp->stat_sims += sims;
+        for (int g = 0; g < sp->games; ++g) /* (ascending, destination <= source: in place) */
+            for (int i = 0; i < sp->mt_cnt[g]; ++i) {
+                sp->req_game[sp->n_req] = sp->req_game[64 * g + i];
+                sp->req_node[sp->n_req] = sp->req_node[64 * g + i];
+                sp->n_req++;
+            }
+    } else
     for (int g = 0; g < sp->games; ++g) {
         if (!sp->alive[g]) continue;
         tree_t* t = &sp->trees[side][g];
@@ -443,9 +480,10 @@ int orc_sp_round_generate(orc_sp* sp, int round, int batch_size, float epsilon, 
     }
     if (inputs) {
         if (sp->n_req > max_req) { sp->error = 3; return -1; }
-        orc_env env;
-        env.n = sp->n;
+#pragma omp parallel for schedule(static) num_threads(sp->threads) if (sp->threads > 1)
         for (int r = 0; r < sp->n_req; ++r) {
+            orc_env env;
+            env.n = sp->n;
             const node_t* nd = &sp->trees[side][sp->req_game[r]].nodes[sp->req_node[r]];
             env.turn = nd->turn;
             env.legal = nd->legal;
@@ -464,7 +502,16 @@ void orc_sp_request_info(const orc_sp* sp, int r, int* game, int* node) {
 /* pme.rs:222-265 */
 void orc_sp_round_scatter(orc_sp* sp, const float* p, const float* v) {
     const int side = sp->ply & 1, hw = sp->hw;
-    for (int r = 0; r < sp->n_req; ++r) {
+    /* a game's requests are adjacent and must be applied in order (one tree); different games are independent: with threads > 1 a task = one game's stretch */
+    int n_seg = 0;
+    int32_t* seg = sp->mt_cnt; /* (reused: start of every stretch, n_seg <= games) */
+    if (sp->threads > 1)
+        for (int r = 0; r < sp->n_req; ++r)
+            if (r == 0 || sp->req_game[r] != sp->req_game[r - 1]) seg[n_seg++] = r;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(sp->threads) if (sp->threads > 1)
+    for (int sgi = 0; sgi < (sp->threads > 1 ? n_seg : 1); ++sgi) {
+      const int r0 = sp->threads > 1 ? seg[sgi] : 0, r1 = sp->threads > 1 ? (sgi + 1 < n_seg ? seg[sgi + 1] : sp->n_req) : sp->n_req;
+      for (int r = r0; r < r1; ++r) {
         tree_t* t = &sp->trees[side][sp->req_game[r]];
         node_t* nd = &t->nodes[sp->req_node[r]];
         const float* raw = p + (size_t)r * (size_t)hw;
@@ -478,6 +525,7 @@ void orc_sp_round_scatter(orc_sp* sp, const float* p, const float* v) {
         }
         nd->has_policy = 1;
         backup(t, sp->req_node[r], value);
+      }
     }
     sp->n_req = 0;
 }

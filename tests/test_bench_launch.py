@@ -58,6 +58,49 @@ def test_bench_says_so_when_the_gpus_are_not_there(tmp_path):
     import torch
     if torch.cuda.device_count() >= 4:
         return
-    assert r.returncode == 0
+    assert r.returncode != 0  # nothing was measured: not a success
     out = json.loads(r.stdout.splitlines()[-1])
     assert "4 GPUs needed" in out["error"] and out["value"] is None
+
+
+def test_result_line_is_short_and_complete(tmp_path):
+    """The driver parses ONE line of a few KB (round 5's had grown to 24 KB and its cpu_baseline fell out of the record): the last line stays under 8000 characters
+    and carries the contract's keys, `roofline` and `cpu_baseline` (here: the mock engine + the real CPU leg, bounded to a few seconds); the verbose record goes
+    to the sidecar file."""
+    full = tmp_path / "full.json"
+    r = _run(["--steps", "1", "--warmup", "0", "--games", "4", "--cpu-seconds", "14"], tmp_path, {"OMOK_BENCH_FULL": str(full)})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 2 and all(len(x) < 8000 for x in lines)
+    first, last = json.loads(lines[0]), json.loads(lines[-1])
+    assert "cpu_baseline" not in first and not any(v is None for k, v in first.items() if k != "vs_baseline")  # the early safety line has no null placeholders
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in last, key
+    assert len(last["dtype"]) <= 80 and last["notes"] == "profiles/bench_line_notes.md"
+    cb = last["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["unit"] == "games/s" and len(cb["sample"]) < 200 and cb["net_tflops"] > 0
+    rf = last["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and {"achieved", "peak", "unit", "frac", "traffic"} <= set(rf)
+    assert all(not isinstance(v, str) or len(v) <= 120 for v in rf.values())  # numbers and short identifiers only
+    assert os.path.exists(os.path.join(ROOT, "profiles", "bench_line_notes.md"))
+    rec = json.load(open(full))  # the verbose record of the same run
+    assert rec["value"] == first["value"] or abs(rec["value"] - first["value"]) <= 1e-4 * abs(rec["value"])
+    assert "legs" in rec["cpu_baseline"] and "mm_calibration_tflops_by_threads" in rec["cpu_baseline"]
+
+
+def test_compact_line_of_a_real_verbose_record():
+    """compact_line on round 5's real 24-KB line (profiles/r05_bench_c2_20steps_driver_style_final_build.json): under the limit, and the oracle precision leg, the
+    CPU baseline and every roofline object survive as numbers."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_c2_20steps_driver_style_final_build.json")))
+    assert len(json.dumps(rec)) > 20000
+    line = bench.compact_line(rec)
+    text = json.dumps(line)
+    assert len(text) < 8000, len(text)
+    assert line["value"] == float(f"{rec['value']:.5g}") and line["cpu_baseline"]["cores"] == rec["cpu_baseline"]["cores"]
+    vs = line["precision"]["vs_oracle"]
+    assert vs["difference_path"]["max_dlogit"] < 1e-3 and vs["difference_path"]["difference_path_rounds"] > 0 and vs["north_star_logits_1e-3"]["difference_path"] is True
+    for key in ("roofline", "roofline_fc0", "roofline_net", "roofline_tree"):
+        assert 0 < line[key]["frac"] and "note" not in line[key] and "kernel_members" not in line[key]

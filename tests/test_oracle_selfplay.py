@@ -110,3 +110,64 @@ def test_first_round_semantics():
     # masked + renormalised policy: occupied cell is 0 (pme.rs:235-249)
     for i in range(1, 1 + k):
         assert floats[i, 1 + ints[i, 1]] == 0.0 and abs(floats[i, 1:].sum() - 1.0) < 1e-5
+
+
+def test_threaded_round_loops_reproduce_the_serial_ones():
+    """orc_sp_set_threads (bench.py's CPU baseline: the reference's rayon par_iter over agents, pme.rs:200-205): games in parallel, the request list packed in game
+    order -> request rows, moves and trees are the serial loop's, bit for bit."""
+    n, games, count, k = 9, 12, 48, 8
+    tensors = weights.init_random(n, seed=0)
+    net = O.Net(n, tensors)
+    root_p, _ = net.forward(O.Environment(n).encode_nn_input(0)[None])
+    sps = [O.SelfPlay(n, games, cap_nodes=1024, cap_tables=512, seed=5) for _ in range(2)]
+    sps[1].set_threads(4)
+    for sp in sps:
+        sp.reset(root_p[0])
+    for ply in range(12):
+        for rnd in range(count // k):
+            a, b = (sp.round_generate(rnd, k, 0.25, 0.03) for sp in sps)
+            assert np.array_equal(a, b), (ply, rnd)
+            if len(a):
+                p, v = net.forward(a, threads=4)
+                for sp in sps:
+                    sp.round_scatter(p, v)
+        assert np.array_equal(sps[0].sample(1.0, 30), sps[1].sample(1.0, 30))
+        m = sps[0].mirror_generate()
+        assert np.array_equal(m, sps[1].mirror_generate())
+        p, _ = net.forward(m, threads=4)
+        for sp in sps:
+            sp.advance(p)
+        assert _fingerprint(sps[0], games) == _fingerprint(sps[1], games), f"ply {ply}"
+    assert sps[0].error == 0 and sps[1].error == 0
+
+
+def test_selfplay_fixture_n15_headline_regime():
+    """tests/golden/selfplay_n15.npz was generated through the LITERAL restatement (oracle/literal.c, tools/make_golden.py): 15x15, 800 simulations per move in 50
+    rounds of K = 16 -- fully expanded nodes, depth >= 3, the regime the headline runs in.  oracle/selfplay.c (the checker of the -m gpu tests) must reproduce its
+    moves and canonical tree dumps ply by ply."""
+    g = np.load(os.path.join(GOLD, "selfplay_n15.npz"))
+    n, games, count, k = int(g["n"]), int(g["games"]), int(g["count"]), int(g["k"])
+    assert n == 15 and count == 800 and int(g["searched_depth"].min()) >= 3 and int(g["searched_nodes"].min()) > 700
+    net = O.Net(n, weights.init_random(n, seed=0))
+    root_p, _ = net.forward(O.Environment(n).encode_nn_input(0)[None])
+    sp = O.SelfPlay(n, games, cap_nodes=8192, cap_tables=2048, seed=int(g["seed"]))
+    sp.set_threads(2)
+    sp.reset(root_p[0])
+    for ply in range(int(g["plies"])):
+        for rnd in range(count // k):
+            inp = sp.round_generate(rnd, k, 0.25, 0.03)
+            if len(inp):
+                p, v = net.forward(inp, threads=8)
+                sp.round_scatter(p, v)
+        assert np.array_equal(sp.sample(1.0, int(g["threshold"])), g["actions"][ply]), f"ply {ply}"
+        p, _ = net.forward(sp.mirror_generate(), threads=8)
+        sp.advance(p)
+        h = hashlib.sha256()
+        for gi in range(games):
+            for side in (0, 1):
+                ints, floats = sp.tree_dump(gi, side)
+                h.update(np.ascontiguousarray(ints[:, :7]).tobytes())
+                h.update(np.ascontiguousarray(ints[:, 7] & 0xFFFF).tobytes())
+                h.update(floats.tobytes())
+        assert h.hexdigest() == str(g["fingerprints"][ply]), f"ply {ply}"
+    assert sp.error == 0

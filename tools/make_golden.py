@@ -7,6 +7,10 @@
    vectors, not reference outputs.
 2. selfplay_n9.npz — move sequences / final tree fingerprints of small oracle self-play runs
    (regression pins for oracle/selfplay.c; the reference has no tests for mcts/executor/agent).
+3. selfplay_n15.npz — the regime the headline runs in (15x15, 800 simulations per move in 50 rounds of K = 16: fully
+   expanded nodes, depth >= 3), generated through the LITERAL restatement (oracle/literal.c: the reference's own data
+   structures) and checked against oracle/selfplay.c by tests/test_oracle_selfplay.py: moves and canonical tree dumps
+   of the first plies of two games.
 """
 import hashlib
 import os
@@ -108,8 +112,57 @@ def make_selfplay():
     print("selfplay_n9: plies", [sp.game_plies(g) for g in range(games)], "status", [sp.game_status(g) for g in range(games)])
 
 
+def fingerprint_dumps(sp, games):
+    """sha256 over the canonical dumps of both trees of every game (the surface oracle.SelfPlay and oracle.Literal share)"""
+    h = hashlib.sha256()
+    for g in range(games):
+        for side in (0, 1):
+            ints, floats = sp.tree_dump(g, side)
+            h.update(np.ascontiguousarray(ints[:, :7]).tobytes())  # node records
+            h.update(np.ascontiguousarray(ints[:, 7] & 0xFFFF).tobytes())  # insertion ranks (the high half is per-oracle bookkeeping)
+            h.update(floats.tobytes())  # w and policy bits
+    return h.hexdigest()
+
+
+def make_selfplay_n15():
+    n, games, count, k, plies, seed = 15, 2, 800, 16, 4, 15
+    tensors = weights.init_random(n, seed=0)
+    net = oracle.Net(n, tensors)
+    root_p, _ = net.forward(oracle.Environment(n).encode_nn_input(0)[None])
+    sp = oracle.Literal(n, games, seed=seed, cap_nodes=8192)
+    sp.reset(root_p[0])
+    actions, prints, nodes, depth = [], [], [], []
+    for _ in range(plies):
+        for rnd in range(count // k):
+            inp, _ = sp.round_generate(rnd, k, 0.25, 0.03)
+            if len(inp):
+                p, v = net.forward(inp, threads=8)
+                sp.round_scatter(p, v)
+        side = sp.ply & 1
+        for g in range(games):  # the searched trees' shape: what makes this the headline's regime
+            ints, _ = sp.tree_dump(g, side)
+            d = np.zeros(len(ints), dtype=np.int64)
+            for i in range(1, len(ints)):
+                d[i] = d[ints[i, 0]] + 1
+            nodes.append(len(ints))
+            depth.append(int(d.max()))
+        actions.append(sp.sample(1.0, 30))
+        m, _ = sp.mirror_generate()
+        p, _ = net.forward(m, threads=8)
+        sp.advance(p)
+        prints.append(fingerprint_dumps(sp, games))
+    assert sp.error == 0
+    np.savez_compressed(os.path.join(OUT, "selfplay_n15.npz"), n=n, games=games, count=count, k=k, seed=seed, threshold=30, plies=plies,
+                        actions=np.stack(actions), fingerprints=np.array(prints), searched_nodes=np.array(nodes), searched_depth=np.array(depth))
+    print("selfplay_n15: nodes of the searched trees", nodes, "depth", depth)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "n15" in sys.argv[1:]:  # (only the new fixture: the others are committed and stay as they are)
+        make_selfplay_n15()
+        sys.exit(0)
     make_net(9, 8)
     make_net(15, 4)
     make_selfplay()
+    make_selfplay_n15()
