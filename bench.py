@@ -307,7 +307,8 @@ def cpu_baseline(args, mean_plies, budget_s):
         115 KB-per-row activations in cache, large ones give MKL more rows per product)."""
         cs = 256
 
-        def __init__(self):
+        def __init__(self, row_parallel):
+            self.row_parallel = row_parallel  # False: whole chunks of 256 rows one after the other on torch's intra-op threads (the better one on a few cores)
             sh = oa.weights.tensor_shapes(n)
             t = [torch.as_tensor(np.asarray(x, dtype=np.float32).reshape(s_)) for x, s_ in zip(tensors, sh)]
             self.w_in, self.b_in = t[0].reshape(3, 128).contiguous(), t[1]
@@ -335,16 +336,26 @@ def cpu_baseline(args, mean_plies, budget_s):
             return torch.softmax(torch.addmm(b_p, h1, w_p), dim=1), torch.tanh(torch.addmm(b_v, h1, w_v))
 
         def __call__(self, x, threads):
+            """rows dealt in chunks of `cs` to `threads` workers, every worker running its matrix products on ONE MKL thread: torch's intra-op pool does not scale the
+            trunk's small products (on the GPU box's 2 x 64 cores the same graph with 64 intra-op threads ran 3.4 k rows/s against 10.8 k of the row-parallel C loops)"""
             xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).reshape(len(x), hw * 3)
-            ps, vs = [], []
+            starts = list(range(0, len(xt), self.cs))
             with torch.no_grad():
-                for i in range(0, len(xt), self.cs):
-                    p, v = self.chunk(xt[i:i + self.cs])
-                    ps.append(p)
-                    vs.append(v)
-            return torch.cat(ps).numpy(), torch.cat(vs).numpy().reshape(-1)
+                if threads <= 1 or len(starts) == 1 or not self.row_parallel:
+                    outs = [self.chunk(xt[i:i + self.cs]) for i in starts]
+                else:
+                    outs = list(self.pool(threads).map(lambda i: self.chunk(xt[i:i + self.cs]), starts))
+            return torch.cat([o[0] for o in outs]).numpy(), torch.cat([o[1] for o in outs]).numpy().reshape(-1)
 
-    mm_net = MMForward()
+        pools = {}
+
+        def pool(self, threads):
+            from concurrent.futures import ThreadPoolExecutor
+            if threads not in self.pools:  # (a worker's OpenMP / MKL team size is its own: set once, when the worker starts)
+                self.pools[threads] = ThreadPoolExecutor(max_workers=threads, initializer=lambda: torch.set_num_threads(1))
+            return self.pools[threads]
+
+    mm_net, mm_intra = MMForward(True), MMForward(False)
 
 
     def forward_torch(x, threads):
@@ -355,12 +366,14 @@ def cpu_baseline(args, mean_plies, budget_s):
     def forward_c(x, threads):  # the oracle's own fp32 forward (oracle/net.c: plain loops, OpenMP over blocks of 8 rows)
         return onet_c.forward(np.ascontiguousarray(x, dtype=np.float32).reshape(len(x), -1), threads=threads)
 
-    FORWARDS = {"torch-CPU mm (MKL sgemm)": mm_net, "torch-CPU (conv2d graph)": forward_torch, "oracle/net.c (OpenMP over rows)": forward_c}
+    FORWARDS = {"torch-CPU mm (MKL sgemm, row-parallel)": mm_net, "torch-CPU mm (MKL sgemm, intra-op threads)": mm_intra, "oracle/net.c (OpenMP over rows)": forward_c}
+    if os.environ.get("OMOK_BENCH_CONV2D"):  # (train.py's conv2d graph: 2.9 k rows/s on the GPU box's host at any thread count, rounds 5 and 6 -- not worth its calibration time)
+        FORWARDS["torch-CPU (conv2d graph)"] = forward_torch
 
     seen_rows = []  # request rows of the legs' real search rounds (for the oracle-vs-GPU check of the net outputs below)
 
-    def leg(games, sims, threads, seconds, max_plies, engine="torch-CPU mm (MKL sgemm)"):
-        torch.set_num_threads(threads)
+    def leg(games, sims, threads, seconds, max_plies, engine="torch-CPU mm (MKL sgemm, row-parallel)"):
+        torch.set_num_threads(1 if engine.endswith("row-parallel)") else threads)  # (the matrix-product forward runs its own workers, one MKL thread each)
         fwd = FORWARDS[engine]
 
         def forward(x):
@@ -426,19 +439,22 @@ def cpu_baseline(args, mean_plies, budget_s):
             calls += 1
         mm_cal[str(t)] = 2.0 * 1024 * 128 * hw * 512 / best_call / 1e12
     del xa, wb
-    # chunk size of the matrix-product forward: one 4096-row forward per candidate at the largest thread count
+    # chunk size of the matrix-product forward (rows per task of a worker): two 4096-row forwards per candidate on the smallest candidate thread count
+    torch.set_num_threads(1)
     xv = (np.random.RandomState(1).rand(4096, 3 * hw) < 0.2).astype(np.float32)
     mm_chunks = {}
-    for cs in (256, 1024, 4096):
+    for cs in (32, 64, 128, 256):
+        if 4096 // cs < cand[0]:
+            continue  # (fewer tasks than workers)
         mm_net.cs = cs
-        mm_net(xv[:max(cs, 1024)], cand[-1])
+        mm_net(xv, cand[0])
         t1 = time.perf_counter()
-        mm_net(xv, cand[-1])
+        mm_net(xv, cand[0])
         mm_chunks[cs] = 4096 / (time.perf_counter() - t1)
-    mm_net.cs = max(mm_chunks, key=mm_chunks.get)
+    mm_net.cs = max(mm_chunks, key=mm_chunks.get) if mm_chunks else 64
     # the matrix-product forward against the oracle's own (the checker of the -m gpu tests) on 64 deterministic rows
     xv = (np.random.RandomState(0).rand(64, 3 * hw) < 0.2).astype(np.float32)
-    pm, vm = mm_net(xv, cand[-1])
+    pm, vm = mm_net(xv, min(8, cores))
     pc, vc = forward_c(xv, min(8, cores))
     mm_check = {"rows": 64, "max_dp": float(np.abs(pm - pc).max()), "max_dv": float(np.abs(vm - vc).max())}
     calib_legs = {(e, t): leg(g2, args.sims, t, max(0.6, 0.15 * budget_s / (len(FORWARDS) * len(cand))), 1, e) for e in FORWARDS for t in cand}
@@ -485,7 +501,7 @@ def cpu_baseline(args, mean_plies, budget_s):
             "thread_calibration_sims_per_s": {f"{e} @ {t} threads": v for (e, t), v in calib.items()},
             "sample": f"C2': {g2} games x {rounds_up} sims x {best['plies_completed']} plies ({best['seconds']:.0f} s), {best_t} of {cores} threads",
             "sample_long": f"C2' = {g2} games x {rounds_up} sims/move ({g2 * k}-row forwards) x up to 4 plies (bounded to {share:.0f} s; {best['plies_completed']} plies completed) on {best_t} of {cores} "
-                           f"threads (fastest of {cand} x three forwards): oracle C tree code (games under OpenMP) + fp32 forward by {best_e}; {best['sims_per_s']:.0f} sims/s, converted with {mean_plies:.1f} plies/game "
+                           f"threads (fastest of {cand} x the forwards of thread_calibration_sims_per_s): oracle C tree code (games under OpenMP) + fp32 forward by {best_e}; {best['sims_per_s']:.0f} sims/s, converted with {mean_plies:.1f} plies/game "
                            f"from the GPU run.  Also C1 (1 game, 100->112 sims/move, whole game or {0.08 * budget_s:.0f} s) and, on 1 thread, C1 and {g1t} games of C2': see legs",
             "cpu_model": model, "sims_per_s": best["sims_per_s"],
             "one_thread_value": legs["c2p_one_thread"]["sims_per_s"] / (rounds_up * mean_plies),

@@ -75,9 +75,19 @@ __device__ inline void split8(const float* v, half8& hi, half8& lo) {
     hi = H.h;
     lo = L.h;
 }
-// LeakyRelu on a pair: one packed multiply + two v_max
+// LeakyRelu on a pair: one packed multiply + two v_max.  The multiply is written as the instruction: left to the compiler, `(f32x2){a, b} * 0.2f` came out as two
+// v_mul_f32 in 114 of k_sib_children2's 216 pairs (tools/isa_hist.py).  Same rounding either way.
+#ifndef LRELU_PK_ASM
+#define LRELU_PK_ASM 0 // (round 6 A-B, profiles/r06_ab_children_diet.txt: -115 VALU per child, no change in time: off)
+#endif
 __device__ inline f32x2 lrelu2(float a, float b) {
+#if LRELU_PK_ASM
+    const f32x2 x = {a, b}, c = {0.2f, 0.2f};
+    f32x2 y;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(y) : "v"(x), "s"(c));
+#else
     const f32x2 y = (f32x2){a, b} * 0.2f;
+#endif
     f32x2 r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r[0]) : "v"(a), "v"(y[0]));
     asm("v_max_f32 %0, %1, %2" : "=v"(r[1]) : "v"(b), "v"(y[1]));
@@ -1835,7 +1845,23 @@ constexpr int V2_RING = SIB_WPX - V2_TPX;                 // 24
 constexpr int V2_ZERO_CELL = 32, V2_WORD_CELL = 33;       // cells 0..31: tile grid / staging rows
 constexpr int V2_CELLS = 34;
 constexpr int V2_WAVE_FLOATS = V2_CELLS * GRID_STRIDE;
-constexpr int V2_LDS = TR_WBYTES + TR_SIDE_FLOATS * 4 + 8 * V2_WAVE_FLOATS * 4;
+// Round 6: the last layer's bias (b2, 128 channels per block) is added by ONE more MFMA per m-tile instead of 64 vector adds + 16 LDS reads per call: A = the bias as three f16 pieces
+// (hi, lo, lo of lo: 33 bits) in k = 0..2 of a 512-B fragment (only the k = 0..7 half of a fragment is stored: B is zero in k = 8..15, so both lane halves read the same 32 lanes),
+// B = 1.0 in k = 0..2.  216 MFMAs per child instead of 200, 128 vector adds fewer per L1L2 call pair (tools/isa_hist.py); the matrix pipes are the idle unit of this kernel.
+#ifndef V2_BIAS_MFMA
+#define V2_BIAS_MFMA 0 // (round 6 A-B: measured, no gain: off)
+#endif
+#ifndef V2_DYNAMIC
+#define V2_DYNAMIC 1 // a workgroup's children handed out from an LDS counter (0: every wave takes every eighth entry)
+#endif
+#if V2_DYNAMIC && SIB2_EXP == 8
+#error "SIB2_EXP=8 (contiguous shares per wave) needs -DV2_DYNAMIC=0"
+#endif
+#ifndef V2_FAR_BY_STORE
+#define V2_FAR_BY_STORE 0 // (round 6 A-B: no gain: off) the exact zeros of far pixels: staged pieces overwritten under a branch instead of selected value by value (44 selects per store_rows call)
+#endif
+constexpr int V2_BIAS_BYTES = V2_BIAS_MFMA ? 3 * 4 * 512 : 0;
+constexpr int V2_LDS = TR_WBYTES + TR_SIDE_FLOATS * 4 + 8 * V2_WAVE_FLOATS * 4 + V2_BIAS_BYTES;
 static_assert(V2_LDS <= 160 * 1024, "k_sib_children2 LDS");
 #define OL() ({ int lq_ = lane; asm volatile("" : "+v"(lq_)); lq_; })
 #define TILE_A(LQ) (((LQ) & 31) < V2_TPX ? ((LQ) & 31) : V2_TPX - 1)
@@ -1871,6 +1897,26 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
     for (int i = tid; i < TR_WBYTES / 16; i += blockDim.x) ((uint4*)smem)[i] = wt[i];
     for (int i = tid; i < TR_SIDE_FLOATS; i += blockDim.x) ((float*)lside)[i] = side[i];
     for (int i = tid; i < 8 * V2_WAVE_FLOATS; i += blockDim.x) ((float*)(smem + TR_WBYTES + TR_SIDE_FLOATS * 4))[i] = 0.0f;
+    const half8* lbias = (const half8*)(smem + TR_WBYTES + TR_SIDE_FLOATS * 4 + 8 * V2_WAVE_FLOATS * 4); // [blk][m][row 32]: b2 as f16 pieces in k = 0..2
+    if (V2_BIAS_MFMA)
+        for (int i = tid; i < 3 * 4 * 32; i += blockDim.x) {
+            const float b = side[(i >> 7) * TR_SIDE_PER_BLOCK + 11 * NM + (i & 127)];
+            const _Float16 p0 = (_Float16)b;
+            const float r1 = b - (float)p0;
+            const _Float16 p1 = (_Float16)r1, p2 = (_Float16)(r1 - (float)p1);
+            ((half8*)lbias)[i] = (half8){p0, p1, p2, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+        }
+#if V2_DYNAMIC
+    // Round 6: the children of a workgroup are handed out from a counter in LDS instead of every wave taking every eighth entry.  The second wave of a SIMD (waves 4..7)
+    // runs ~15 % slower than the first (issue arbitration favours the older wave: profiles/r05_children_store_order.txt, item 7), so with equal shares waves 0..3 end early
+    // and the others finish alone; handed out on demand, all eight end together.  A child's arithmetic does not depend on the wave that takes it: same bits.
+    __shared__ int s_next_entry;
+    if (tid == 0) {
+        const int nsib0 = d_cnt[2], per0 = (nsib0 + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int wb0 = (int)blockIdx.x * per0 < nsib0 ? (int)blockIdx.x * per0 : nsib0;
+        s_next_entry = wb0 + 16; // (entries wb0 .. wb0 + 15: the waves' first two passes)
+    }
+#endif
     __syncthreads(); // (the only workgroup barrier: from here on a wave touches read-only LDS and its own cells)
     for (int i = 0; i < (wv >> 2); ++i) __builtin_amdgcn_s_sleep(120); // the two waves of a SIMD (w, w + 4) start about half a pass apart
 #if SIB2_EXP == 17 // (diagnostic, results unchanged: every wave's cycles from here to its end -> tprof[workgroup * 8 + wave], summed over the launches)
@@ -1939,13 +1985,21 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
         half8 gh[2], gl[2];
         split8(gv, gh[0], gl[0]);
         split8(gv + 8, gh[1], gl[1]);
+        union { uint32_t u[4]; half8 v; } one3; // B of the bias MFMA: 1.0 in k = 0..2 (lanes of half h = 0), zero elsewhere
+        one3.u[0] = h == 0 ? 0x3C003C00u : 0u;
+        one3.u[1] = h == 0 ? 0x00003C00u : 0u;
+        one3.u[2] = 0u;
+        one3.u[3] = 0u;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
+            if (V2_BIAS_MFMA) x[m] = MFMA16(lbias[(blk * 4 + m) * 32 + (lane & 31)], one3.v, x[m]);
+            else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 bv = *(const f32x4*)(b2 + 32 * m + 8 * g + 4 * h);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x[m][4 * g + i] += bv[i];
+            }
             }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -2044,8 +2098,12 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
                         asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax_v) : "v"(v0), "v"(v1));
                         asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax_l) : "v"(l0), "v"(l1));
                     }
-                    if (lane_valid) stage_w[(mm * 2 + sx) * 2 + h] = far ? make_uint4(0u, 0u, 0u, 0u) : H.v;
+                    if (lane_valid) stage_w[(mm * 2 + sx) * 2 + h] = V2_FAR_BY_STORE ? H.v : (far ? make_uint4(0u, 0u, 0u, 0u) : H.v);
                 }
+            if (V2_FAR_BY_STORE && lane_valid && far) { // a far lane's pieces are overwritten with zeros (a branch most passes of interior children skip) instead of 32 selects per call
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) stage_w[p4 * 2 + h] = make_uint4(0u, 0u, 0u, 0u);
+            }
             WAVE_LDS_FENCE();
             int eh = (int)((__float_as_uint(amax_v * MX6_AMAX_ADJ) >> 23) & 0xFFu) - 2, el = (int)((__float_as_uint(amax_l * MX6_AMAX_ADJ) >> 23) & 0xFFu) - 2;
             eh = eh < 1 ? 1 : eh;
@@ -2055,7 +2113,7 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ev[i] = res[2 * i]; od[i] = res[2 * i + 1]; }
             lo6[q] = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ev, od, __uint_as_float((uint32_t)el << 23));
-            if (far) lo6[q] = (u32x6){0u, 0u, 0u, 0u, 0u, 0u};
+            if (!V2_FAR_BY_STORE && far) lo6[q] = (u32x6){0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint4 v = *(const uint4*)(wgrid + rd_gi[i] * GRID_STRIDE + 4 * (lane & 7));
@@ -2069,6 +2127,13 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
                 stage_w[q * 4 + h] = make_uint4(lo6[q][0], lo6[q][1], lo6[q][2], lo6[q][3]);
                 ((uint2*)(stage_w + q * 4 + 2))[h] = make_uint2(lo6[q][4], lo6[q][5]);
                 ((uint16_t*)(stage_w + q * 4 + 3))[h] = (uint16_t)esc[q];
+            }
+            if (V2_FAR_BY_STORE && far) { // zero codes (the scale bytes stay: any scale times zero)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    stage_w[q * 4 + h] = make_uint4(0u, 0u, 0u, 0u);
+                    ((uint2*)(stage_w + q * 4 + 2))[h] = make_uint2(0u, 0u);
+                }
             }
         }
         WAVE_LDS_FENCE();
@@ -2185,7 +2250,13 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
     uint4 ent_c = sib_rows[entry_of(e_begin)], ent_n = sib_rows[entry_of(e_begin + ESTR)];
     uint32_t slot_c = sib_slot[entry_of(e_begin)], slot_n = sib_slot[entry_of(e_begin + ESTR)];
     uint64_t word_c = fetch_word(ent_c);
+#if V2_DYNAMIC
+    int e_nn_keep = 0;
+    int e_next = e_begin + ESTR; // entry of the next pass (its descriptor is in ent_n); the one after that comes from the counter
+    for (int e0 = e_begin; e0 < e_end; e0 = e_next, e_next = e_nn_keep) {
+#else
     for (int e0 = e_begin; e0 < e_end; e0 += ESTR) {
+#endif
 #if SIB2_EXP == 3 || SIB2_EXP == 6
         // (experiment: the waves of the workgroup stay on the same entries by a barrier per pass / per 4 passes; a wave that has left the loop has ended and no longer counts)
         if (SIB2_EXP == 3 || (((e0 - e_begin) >> 3) & 3) == 0) __builtin_amdgcn_s_barrier();
@@ -2251,8 +2322,16 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
         uint64_t* cw = (uint64_t*)(wgrid + V2_WORD_CELL * GRID_STRIDE);
         if (lane < 2 * NW) cw[lane] = word_c;
         const uint64_t word_n = fetch_word(ent_n);
-        const uint4 ent_nn = sib_rows[entry_of(e0 + 2 * ESTR)];
-        const uint32_t slot_nn = sib_slot[entry_of(e0 + 2 * ESTR)];
+#if V2_DYNAMIC
+        int e_nn = 0;
+        if (lane == 0) e_nn = atomicAdd(&s_next_entry, 1);
+        e_nn = __builtin_amdgcn_readfirstlane(e_nn);
+        e_nn_keep = e_nn;
+#else
+        const int e_nn = e0 + 2 * ESTR;
+#endif
+        const uint4 ent_nn = sib_rows[entry_of(e_nn)];
+        const uint32_t slot_nn = sib_slot[entry_of(e_nn)];
         WAVE_LDS_FENCE();
         uint32_t bits[3];
         input_bits(cw, turn, bpxA, bits);
@@ -3340,6 +3419,9 @@ __global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, co
 // Wp : [ksteps][MT][hi|lo][lane][8] f16 (1 KiB fragments), Act: rows of [ksteps][hi h0|hi h1|lo h0|lo h1]
 // 8 waves: wm = wave>>1 owns MT/4 m-tiles, ws = wave&1 owns 2 of the 4 sample tiles.
 
+#ifndef GEMM_T_DB
+#define GEMM_T_DB 0 // (round 6 A-B: 1 = fragments of k-step t + 1 read into a second register set during the MFMAs of k-step t: fc1 + heads 28.5 ms per 150 rounds against 26.8: slower, off)
+#endif
 template <int MT, int EPI, int TAG, int NST, int PRIO>
 __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksteps,
                                                 size_t act_row_u4, int k_full, int last_cnt, int lo_off,
@@ -3408,6 +3490,74 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
 
+#if GEMM_T_DB
+    // Round 6: the fragments of k-step t + 1 are read from LDS into a second register set while the MFMAs of k-step t run, and the LDS-DMA of k-step t + 3 goes out behind
+    // the same barrier (its slot's readers -- k-step t -- have all passed their lgkmcnt wait in front of that barrier): nothing waits on the LDS or on L2 between a barrier and the
+    // k-step's 6 MTW MFMAs.  Before (one register set, read after the barrier): fc1 35 % of the matrix peak, the heads 34 %.  Same MFMAs in the same order: same bits.
+    static_assert(NST == 3, "the double-buffered loop is written for a 3-slot ring");
+    struct Frags { half8 bh[2], bl[2], ah[MTW], al[MTW]; };
+    auto lds_read = [&](Frags& f, int sl) {
+        const half8* L = (const half8*)(lds + sl * STAGE_U4);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f.bh[c] = L[(WFR + (2 * ws + c) * 2 + 0) * 64 + lane];
+            f.bl[c] = L[(WFR + (2 * ws + c) * 2 + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            f.ah[i] = L[((wm * MTW + i) * 2 + 0) * 64 + lane];
+            f.al[i] = L[((wm * MTW + i) * 2 + 1) * 64 + lane];
+        }
+    };
+    const int pre = ksteps < 3 ? ksteps : 3;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        if (p < pre) issue(p);
+    // k-step 0's share has landed (later ones stay in flight), every wave's share is visible, its fragments go to the first register set
+    if (pre == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+    else if (pre == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    Frags fa, fb;
+    lds_read(fa, 0);
+    auto kstep = [&](const Frags& cur, Frags& nxt, int t, int sl) { // sl = t % 3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // `cur` (read a whole k-step ago) is complete; behind the barrier below slot sl is free
+        const bool more = t + 1 < ksteps;
+        if (more) { // this wave's share of k-step t + 1 has landed (k-step t + 2's may still be in flight)
+            if (t + 2 < ksteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (more) lds_read(nxt, sl == 2 ? 0 : sl + 1);
+        const bool stage = t + 3 < ksteps;
+        if (stage) issue_begin();
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) MFMA3(cur.ah[i], cur.al[i], cur.bh[c], cur.bl[c], acc[i][c]);
+            if (stage) {
+#pragma unroll
+                for (int q = i; q < LPW; q += MTW) issue_one(q, sl);
+            }
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (stage) kt += 1;
+    };
+    {
+        int sl = 0;
+        for (int t = 0; t < ksteps; t += 2) {
+            kstep(fa, fb, t, sl);
+            sl = sl == 2 ? 0 : sl + 1;
+            if (t + 1 < ksteps) {
+                kstep(fb, fa, t + 1, sl);
+                sl = sl == 2 ? 0 : sl + 1;
+            }
+        }
+    }
+#else
 #pragma unroll
     for (int p = 0; p < NST - 1; ++p)
         if (p < ksteps) issue(p);
@@ -3451,6 +3601,8 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
         slot = slot + 1 == NST ? 0 : slot + 1;
         nslot = nslot + 1 == NST ? 0 : nslot + 1;
     }
+
+#endif
 
     // ---- epilogue ----
 #pragma unroll
