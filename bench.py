@@ -88,7 +88,7 @@ def compact_line(full):
     cb = full.get("cpu_baseline")
     line["cpu_baseline"] = None  # (the contract's key: null on multi-GPU runs and when the leg was switched off; the early line drops nulls)
     if isinstance(cb, dict):
-        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "host_threads", "cpu_model", "sims_per_s", "nn_evals_per_s", "net_tflops",
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "host_threads", "host_cpu_quota", "cpu_model", "sims_per_s", "nn_evals_per_s", "net_tflops",
                                           "tree_threads", "net_forward", "one_thread_value", "c1_games_per_s", "error", "skipped"))
     fmt = full.get("fc0_format")
     if isinstance(fmt, dict):
@@ -423,7 +423,29 @@ def cpu_baseline(args, mean_plies, budget_s):
     # (VERDICT round 5, item 8), train.py's conv2d graph (2.9 k rows/s on the GPU box's 2 x 64-core host whatever the thread count: it does not use the machine) and the
     # oracle's own row-parallel C loops.  The tree part is the oracle's C code with the loops over the games under OpenMP on the same threads (the reference: a rayon pool).
     # The one-thread legs keep 16 games.  Budget: 15 % calibration, 8 % per C1 leg, 50 % the C2' leg, 12 % the one-thread C2' leg.
-    cand = sorted({t for t in (64, 128, cores) if t <= cores}) or [cores]
+    # what the process may use of the host: the cgroup's CPU quota (the GPU pool's boxes grant 16 CPUs of a 2 x 64-core host: cpu.max "1600000 100000", measured round 6 --
+    # 64 workers then run at a quarter of their speed each) and the affinity mask
+    quota = None
+    try:
+        q_, per_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q_ == "max" else max(1, int(round(float(q_) / float(per_))))
+    except (OSError, ValueError):
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = cores
+    if quota and quota < usable:
+        cand = sorted({t for t in (quota, 2 * quota, 4 * quota) if t <= usable})
+    else:
+        cand = sorted({t for t in (64, 128, usable) if t <= usable}) or [usable]
+    try:  # glibc: keep the forward's multi-megabyte temporaries in the arenas (every mmap / munmap / page fault of 16+ workers in one process goes through one lock)
+        import ctypes
+        libc_ = ctypes.CDLL("libc.so.6")
+        libc_.mallopt(-3, 1 << 30)  # M_MMAP_THRESHOLD
+        libc_.mallopt(-1, 1 << 30)  # M_TRIM_THRESHOLD
+    except Exception:
+        pass
     g2, g1t = 256, 16
     flop_eval = 2.0 * (3 * 128 * hw + 3 * hw * (128 * 32 + 9 * 32 + 32 * 32 + 32 * 128) + 128 * hw * 512 + 512 * 512 + 512 + 512 * hw)
     # does MKL use the machine?  fc0's product alone ([1024, 128 HW] x [128 HW, 512]) at 1 thread and at every candidate count, ~1 s in all: TFLOP/s must scale
@@ -443,7 +465,7 @@ def cpu_baseline(args, mean_plies, budget_s):
     torch.set_num_threads(1)
     xv = (np.random.RandomState(1).rand(4096, 3 * hw) < 0.2).astype(np.float32)
     mm_chunks = {}
-    for cs in (32, 64, 128, 256):
+    for cs in (64, 128, 256):
         if 4096 // cs < cand[0]:
             continue  # (fewer tasks than workers)
         mm_net.cs = cs
@@ -494,12 +516,12 @@ def cpu_baseline(args, mean_plies, budget_s):
                                     "threads": best_t, "what": "oracle/net.c fp32 forward (plain loops, OpenMP over blocks of 8 rows) on request rows of the legs' search rounds"}
                                    if net_check else None),
             "value": best["sims_per_s"] / (rounds_up * mean_plies), "unit": "games/s", "cores": best_t, "host_threads": cores, "kind": "port",
-            "net_forward": best_e, "tree_threads": min(best_t, g2),
+            "net_forward": best_e, "tree_threads": min(best_t, g2), "host_cpu_quota": quota, "host_affinity_cpus": usable,
             "net_tflops": best["nn_evals"] * flop_eval / max(best["net_seconds"], 1e-9) / 1e12,  # the forward alone: evaluations x 2*MAC flops / time inside the forward
             "net_share_of_time": best["net_seconds"] / max(best["seconds"], 1e-9), "nn_evals_per_s": best["nn_evals_per_s"],
             "mm_calibration_tflops_by_threads": mm_cal, "mm_forward_rows_per_s_by_chunk": mm_chunks, "mm_forward_vs_oracle": mm_check,
             "thread_calibration_sims_per_s": {f"{e} @ {t} threads": v for (e, t), v in calib.items()},
-            "sample": f"C2': {g2} games x {rounds_up} sims x {best['plies_completed']} plies ({best['seconds']:.0f} s), {best_t} of {cores} threads",
+            "sample": f"C2': {g2} games x {rounds_up} sims x {best['plies_completed']} plies ({best['seconds']:.0f} s), {best_t} threads on {quota if quota else usable} granted CPUs of {cores}",
             "sample_long": f"C2' = {g2} games x {rounds_up} sims/move ({g2 * k}-row forwards) x up to 4 plies (bounded to {share:.0f} s; {best['plies_completed']} plies completed) on {best_t} of {cores} "
                            f"threads (fastest of {cand} x the forwards of thread_calibration_sims_per_s): oracle C tree code (games under OpenMP) + fp32 forward by {best_e}; {best['sims_per_s']:.0f} sims/s, converted with {mean_plies:.1f} plies/game "
                            f"from the GPU run.  Also C1 (1 game, 100->112 sims/move, whole game or {0.08 * budget_s:.0f} s) and, on 1 thread, C1 and {g1t} games of C2': see legs",

@@ -357,3 +357,34 @@ def test_full_size_rounds_first_games_against_the_oracle(n, games, count, k, max
     print(f"full-size rounds: {int(st['children2_launches'])} on the difference path, fully expanded non-root nodes {shape[0]}, depth {shape[1]}")
     assert st["children2_launches"] >= count // k + 10 and shape[0] >= 1 and shape[1] >= 2
     eng.close()
+
+
+def test_executed_work_counters_account_for_every_request_row():
+    """OMOK_STAT_WORK_* (the device-side counters behind bench.py's `executed_flops`): over a few plies of omok_selfplay_run with rounds on BOTH sibling paths (difference
+    path while >= 2048 rows, copy path below) every request row of a search round is counted exactly once -- as a child of a run or as a single row, on one of the two
+    paths -- runs evaluated in full never exceed the runs, and the window tiles walk between 1 and 49 pixels each."""
+    n, k, sims = 15, 16, 64
+    for games, diff_expected in ((192, True), (48, False)):  # 3072-row rounds (difference path), 768-row rounds (copy path)
+        eng = oa.Engine(board_size=n, games=games, max_nodes=1024, max_tables=256, max_batch_k=k, seed=5)
+        eng.load_random_weights(0)
+        sp = oa.SelfPlay(eng)
+        sp.reset()
+        eng.reset_stats()
+        st = sp.run(sims, k, 0.25, 0.03, 1.0, 30, 3)
+        rounds = 3 * (sims // k)
+        diff_rows = st["work_diff_children"] + st["work_diff_singles"]
+        copy_rows = st["work_copy_children"] + st["work_copy_singles"]
+        # every simulation of these first plies ends in one request row (no terminal leaves yet); the engine's `evals` adds the plies' mirror evaluations (at most one per game and ply)
+        assert diff_rows + copy_rows == st["sims"] == rounds * k * games, (games, st)
+        assert diff_rows + copy_rows <= st["evals"] <= diff_rows + copy_rows + 3 * games, (games, st)
+        assert (st["children2_launches"] > 0) == diff_expected and (diff_rows > 0) == diff_expected
+        assert st["children2_launches"] + st["children1_launches"] == rounds
+        if diff_expected:
+            assert 0 < st["work_diff_full_runs"] <= st["work_diff_runs"] and st["work_diff_children"] >= 3 * st["work_diff_runs"]
+            assert st["work_win_tiles"] <= st["work_win_pixels"] <= 49 * st["work_win_tiles"]
+            assert 1 <= st["work_full_tiles"] <= 4 * st["children2_launches"]  # (a round whose bases are all cached and that has no single rows evaluates nothing in full)
+        else:
+            assert st["work_copy_children"] >= 3 * st["work_copy_runs"] > 0 and st["work_win_pixels"] == 0
+        eng.reset_stats()
+        assert eng.stats()["work_diff_children"] == 0 and eng.stats()["work_copy_children"] == 0
+        eng.close()
