@@ -60,6 +60,13 @@ struct Net {
     void* d_sib_rows = nullptr; // (request row, run) of the rows inside runs
     int32_t* d_gcnt = nullptr;  // [0] runs, [1] rows outside runs, [2] rows inside runs, [3] full rows (runs + singles), [4] fc0 window tiles,
                                 // [8 + b] children whose window is bin b (SIB_CNT_INTS in all)
+    // Round 6: the fc0 of a sibling round's FULL rows (the runs' bases evaluated this round + the single rows) depends on the base trunk only, not on the children kernel:
+    // it is launched on a side stream behind the base trunk and joins the main stream in front of the window tiles, so that its workgroups take the CUs the persistent
+    // children kernel's workgroups leave at their end (the children hold every CU's LDS: nothing else is resident before that).  side_on = false (the default, see
+    // SIDE_STREAM_DEFAULT below): everything on the main stream.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_base = nullptr, ev_full = nullptr;
+    bool side_on = false;
     unsigned long long* d_work = nullptr; // [NET_WORK_COUNT] executed-work counters summed over the rounds since omok_reset_stats (k_group, k_bin_prefix add; only omok_get_stats reads)
     float* sib_h = nullptr;     // [run][3 blocks][225][32] the base passes' depthwise inputs
     // difference path: a child's fc0 input = its run's base row + a 7x7-window difference row
@@ -138,6 +145,10 @@ bool net_logits_cover_batch(const Net& net, int max_count);
 bool net_round_takes_sibling_path(const Net& net, int max_count);
 constexpr int NET_GCNT_P0 = 8 + 81 + 7 + 16;   // Net::d_gcnt[NET_GCNT_P0 + pixel]: children whose stone lands in net pixel `pixel` (their rows take consecutive slots inside the window bin)
 constexpr int NET_GCNT_INTS = NET_GCNT_P0 + 225; // ints of Net::d_gcnt
+#ifndef SIDE_STREAM_DEFAULT
+#define SIDE_STREAM_DEFAULT 0 // 1: Net::side_on unless OMOK_SIDE_STREAM=0; 0: only with OMOK_SIDE_STREAM=1.  Measured (profiles/r06_ab_side_stream.txt): three plies of configs[1] 0.3152 s off / 0.3145 s on --
+                              // the full rows' fc0 (82 us per round) does start in the children kernel's tail, but the tail is one pass long and the join costs what it saves: off
+#endif
 // Net::d_work: [DIFF + 0..2] runs, single rows, rows in runs of the rounds on the difference path, [COPY + 0..2] the same on the copy path, [DIFF_FULL] runs of the difference
 // path whose base was evaluated in full (base-cache misses + uncacheable runs), [WIN_PIXELS] window pixels the fc0 window tiles walked (tiles x their rectangles),
 // [WIN_TILES] window tiles, [FULL_TILES] 128-row tiles of the full-row fc0

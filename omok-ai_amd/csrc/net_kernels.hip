@@ -3863,6 +3863,13 @@ size_t net_alloc(Net& net) {
             ok = ok && A((void**)&net.d_gcnt, sizeof(int32_t) * SIB_CNT_INTS);
             ok = ok && A((void**)&net.d_work, sizeof(unsigned long long) * NET_WORK_COUNT);
             if (ok) hipMemset(net.d_work, 0, sizeof(unsigned long long) * NET_WORK_COUNT);
+            {
+                const char* e = getenv("OMOK_SIDE_STREAM"); // (A-B runs: 0 = everything on the engine's stream)
+                const bool want = SIDE_STREAM_DEFAULT ? !(e && atoi(e) == 0) : (e && atoi(e) != 0);
+                if (ok && want && hipStreamCreateWithFlags(&net.side, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&net.ev_base, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&net.ev_full, hipEventDisableTiming) == hipSuccess)
+                    net.side_on = true;
+            }
             ok = ok && A((void**)&net.d_sib_rows, sizeof(uint4) * mb);
             net.base_slots = (size_t)SIB_WAYS * net.games + mb / SIB_MIN + 1; // SIB_WAYS slots per game + the other runs a round can hold
             { // V2 children (default; OMOK_SIB_V2=0 or omok_debug_set_children_kernel(1): k_sib_children on the difference path too): a base slot holds 1280 B per pixel instead of 3 h grids
@@ -3899,6 +3906,10 @@ size_t net_alloc(Net& net) {
 }
 
 void net_free(Net& net) {
+    if (net.side) { hipStreamSynchronize(net.side); hipStreamDestroy(net.side); net.side = nullptr; }
+    if (net.ev_base) { hipEventDestroy(net.ev_base); net.ev_base = nullptr; }
+    if (net.ev_full) { hipEventDestroy(net.ev_full); net.ev_full = nullptr; }
+    net.side_on = false;
     if (net.s0_x3 || net.s0_f32) { // (a split-precision engine that has taken the fp32 fallback holds two buffers behind s0)
         net.s0 = nullptr;
         if (net.s0_x3) hipFree(net.s0_x3);
@@ -4287,6 +4298,7 @@ static void launch_trunk_siblings(Net& net, const Store& S, int side, int max_co
     // runs without a cached base -> compact rows [0, misses) + their base slots; then the single rows -> compact rows [misses, misses + singles)
     if (net.n == 9) launch_trunk_fmt<9, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1, v2);
     else launch_trunk_fmt<15, false, 48>(net, S, max_count, st, net.d_singles, net.d_gcnt + 96, nullptr, net.d_gcnt + 1, v2);
+    if (net.side_on) hipEventRecord(net.ev_base, st); // (the full rows' fc0 may start from here: launch_fc0_delta)
     if (v2 && tprof_mode == 2 && !x16 && net.n == 15) {
         static unsigned long long* d_tp = nullptr;
         static unsigned long long acc[32] = {};
@@ -4387,11 +4399,20 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
     const int n_cu = net.n_cu;
     // the live count of full rows is only known on the device: k_bin_prefix chose the K split and the partial slab's row stride (d_gcnt[98], [99])
     const int fgrid = ((tiles_max > n_cu ? tiles_max : n_cu) + 7) / 8 * 8; // (tiles x ways <= CUs by construction unless there are more tiles than CUs: then 1 way; whole eighths: xcd_item)
+    // the full rows' fc0 + its reduction: behind the base trunk on the side stream (Net::side), joined in front of the window tiles
+    hipStream_t fs = net.side_on ? net.side : st;
+    if (net.side_on) hipStreamWaitEvent(net.side, net.ev_base, 0);
+    auto join_side = [&]() {
+        if (!net.side_on) return;
+        hipEventRecord(net.ev_full, net.side);
+        hipStreamWaitEvent(st, net.ev_full, 0);
+    };
     if (net.fc0_fmt == FC0_F16) { // the same four launches on f16 residuals (k_fc0_x3)
         const int lc = (hw % 32) ? (hw % 32) : 1;
-        k_fc0_x3<EPI_PARTIAL, false><<<dim3(fgrid, 1), 256, 0, st>>>((const uint4*)net.wt_fc0x, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32, lc, bias_fc0, nullptr,
+        k_fc0_x3<EPI_PARTIAL, false><<<dim3(fgrid, 1), 256, 0, fs>>>((const uint4*)net.wt_fc0x, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32, lc, bias_fc0, nullptr,
                                                                      cap_rows, net.part, net.d_gcnt + 3, max_count, net.d_gcnt + 98, nullptr, nullptr, net.n);
-        k_facc_reduce<<<512, 256, 0, st>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 98, net.facc, (const uint2*)net.d_comp, net.d_gcnt + 96, (int)net.base_slots);
+        k_facc_reduce<<<512, 256, 0, fs>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 98, net.facc, (const uint2*)net.d_comp, net.d_gcnt + 96, (int)net.base_slots);
+        join_side();
     }
     if (net.fc0_fmt == FC0_F16 && !net.diff_fp6) {
         const int lc = (hw % 32) ? (hw % 32) : 1;
@@ -4406,10 +4427,11 @@ static void launch_fc0_delta(Net& net, int max_count, const MxScales& sc, const 
         return;
     }
     if (net.fc0_fmt != FC0_F16) { // (FC0_MIXED: the full rows went through k_fc0_x3 above; the window tiles below run on fp6 difference rows)
-    k_fc0_mx<EPI_PARTIAL><<<dim3(fgrid, 1), 256, 0, st>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32,
+    k_fc0_mx<EPI_PARTIAL><<<dim3(fgrid, 1), 256, 0, fs>>>((const uint4*)net.wt_fc0, (const uint4*)net.a_fc0, nsup, net.row_u4, hw / 32,
                                                                (hw % 32) ? (hw % 32) : 1, sc, bias_fc0, nullptr, cap_rows, net.part, net.d_gcnt + 3,
                                                                max_count, net.d_gcnt + 98, nullptr, nullptr, net.n);
-    k_facc_reduce<<<512, 256, 0, st>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 98, net.facc, (const uint2*)net.d_comp, net.d_gcnt + 96, (int)net.base_slots);
+    k_facc_reduce<<<512, 256, 0, fs>>>(net.part, cap_rows, net.d_gcnt + 3, net.d_gcnt + 98, net.facc, (const uint2*)net.d_comp, net.d_gcnt + 96, (int)net.base_slots);
+    join_side();
     }
     // window tiles: whole rounds of workgroups at full K, the tiles of the last partial round split over K (k_bin_prefix)
     const int wtiles_max = (tiles_max + SIB_BINS + 1 + 7) / 8 * 8 + 8; // (the XCD-aware tile mapping rounds an eighth of the tiles up)
