@@ -3419,6 +3419,9 @@ __global__ __launch_bounds__(256) void k_fc0_x3(const uint4* __restrict__ wp, co
 // Wp : [ksteps][MT][hi|lo][lane][8] f16 (1 KiB fragments), Act: rows of [ksteps][hi h0|hi h1|lo h0|lo h1]
 // 8 waves: wm = wave>>1 owns MT/4 m-tiles, ws = wave&1 owns 2 of the 4 sample tiles.
 
+#ifndef GEMM_T_TERM_MAJOR
+#define GEMM_T_TERM_MAJOR 1 // the k-step's MFMAs term by term over all the wave's accumulators (0: accumulator by accumulator, three dependent MFMAs in a row)
+#endif
 #ifndef GEMM_T_DB
 #define GEMM_T_DB 0 // (round 6 A-B: 1 = fragments of k-step t + 1 read into a second register set during the MFMAs of k-step t: fc1 + heads 28.5 ms per 150 rounds against 26.8: slower, off)
 #endif
@@ -3587,6 +3590,21 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
             al[i] = L[((wm * MTW + i) * 2 + 1) * 64 + lane];
         }
         if (PRIO) __builtin_amdgcn_s_setprio(1);
+#if GEMM_T_TERM_MAJOR
+        // term-major: the 2 MTW accumulators of the wave take the hi x hi products, then all take lo x hi, then hi x lo -- consecutive MFMAs are independent (a dependent one
+        // is 2 MTW instructions away instead of 2) and every accumulator still sums its three terms in the same order: same bits
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[i][c] = MFMA16(term == 1 ? al[i] : ah[i], term == 2 ? bl[c] : bh[c], acc[i][c]);
+                if (stage && term == 0) {
+#pragma unroll
+                    for (int q = i; q < LPW; q += MTW) issue_one(q, nslot);
+                }
+            }
+#else
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
 #pragma unroll
@@ -3596,6 +3614,7 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
                 for (int q = i; q < LPW; q += MTW) issue_one(q, nslot);
             }
         }
+#endif
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         if (stage) kt += 1;
         slot = slot + 1 == NST ? 0 : slot + 1;
