@@ -1919,6 +1919,9 @@ __global__ __launch_bounds__(512) void k_sib_children2(const uint64_t* __restric
 #endif
     __syncthreads(); // (the only workgroup barrier: from here on a wave touches read-only LDS and its own cells)
     for (int i = 0; i < (wv >> 2); ++i) __builtin_amdgcn_s_sleep(120); // the two waves of a SIMD (w, w + 4) start about half a pass apart
+#ifdef V2_PRIO // (round 6 A-B: static issue priority for one wave of each SIMD's pair -- 1: the younger waves 4..7, 2: the older waves 0..3)
+    if ((V2_PRIO == 1) == (wv >= 4)) __builtin_amdgcn_s_setprio(1);
+#endif
 #if SIB2_EXP == 17 // (diagnostic, results unchanged: every wave's cycles from here to its end -> tprof[workgroup * 8 + wave], summed over the launches)
     const unsigned long long wt0 = __builtin_readcyclecounter();
 #endif
@@ -3671,6 +3674,165 @@ __global__ __launch_bounds__(512) void k_gemm_t(const uint4* __restrict__ wp, co
     }
 }
 
+// ===============================================================================================
+// OMOK_NET_F16X3: the same GEMM with WAVE-PRIVATE weight rings (round 6; fc1 and the heads of whole-K launches)
+// ===============================================================================================
+// k_gemm_t stages a k-step's 40 fragments with all 8 waves and meets at a workgroup barrier per k-step of 16 (24 MFMAs per wave between barriers), and its sample fragments
+// are gathered lane = sample (every lane its own 32-B segment).  Here wave w owns m-tiles [w MT/8, (w + 1) MT/8) for ALL four sample tiles: the weight fragments it
+// consumes (MT/4 per k-step) go through a ring of its own -- 3 k-steps deep, filled by LDS-DMA and ordered by its own counted vmcnt waits, no barrier -- and only the
+// sample operands are shared: a CHUNK of two k-steps (128 samples x 128 contiguous bytes: [k0: hi h0, hi h1, lo h0, lo h1][k1: ...]) per workgroup barrier, triple-buffered,
+// DMA'd with 8 adjacent lanes on the 8 pieces of one sample (whole lines) and XOR-swizzled like k_fc0_mx's sample image so that the MFMA-fragment reads (lane = sample,
+// 128-B stride) are conflict-free.  One barrier per 2 k-steps; the waves of a SIMD are not held in step by the weights.  Every accumulator sums its k-steps in order and its
+// three terms as k_gemm_t does (hi x hi, lo x hi, hi x lo): same bits.
+// vmcnt book-keeping (per wave, issue order): prologue B0 A0 B1 A1 A2; chunk c issues B(c+2) behind its barrier, A(2c+3) inside k-step 2c, A(2c+4) inside k-step 2c+1
+// (indices past the end are clamped: re-reads into slots nobody reads again, so that the counts stay uniform).  At the top of chunk c the younger issues are
+// B(c+1) A(2c+1) A(2c+2); in front of k-step 2c+1 they are A(2c+2) B(c+2) A(2c+3): 2 + 2 AF pieces both times.
+// Measured (profiles/r06_ab_gemm_w.txt, three interleaved A-B pairs of the first three plies of configs[1]): tail group 25.8 -> 26.1 ms per 150 rounds and every OTHER
+// group 1.2 - 1.4 % slower beside it (the package is at its power limit: a kernel that keeps its pipes busier between barriers lowers the clock for its neighbours and
+// gains nothing itself).  Built, bit-identical (tests/test_gpu_tail_gemm.py), default OFF: OMOK_GEMM_W=1 selects it.
+#ifndef GEMM_W
+#define GEMM_W 1 // (0: not even selectable)
+#endif
+constexpr int GW_DA = 3, GW_NB = 3;
+constexpr int gemm_w_lds(int mt) { return (8 * GW_DA * (mt / 8) * 2 + GW_NB * 16) * 1024; }
+template <int MT, int EPI>
+__global__ __launch_bounds__(512) void k_gemm_w(const uint4* __restrict__ wp, const uint4* __restrict__ act, int ksteps, size_t act_row_u4,
+                                                const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
+                                                float* __restrict__ out_logits, const int32_t* __restrict__ d_count, int max_count) {
+    static_assert(MT % 8 == 0 && EPI != EPI_PARTIAL, "k_gemm_w: whole-K launches of at least one m-tile per wave");
+    constexpr int MTW = MT / 8;               // m-tiles per wave
+    constexpr int AF = MTW * 2;               // weight fragments (hi, lo) per wave and k-step
+    constexpr int B_U4 = 128 * 8;             // one sample chunk: [128 samples][8 pieces of 16 B]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int count = d_count[0];
+    if (count > max_count) count = max_count;
+    const int b0 = blockIdx.x * GT_BS;
+    if (b0 >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, sl = lane & 31;
+    uint4* aring = (uint4*)smem + (size_t)wave * (GW_DA * AF * 64);   // this wave's ring: [slot][fragment][lane]
+    uint4* ldsB = (uint4*)smem + (size_t)8 * GW_DA * AF * 64;          // [buffer][sample][piece ^ swizzle]
+    const int nchunks = ksteps >> 1;                                   // (ksteps is even: 32)
+    const uint4* asrc = wp + (size_t)(wave * AF) * 64 + lane;          // + kt * (MT * 2 * 64) + i * 64
+    const uint4* bsrc[2];                                              // this wave's two DMA pieces of a chunk: samples 16 wave + 8 e + (lane >> 3), piece lane & 7
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int s = 16 * wave + 8 * e + (lane >> 3);
+        bsrc[e] = act + (size_t)(b0 + s) * act_row_u4 + (size_t)((lane & 7) ^ ((s >> 1) & 7)); // + chunk * 8
+    }
+    auto issueA = [&](int kt, int slot) {
+        kt = kt < ksteps ? kt : ksteps - 1;
+#pragma unroll
+        for (int i = 0; i < AF; ++i) dma16(asrc + (size_t)kt * (MT * 2 * 64) + i * 64, aring + (slot * AF + i) * 64);
+    };
+    auto issueA1 = [&](int kt, int slot, int i) {
+        kt = kt < ksteps ? kt : ksteps - 1;
+        dma16(asrc + (size_t)kt * (MT * 2 * 64) + i * 64, aring + (slot * AF + i) * 64);
+    };
+    auto issueB = [&](int ch, int buf) {
+        ch = ch < nchunks ? ch : nchunks - 1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) dma16(bsrc[e] + ch * 8, ldsB + buf * B_U4 + (2 * wave + e) * 64);
+    };
+    f32x16 acc[MTW][4];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
+    // read offsets (uint4) of this lane's pieces inside sample tile 0 of a chunk buffer: logical piece kk * 4 + part * 2 + h of sample sl
+    int b_rd[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) b_rd[kk][p] = sl * 8 + ((kk * 4 + p * 2 + h) ^ ((sl >> 1) & 7));
+    issueB(0, 0);
+    issueA(0, 0);
+    issueB(1, 1);
+    issueA(1, 1);
+    issueA(2, 2);
+    int sa = 0, bb = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 2 * AF) : "memory"); // this wave's share of B(c) and its A(2c) have landed
+        __builtin_amdgcn_s_barrier();                                       // every wave's share of B(c) is visible; B(c - 1)'s buffer is free
+        asm volatile("" ::: "memory");
+        issueB(c + 2, bb == 0 ? 2 : bb - 1);
+        const uint4* LB = ldsB + bb * B_U4;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 2 * AF) : "memory"); // A(2c + 1) has landed
+            const uint4* LA = aring + sa * AF * 64 + lane;
+            half8 ah[MTW], al[MTW], bh[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                ah[i] = __builtin_bit_cast(half8, LA[(2 * i) * 64]);
+                al[i] = __builtin_bit_cast(half8, LA[(2 * i + 1) * 64]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bh[ct] = __builtin_bit_cast(half8, LB[ct * 256 + b_rd[kk][0]]);
+                bl[ct] = __builtin_bit_cast(half8, LB[ct * 256 + b_rd[kk][1]]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot's fragments are in registers: its refill may be issued
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int i = 0; i < MTW; ++i) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc[i][ct] = MFMA16(term == 1 ? al[i] : ah[i], term == 2 ? bl[ct] : bh[ct], acc[i][ct]);
+                    if (term == 0) {
+                        issueA1(2 * c + kk + 3, sa, 2 * i);
+                        issueA1(2 * c + kk + 3, sa, 2 * i + 1);
+                    }
+                }
+            sa = sa + 1 == GW_DA ? 0 : sa + 1;
+        }
+        bb = bb + 1 == GW_NB ? 0 : bb + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue (k_gemm_t's, accumulator (i, ct) = m-tile wave * MTW + i, sample tile ct) ----
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int sample = b0 + 32 * ct + sl;
+        if (sample >= count) continue;
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            const int mt = wave * MTW + i;
+            float y[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *(const f32x4*)(bias + 32 * mt + 8 * g + 4 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[4 * g + q] = acc[i][ct][4 * g + q] + bv[q];
+            }
+            if (EPI == EPI_SPLIT) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = lrelu(y[8 * s + j]);
+                    half8 hi, lo;
+                    split8(v, hi, lo);
+                    uint4* row = out_split + (size_t)sample * out_row_u4 + (size_t)(2 * mt + s) * 4;
+                    row[h] = *(const uint4*)&hi;
+                    row[2 + h] = *(const uint4*)&lo;
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = y[4 * g + q];
+                    *(f32x4*)(out_logits + (size_t)sample * (MT * 32) + 32 * mt + 8 * g + 4 * h) = o;
+                }
+            }
+        }
+    }
+}
+
 // split-K finish: sums the partials in split order (deterministic), + bias, LeakyReLU, writes the hi|lo operand row
 __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ part, int nsplit, size_t cap_rows,
                                                        const float* __restrict__ bias, uint4* __restrict__ out_split, size_t out_row_u4,
@@ -4211,6 +4373,21 @@ static void launch_gemm(const void* wp, const void* act, int ksteps, size_t act_
                                   out_row_u4, out_logits, S.d_count, max_count);
 }
 
+template <int MT, int EPI>
+static void launch_gemm_w(const void* wp, const void* act, int ksteps, size_t act_row_u4, const float* bias, void* out_split, size_t out_row_u4, float* out_logits,
+                          const Store& S, int max_count, hipStream_t st, int device) {
+    constexpr int LDS = gemm_w_lds(MT);
+    static_assert(LDS <= 160 * 1024, "k_gemm_w LDS");
+    static bool attr_done[64] = {};
+    auto kern = k_gemm_w<MT, EPI>;
+    if (!attr_done[device & 63]) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_done[device & 63] = true;
+    }
+    kern<<<dim3((max_count + GT_BS - 1) / GT_BS), 512, LDS, st>>>((const uint4*)wp, (const uint4*)act, ksteps, act_row_u4, bias, (uint4*)out_split, out_row_u4, out_logits,
+                                                                 S.d_count, max_count);
+}
+
 // K splits of the difference path's fc0 launches (chosen on the device, k_bin_prefix): the full rows up to 30 ways as far as the
 // partial slab holds ways x (the launch's row capacity); window tiles of the split set up to 14 ways (7 super-steps each)
 constexpr int SIB_MAX_WWAYS = 14;
@@ -4621,12 +4798,19 @@ static void forward_f16x3(Net& net, const Store& S, int max_count, bool from_f32
     const size_t fin_threads = (size_t)max_count * 64;
     if (tsplit == 1) {
         static const int rep_fc1 = repeat_env("OMOK_REPEAT_FC1"), rep_heads = repeat_env("OMOK_REPEAT_HEADS");
-        for (int r = 0; r < rep_fc1; ++r)
-        launch_gemm<16, EPI_SPLIT, 1, FC1_NST, TAIL_PRIO>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st, net.device);
-        for (int r = 1; r < rep_heads; ++r)
-            if (MT == 8) launch_gemm<8, EPI_LOGITS, 2, HEADS_NST, TAIL_PRIO>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
-        if (MT == 8) launch_gemm<8, EPI_LOGITS, 2, HEADS_NST, TAIL_PRIO>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
-        else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
+        // whole-K launches: k_gemm_t; OMOK_GEMM_W=1 selects k_gemm_w (wave-private weight rings, one barrier per two k-steps; same bits, measured no faster: see the
+        // kernel) for A-B runs and the test that compares the two kernels' outputs bit for bit; the N = 9 heads (4 m-tiles: less than one per wave) stay on k_gemm_t
+        const char* gw_env = getenv("OMOK_GEMM_W");
+        const bool gw = GEMM_W && gw_env && gw_env[0] == '1';
+        for (int r = 0; r < rep_fc1; ++r) {
+            if (gw) launch_gemm_w<16, EPI_SPLIT>(net.wt_fc1, h0, 32, 128, bias_fc1, h1, 128, nullptr, S, max_count, st, net.device);
+            else launch_gemm<16, EPI_SPLIT, 1, FC1_NST, TAIL_PRIO>(net.wt_fc1, h0, 32, 128, 32, 1, 2, bias_fc1, h1, 128, nullptr, S, max_count, st, net.device);
+        }
+        for (int r = 0; r < rep_heads; ++r) {
+            if (MT == 8 && gw) launch_gemm_w<8, EPI_LOGITS>(net.wt_heads, h1, 32, 128, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
+            else if (MT == 8) launch_gemm<8, EPI_LOGITS, 2, HEADS_NST, TAIL_PRIO>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
+            else launch_gemm<4, EPI_LOGITS, 2>(net.wt_heads, h1, 32, 128, 32, 1, 2, bias_heads, nullptr, 0, net.s0, S, max_count, st, net.device);
+        }
     } else {
         launch_gemm<16, EPI_PARTIAL, 1>(net.wt_fc1, h0, 32 / tsplit, 128, 32, 1, 2, bias_fc1, nullptr, cap_t, net.part, S, max_count, st, net.device, tsplit);
         k_splitk_finish<<<(unsigned)((fin_threads + 255) / 256), 256, 0, st>>>(net.part, tsplit, cap_t, bias_fc1, h1, 128, S.d_count, max_count);
