@@ -1,4 +1,5 @@
 #!/bin/bash
+# (SB2_LINES / SB2_ABL are the switches of docs/experiments/r06_base_slot_whole_line_stores.diff: apply it before building the variants)
 # timing-only: what the BASE pass's stores cost (SB2_ABL builds; mixed format forced so that the commit probe does not fall back on the wrong rows)
 R=$PWD; cd /tmp; export TMPDIR=/tmp; mkdir -p $R/gpurun_out/sb2
 for v in "$@"; do

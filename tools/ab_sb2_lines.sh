@@ -1,4 +1,5 @@
 #!/bin/bash
+# (SB2_LINES / SB2_ABL are the switches of docs/experiments/r06_base_slot_whole_line_stores.diff: apply it before building the variants)
 # A-B of the BASE pass's base-slot stores (SB2_LINES: whole lines through the halo grid / 0: lane-per-pixel pieces): parity tests of the product build first, then
 # three interleaved pairs of the first 3 plies of configs[1] (tools/ab_lib.py), then the kernel's own time by rocprofv3 for both builds
 set -o pipefail
